@@ -1,0 +1,70 @@
+"""ctypes binding of libdrt_hip.so (C ABI in include/drt_hip.h).
+
+There is no CPU or PyTorch fallback: if the HIP library has not been built, or no
+GPU is visible, the calls raise.  Build with ``python __graft_entry__.py`` (or
+``make -C drt_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrt_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I64 = _c.c_int64
+_D = _c.c_double
+
+# name -> (restype, argtypes); must list every function declared in include/drt_hip.h
+SIGNATURES = {
+    "drt_last_error": (_c.c_char_p, []),
+    "drt_version": (_c.c_int, []),
+    "drt_create": (_c.c_int, [_c.c_int, _c.POINTER(_P)]),
+    "drt_destroy": (None, [_P]),
+    "drt_update_mesh": (_c.c_int, [_P, _P, _I64, _P, _I64, _P]),
+    "drt_update_vert": (_c.c_int, [_P, _P, _I64, _P]),
+    "drt_update_vert_f64": (_c.c_int, [_P, _P, _I64, _P]),
+    "drt_intersect": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "drt_intersect_any": (_c.c_int, [_P, _P, _I64, _P, _P]),
+    "drt_intersect_bruteforce": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "drt_bvh_check": (_c.c_int, [_P, _P, _c.POINTER(_I64), _c.POINTER(_c.c_int32)]),
+    "drt_bvh_sorted_faces": (_c.c_int, [_P, _P, _P]),
+    "drt_render_forward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P]),
+    "drt_render_backward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P]),
+    "drt_ray_loss": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "drt_render_ray_loss_fused": (_c.c_int, [_P, _P, _P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class DrtError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises DrtError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DrtError(f"{LIB_PATH} not found: the HIP extension is not built "
+                           "(run `python __graft_entry__.py`); there is no CPU fallback")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DrtError(f"libdrt_hip error {rc}: {lib().drt_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

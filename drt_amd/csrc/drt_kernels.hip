@@ -1,0 +1,702 @@
+// drt_kernels.hip -- gfx950 kernels and the C ABI of libdrt_hip.so (include/drt_hip.h).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// Wave size is 64 throughout.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/drt_hip.h"
+#include "drt_common.h"
+#include "drt_lbvh.h"
+#include "drt_path.h"
+#include "drt_shade.h"
+#include "drt_traverse.h"
+#include "drt_tri.h"
+
+using namespace drt;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(DRT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// scene object
+// ------------------------------------------------------------------------------------------
+constexpr int kTraceBlock = 128;       // threads per block in traversal kernels (2 waves)
+constexpr int kStackFast = 32;         // LDS stack entries per lane
+constexpr int kStackSlowDev = 32;      // global overflow entries per thread (height <= 30 + log2 F)
+constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (grid-stride beyond)
+
+constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
+
+struct BuildParams {   // written by k_bounds, read by the later build kernels
+    float lox, loy, loz;
+    float ix, iy, iz;   // 1 / extent per axis (0 extent -> 0)
+    float pad;
+    int32_t reserved;
+};
+
+struct drt_scene {
+    int device = 0;
+    int64_t n_faces = 0, n_verts = 0;
+    int64_t cap_faces = 0, cap_verts = 0;
+    int32_t* faces = nullptr;      // [F,3] copy
+    float* verts = nullptr;        // [V,3] float32 copy (tracer precision)
+    Node* nodes = nullptr;         // [max(F-1,1)]
+    TriRec* tris = nullptr;        // [F] Morton order
+    uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
+    uint32_t* hist = nullptr;      // [kRadix * tiles]
+    int32_t *parent_inner = nullptr, *parent_leaf = nullptr;
+    uint32_t* flags = nullptr;
+    BuildParams* params = nullptr;
+    int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev]
+    unsigned long long* scratch = nullptr;  // small counters
+    bool built = false;
+};
+
+static void scene_free_mesh(drt_scene* s) {
+    (void)hipFree(s->faces); (void)hipFree(s->verts); (void)hipFree(s->nodes); (void)hipFree(s->tris);
+    (void)hipFree(s->keys[0]); (void)hipFree(s->keys[1]); (void)hipFree(s->idx[0]); (void)hipFree(s->idx[1]);
+    (void)hipFree(s->hist); (void)hipFree(s->parent_inner); (void)hipFree(s->parent_leaf); (void)hipFree(s->flags);
+    s->faces = nullptr; s->verts = nullptr; s->nodes = nullptr; s->tris = nullptr;
+    s->keys[0] = s->keys[1] = s->idx[0] = s->idx[1] = nullptr;
+    s->hist = nullptr; s->parent_inner = s->parent_leaf = nullptr; s->flags = nullptr;
+    s->cap_faces = s->cap_verts = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// build kernels
+// ------------------------------------------------------------------------------------------
+__global__ void k_cast_verts(const double* __restrict__ v64, float* __restrict__ v32, int64_t n3) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x)
+        v32[i] = (float)v64[i];
+}
+
+// One block: scene box over all vertices -> Morton normalisation + leaf padding.
+__global__ void __launch_bounds__(1024) k_bounds(const float* __restrict__ verts, int64_t n_verts, BuildParams* out) {
+    __shared__ float red[6][16];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = threadIdx.x; i < n_verts; i += blockDim.x) {
+        for (int a = 0; a < 3; ++a) {
+            const float v = verts[3 * i + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; ++w)
+            for (int a = 0; a < 3; ++a) {
+                red[a][0] = fminf(red[a][0], red[a][w]);
+                red[3 + a][0] = fmaxf(red[3 + a][0], red[3 + a][w]);
+            }
+        const float ex = red[3][0] - red[0][0], ey = red[4][0] - red[1][0], ez = red[5][0] - red[2][0];
+        out->lox = red[0][0]; out->loy = red[1][0]; out->loz = red[2][0];
+        out->ix = ex > 0.f ? 1.0f / ex : 0.f;
+        out->iy = ey > 0.f ? 1.0f / ey : 0.f;
+        out->iz = ez > 0.f ? 1.0f / ez : 0.f;
+        out->pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
+        out->reserved = 0;
+    }
+}
+
+__device__ __forceinline__ f3 ld_vert(const float* __restrict__ verts, int32_t i) {
+    return f3{verts[3 * (int64_t)i], verts[3 * (int64_t)i + 1], verts[3 * (int64_t)i + 2]};
+}
+
+__global__ void k_morton(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n,
+                         const BuildParams* __restrict__ bp, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 a = ld_vert(verts, faces[3 * i]), b = ld_vert(verts, faces[3 * i + 1]), c = ld_vert(verts, faces[3 * i + 2]);
+    keys[i] = morton30(a, b, c, f3{bp->lox, bp->loy, bp->loz}, f3{bp->ix, bp->iy, bp->iz});
+    idx[i] = (uint32_t)i;
+}
+
+// ---- LSD radix sort, 8 bits per pass, stable; three launches per pass -------------------
+__global__ void __launch_bounds__(kSortBlock) k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift,
+                                                          uint32_t* __restrict__ hist, int tiles) {
+    __shared__ uint32_t cnt[kRadix];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = base + r * kSortBlock + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * tiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// Exclusive scan of hist[0..total) in place, one block of 1024 threads.
+__global__ void __launch_bounds__(1024) k_sort_scan(uint32_t* __restrict__ hist, int total) {
+    __shared__ uint32_t part[1024];
+    const int chunk = (total + 1023) / 1024;
+    const int b = threadIdx.x * chunk, e = min(b + chunk, total);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += hist[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int i = b; i < e; ++i) {
+        const uint32_t h = hist[i];
+        hist[i] = run;
+        run += h;
+    }
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                             int n, int shift, const uint32_t* __restrict__ hist, int tiles) {
+    constexpr int kWaves = kSortBlock / 64;
+    __shared__ uint32_t running[kRadix];
+    __shared__ uint32_t wcount[kWaves][kRadix];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    running[tid] = hist[tid * tiles + blockIdx.x];
+    for (int w = 0; w < kWaves; ++w) wcount[w][tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = base + r * kSortBlock + tid;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t val = valid ? idx_in[i] : 0u;
+        const uint32_t digit = (key >> shift) & (kRadix - 1);
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool set = (digit >> bit) & 1u;
+            const unsigned long long bm = __ballot(valid && set);
+            peers &= set ? bm : ~bm;
+        }
+        const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcount[wave][digit] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[digit] + rank;
+            for (int w = 0; w < wave; ++w) pos += wcount[w][digit];
+            keys_out[pos] = key;
+            idx_out[pos] = val;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < kWaves; ++w) { add += wcount[w][tid]; wcount[w][tid] = 0; }
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+// ---- hierarchy ---------------------------------------------------------------------------
+__global__ void k_hierarchy(const uint32_t* __restrict__ keys, int n, Node* __restrict__ nodes,
+                            int32_t* __restrict__ parent_inner, int32_t* __restrict__ parent_leaf,
+                            uint32_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) parent_inner[0] = -1;
+    if (n == 1) {   // degenerate: one triangle under a root whose second child is an empty box
+        if (i == 0) {
+            Node nd;
+            node_set_child_box(nd, 0, box_empty());
+            node_set_child_box(nd, 1, box_empty());
+            nd.child0 = ~0; nd.child1 = ~0; nd.pad0 = nd.pad1 = 0;
+            nodes[0] = nd;
+            parent_leaf[0] = 0;
+            flags[0] = 1;   // the single leaf is the "second" arrival: it stops at the root
+        }
+        return;
+    }
+    if (i >= n - 1) return;
+    int32_t l, r;
+    lbvh_children(keys, n, i, l, r);
+    nodes[i].child0 = l; nodes[i].child1 = r; nodes[i].pad0 = 0; nodes[i].pad1 = 0;
+    if (l >= 0) parent_inner[l] = i * 2 + 0; else parent_leaf[~l] = i * 2 + 0;
+    if (r >= 0) parent_inner[r] = i * 2 + 1; else parent_leaf[~r] = i * 2 + 1;
+    flags[i] = 0;
+}
+
+__device__ __forceinline__ void store_child_box(Node* nodes, int parent, int slot, Box b) {
+    float* f = reinterpret_cast<float*>(nodes + parent);
+    if (slot == 0) {
+        f[0] = b.lox; f[1] = b.hix; f[2] = b.loy; f[3] = b.hiy; f[8] = b.loz; f[9] = b.hiz;
+    } else {
+        f[4] = b.lox; f[5] = b.hix; f[6] = b.loy; f[7] = b.hiy; f[10] = b.loz; f[11] = b.hiz;
+    }
+}
+
+// One thread per leaf: write the triangle record, then carry boxes towards the root.  The
+// second thread to arrive at a node owns it.  Hand-off between workgroups is the
+// agent-scope release -> counter -> acquire form (MI355X: per-XCD L2s and per-CU L1s are
+// not coherent): plain stores, release fence, drained, relaxed agent atomic; the taker
+// issues one agent acquire before its plain loads.
+__global__ void k_refit(const uint32_t* __restrict__ sorted_idx, const int32_t* __restrict__ faces,
+                        const float* __restrict__ verts, int n, BuildParams* bp, TriRec* __restrict__ tris,
+                        Node* nodes, const int32_t* __restrict__ parent_inner,
+                        const int32_t* __restrict__ parent_leaf, uint32_t* flags) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t face = (int32_t)sorted_idx[k];
+    const f3 a = ld_vert(verts, faces[3 * face]), b = ld_vert(verts, faces[3 * face + 1]), c = ld_vert(verts, faces[3 * face + 2]);
+    tris[k] = make_tri(a, b, c, face);
+    Box box = box_of_tri(a, b, c, bp->pad);
+    int32_t link = parent_leaf[k];
+    while (link >= 0) {
+        const int p = link >> 1, slot = link & 1;
+        store_child_box(nodes, p, slot, box);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const Node* np = nodes + p;
+        const volatile float* f = reinterpret_cast<const volatile float*>(np);
+        Box sib;
+        if (slot == 0) { sib = Box{f[4], f[6], f[10], f[5], f[7], f[11]}; }
+        else { sib = Box{f[0], f[2], f[8], f[1], f[3], f[9]}; }
+        box = box_union(box, sib);
+        link = parent_inner[p];
+    }
+}
+
+// Diagnostic: every ancestor's child box must enclose the padded box of leaf k.
+__global__ void k_bvh_check(const TriRec* __restrict__ tris, int n, const BuildParams* __restrict__ bp,
+                            const Node* __restrict__ nodes, const int32_t* __restrict__ parent_inner,
+                            const int32_t* __restrict__ parent_leaf, unsigned long long* violations) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const TriRec t = tris[k];
+    const f3 a{t.v0x, t.v0y, t.v0z};
+    // e1/e2 were rounded from b - a; rebuild the leaf box conservatively from a, a+e1, a+e2
+    const f3 b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, c{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+    const Box leaf = box_of_tri(a, b, c, 0.5f * bp->pad);
+    int32_t link = parent_leaf[k];
+    int32_t child_expect = ~k;
+    unsigned long long bad = 0, depth = 0;
+    while (link >= 0) {
+        ++depth;
+        const int p = link >> 1, slot = link & 1;
+        const Node nd = nodes[p];
+        if ((slot == 0 ? nd.child0 : nd.child1) != child_expect) ++bad;
+        if (!box_contains(node_child_box(nd, slot), leaf)) ++bad;
+        child_expect = p;
+        link = parent_inner[p];
+    }
+    if (child_expect != 0 && n > 1) ++bad;   // must end at the root
+    if (bad) atomicAdd(violations, bad);
+    atomicMax(violations + 1, depth);   // tree height = deepest leaf
+}
+
+// ------------------------------------------------------------------------------------------
+// traversal kernels
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ Stack make_stack(int32_t (*lds)[kTraceBlock], const TraceCtx& c) {
+    Stack st;
+    st.fast = &lds[0][threadIdx.x];
+    st.stride = kTraceBlock;
+    st.depth_fast = kStackFast;
+    st.slow = c.slow_stack + ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * kStackSlowDev;
+    st.sp = 0;
+    return st;
+}
+
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_intersect(TraceCtx c, const float* __restrict__ rays, int64_t n,
+                                                            float* __restrict__ T, int32_t* __restrict__ ID,
+                                                            uint8_t* __restrict__ hitflag) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        const f3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+        const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, o, d, st);
+        if (ANY) {
+            hitflag[i] = h.face >= 0 ? 1 : 0;
+        } else {
+            T[i] = h.t;
+            ID[i] = h.face;
+        }
+    }
+}
+
+// Brute force over every triangle with the same test: the GPU-side checker of the traversal.
+__global__ void __launch_bounds__(256) k_bruteforce(const TriRec* __restrict__ tris, int n_tris, const float* __restrict__ rays,
+                                                    int64_t n, float* __restrict__ T, int32_t* __restrict__ ID) {
+    __shared__ TriRec tile[256];
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    f3 o{0, 0, 0}, d{0, 0, 1};
+    if (live) { o = f3{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}; d = f3{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]}; }
+    float best = INFINITY;
+    int32_t best_face = -1;
+    for (int j0 = 0; j0 < n_tris; j0 += 256) {
+        __syncthreads();
+        if (j0 + (int)threadIdx.x < n_tris) tile[threadIdx.x] = tris[j0 + threadIdx.x];
+        __syncthreads();
+        const int m = min(256, n_tris - j0);
+        for (int j = 0; j < m; ++j) {
+            const TriRec t = tile[j];
+            float tt;
+            if (tri_hit(o, d, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) {
+                if (tt < best || (tt == best && t.face < best_face)) { best = tt; best_face = t.face; }
+            }
+        }
+    }
+    if (live) { T[i] = best_face >= 0 ? best : -1.0f; ID[i] = best_face; }
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_render_fwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                             int64_t n, double* __restrict__ out_ori, double* __restrict__ out_dir,
+                                                             uint8_t* __restrict__ mask, int32_t* __restrict__ face1, int32_t* __restrict__ face2) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c.tc);
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+        int32_t f1, f2;
+        d3 eo{0.0, 0.0, 0.0}, ed{0.0, 0.0, 0.0};
+        const bool ok = trace_path(c, st, o, d, f1, f2, eo, ed);
+        const d3 z{0.0, 0.0, 0.0};
+        store_d3(out_ori, i, ok ? eo : z);
+        store_d3(out_dir, i, ok ? ed : z);
+        const uint8_t m = ok ? 1 : 0;
+        mask[3 * i] = m; mask[3 * i + 1] = m; mask[3 * i + 2] = m;
+        face1[i] = f1;
+        face2[i] = f2;
+    }
+}
+
+struct AtomicAdd3 {
+    double* g;
+    __device__ __forceinline__ void operator()(int32_t v, d3 a) const {
+        unsafeAtomicAdd(g + 3 * (int64_t)v + 0, a.x);
+        unsafeAtomicAdd(g + 3 * (int64_t)v + 1, a.y);
+        unsafeAtomicAdd(g + 3 * (int64_t)v + 2, a.z);
+    }
+};
+
+__global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir, int64_t n,
+                                                    const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
+                                                    const double* __restrict__ g_out_ori, const double* __restrict__ g_out_dir,
+                                                    double* grad_verts) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t f2 = face2[i];
+        if (f2 < 0) continue;
+        const int32_t f1 = face1[i];
+        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+        const d3 z{0.0, 0.0, 0.0};
+        const d3 g_ori = g_out_ori ? load_d3(g_out_ori, i) : z;
+        const d3 g_dir = g_out_dir ? load_d3(g_out_dir, i) : z;
+        path_recompute_backward(c, o, d, f1, f2, g_ori, g_dir, AtomicAdd3{grad_verts});
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_ray_loss(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
+                                                  const uint8_t* __restrict__ mask, const double* __restrict__ screen_pixel,
+                                                  const uint8_t* __restrict__ valid, int64_t n, double* loss,
+                                                  double* __restrict__ g_out_dir) {
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        d3 g{0.0, 0.0, 0.0};
+        if (valid[i] && mask[3 * i]) acc += ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g);
+        if (g_out_dir) store_d3(g_out_dir, i, g);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_render_loss_fused(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                                    const double* __restrict__ screen_pixel, const uint8_t* __restrict__ valid,
+                                                                    int64_t n, double* loss, double* grad_verts, unsigned long long* n_valid) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c.tc);
+    double acc = 0.0;
+    unsigned cnt = 0;
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        if (!valid[i]) continue;   // the loss ignores these pixels (reference optim.py:105), so does the trace
+        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+        int32_t f1, f2;
+        d3 eo, ed;
+        if (!trace_path(c, st, o, d, f1, f2, eo, ed)) continue;
+        d3 g_dir;
+        acc += ray_loss_term(eo, ed, load_d3(screen_pixel, i), g_dir);
+        ++cnt;
+        path_recompute_backward(c, o, d, f1, f2, d3{0.0, 0.0, 0.0}, g_dir, AtomicAdd3{grad_verts});
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+    if (n_valid && cnt) atomicAdd(n_valid, (unsigned long long)cnt);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int grid_for(int64_t n, int block, int cap) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+static int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
+    if (n_faces <= s->cap_faces && n_verts <= s->cap_verts) return DRT_OK;
+    scene_free_mesh(s);
+    const int64_t F = n_faces > 0 ? n_faces : 1, V = n_verts > 0 ? n_verts : 1;
+    const int64_t tiles = (F + kSortTile - 1) / kSortTile;
+    HIP_TRY(hipMalloc(&s->faces, sizeof(int32_t) * 3 * F));
+    HIP_TRY(hipMalloc(&s->verts, sizeof(float) * 3 * V));
+    HIP_TRY(hipMalloc(&s->nodes, sizeof(Node) * F));
+    HIP_TRY(hipMalloc(&s->tris, sizeof(TriRec) * F));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc(&s->keys[k], sizeof(uint32_t) * F));
+        HIP_TRY(hipMalloc(&s->idx[k], sizeof(uint32_t) * F));
+    }
+    HIP_TRY(hipMalloc(&s->hist, sizeof(uint32_t) * kRadix * tiles));
+    HIP_TRY(hipMalloc(&s->parent_inner, sizeof(int32_t) * F));
+    HIP_TRY(hipMalloc(&s->parent_leaf, sizeof(int32_t) * F));
+    HIP_TRY(hipMalloc(&s->flags, sizeof(uint32_t) * F));
+    s->cap_faces = F;
+    s->cap_verts = V;
+    return DRT_OK;
+}
+
+static int rebuild(drt_scene* s, hipStream_t st) {
+    const int n = (int)s->n_faces;
+    s->built = true;
+    if (n == 0) return DRT_OK;
+    k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params);
+    k_morton<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->params, s->keys[0], s->idx[0]);
+    const int tiles = (n + kSortTile - 1) / kSortTile;
+    int cur = 0;
+    for (int shift = 0; shift < 30; shift += 8) {
+        k_sort_hist<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], n, shift, s->hist, tiles);
+        k_sort_scan<<<1, 1024, 0, st>>>(s->hist, kRadix * tiles);
+        k_sort_scatter<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], s->idx[cur], s->keys[cur ^ 1], s->idx[cur ^ 1], n, shift, s->hist, tiles);
+        cur ^= 1;
+    }
+    // four passes -> result is back in buffer 0
+    const int inner = n > 1 ? n - 1 : 1;
+    k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags);
+    k_refit<<<(n + 255) / 256, 256, 0, st>>>(s->idx[cur], s->faces, s->verts, n, s->params, s->tris, s->nodes,
+                                             s->parent_inner, s->parent_leaf, s->flags);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+static TraceCtx trace_ctx(const drt_scene* s) { return TraceCtx{s->nodes, s->tris, (int)s->n_faces, s->slow_stack}; }
+
+#define CHECK_SCENE(s)                                                        \
+    do {                                                                      \
+        if (!(s)) return fail(DRT_E_INVALID, "null scene");                   \
+        HIP_TRY(hipSetDevice((s)->device));                                   \
+    } while (0)
+#define CHECK_BUILT(s)                                                                          \
+    do {                                                                                        \
+        CHECK_SCENE(s);                                                                         \
+        if (!(s)->built) return fail(DRT_E_INVALID, "no mesh: call drt_update_mesh first");     \
+    } while (0)
+
+extern "C" {
+
+const char* drt_last_error(void) { return g_err; }
+int drt_version(void) { return 1; }
+
+int drt_create(int device, drt_scene_t** out) {
+    if (!out) return fail(DRT_E_INVALID, "out is null");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(DRT_E_INVALID, "device %d out of range (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    drt_scene* s = new (std::nothrow) drt_scene();
+    if (!s) return fail(DRT_E_NOMEM, "host allocation failed");
+    s->device = device;
+    hipError_t e = hipMalloc(&s->params, sizeof(BuildParams));
+    if (e == hipSuccess) e = hipMalloc(&s->slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
+    if (e == hipSuccess) e = hipMalloc(&s->scratch, sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) {
+        drt_destroy(s);
+        return fail(DRT_E_HIP, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return DRT_OK;
+}
+
+void drt_destroy(drt_scene_t* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    scene_free_mesh(s);
+    (void)hipFree(s->params);
+    (void)hipFree(s->slow_stack);
+    (void)hipFree(s->scratch);
+    delete s;
+}
+
+int drt_update_mesh(drt_scene_t* s, const int32_t* d_faces, int64_t n_faces, const float* d_verts, int64_t n_verts, void* stream) {
+    CHECK_SCENE(s);
+    if (n_faces < 0 || n_verts < 0 || (n_faces && !d_faces) || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "bad mesh arguments");
+    if (n_faces > (int64_t)1 << 30) return fail(DRT_E_INVALID, "too many faces");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_capacity(s, n_faces, n_verts);
+    if (rc) return rc;
+    s->n_faces = n_faces;
+    s->n_verts = n_verts;
+    if (n_faces) HIP_TRY(hipMemcpyAsync(s->faces, d_faces, sizeof(int32_t) * 3 * n_faces, hipMemcpyDeviceToDevice, st));
+    if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
+    return rebuild(s, st);
+}
+
+int drt_update_vert(drt_scene_t* s, const float* d_verts, int64_t n_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_verts != s->n_verts || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "vertex count %lld != %lld", (long long)n_verts, (long long)s->n_verts);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
+    return rebuild(s, st);
+}
+
+int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_verts != s->n_verts || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "vertex count %lld != %lld", (long long)n_verts, (long long)s->n_verts);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_verts) k_cast_verts<<<grid_for(3 * n_verts, 256, 1024), 256, 0, st>>>(d_verts, s->verts, 3 * n_verts);
+    return rebuild(s, st);
+}
+
+int drt_intersect(drt_scene_t* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || (n_rays && (!d_rays || !d_T || !d_ID))) return fail(DRT_E_INVALID, "bad ray arguments");
+    if (n_rays == 0) return DRT_OK;
+    k_intersect<false><<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, d_T, d_ID, nullptr);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_intersect_any(drt_scene_t* s, const float* d_rays, int64_t n_rays, uint8_t* d_hit, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || (n_rays && (!d_rays || !d_hit))) return fail(DRT_E_INVALID, "bad ray arguments");
+    if (n_rays == 0) return DRT_OK;
+    k_intersect<true><<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, nullptr, nullptr, d_hit);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || (n_rays && (!d_rays || !d_T || !d_ID))) return fail(DRT_E_INVALID, "bad ray arguments");
+    if (n_rays == 0) return DRT_OK;
+    k_bruteforce<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(s->tris, (int)s->n_faces, d_rays, n_rays, d_T, d_ID);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height) {
+    CHECK_BUILT(s);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long v[2] = {0, 0};
+    if (s->n_faces) {
+        HIP_TRY(hipMemsetAsync(s->scratch, 0, 2 * sizeof(unsigned long long), st));
+        const int n = (int)s->n_faces;
+        k_bvh_check<<<(n + 255) / 256, 256, 0, st>>>(s->tris, n, s->params, s->nodes, s->parent_inner, s->parent_leaf, s->scratch);
+        HIP_TRY(hipMemcpyAsync(v, s->scratch, sizeof(v), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (n_violations) *n_violations = (int64_t)v[0];
+    if (height) *height = (int32_t)v[1];
+    return DRT_OK;
+}
+
+int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream) {
+    CHECK_BUILT(s);
+    if (s->n_faces && !d_order) return fail(DRT_E_INVALID, "d_order is null");
+    if (s->n_faces) HIP_TRY(hipMemcpyAsync(d_order, s->idx[0], sizeof(int32_t) * s->n_faces, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DRT_OK;
+}
+
+static PathCtx path_ctx(const drt_scene* s, const double* d_verts, double ior_int, double ior_ext) {
+    return PathCtx{trace_ctx(s), s->faces, d_verts, ior_int, ior_ext};
+}
+
+int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                       double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
+                       int32_t* d_face1, int32_t* d_face2, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
+    k_render_fwd<<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(
+        path_ctx(s, d_verts, ior_int, ior_ext), d_origin, d_dir, n_rays, d_out_ori, d_out_dir, d_mask, d_face1, d_face2);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                        double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                        const double* d_grad_out_ori, const double* d_grad_out_dir, double* d_grad_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
+    if (n_rays == 0 || (!d_grad_out_ori && !d_grad_out_dir)) return DRT_OK;
+    if (!d_verts || !d_origin || !d_dir || !d_face1 || !d_face2 || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    k_render_bwd<<<grid_for(n_rays, 256, 8192), 256, 0, (hipStream_t)stream>>>(
+        path_ctx(s, d_verts, ior_int, ior_ext), d_origin, d_dir, n_rays, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t* d_mask, const double* d_screen_pixel,
+                 const uint8_t* d_valid, int64_t n_rays, double* d_loss, double* d_grad_out_dir, void* stream) {
+    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_out_ori || !d_out_dir || !d_mask || !d_screen_pixel || !d_valid || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
+    k_ray_loss<<<grid_for(n_rays, 256, 4096), 256, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays, d_loss, d_grad_out_dir);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir,
+                              const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays, double ior_int,
+                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    k_render_loss_fused<<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(
+        path_ctx(s, d_verts, ior_int, ior_ext), d_origin, d_dir, d_screen_pixel, d_valid, n_rays, d_loss, d_grad_verts,
+        reinterpret_cast<unsigned long long*>(d_n_valid));
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+}  // extern "C"

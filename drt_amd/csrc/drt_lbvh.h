@@ -1,0 +1,129 @@
+// drt_lbvh.h -- per-item bodies of the on-GPU LBVH build (Morton code, Karras
+// radix-tree hierarchy) and the node layout the traversal reads.
+//
+// Replaces the acceleration-structure build the reference gets from OptiX Prime
+// (`model->setTriangles` + `model->update`, reference optix_extend.cpp:61-67),
+// which it re-runs on every `update_vert` (optix_extend.cpp:23-27), i.e. every
+// optimisation iteration (reference DiffRender.py:380, optim.py:203).
+//
+// The hierarchy only decides WHICH triangles a ray is tested against; results are
+// defined by drt_tri.h.  Child boxes are padded (see pad_for_extent) so that box
+// culling can never drop a triangle the float32 test would accept.
+#pragma once
+#include "drt_common.h"
+#include "drt_tri.h"
+
+namespace drt {
+
+// Inner node, 64 bytes = four 16-byte loads.  Both child boxes live in the parent so
+// one fetch decides both descents.  child >= 0: inner node index; child < 0: leaf,
+// triangle slot = ~child (slots are in Morton order).
+struct Node {
+    float c0lox, c0hix, c0loy, c0hiy;
+    float c1lox, c1hix, c1loy, c1hiy;
+    float c0loz, c0hiz, c1loz, c1hiz;
+    int32_t child0, child1, pad0, pad1;
+};
+
+struct Box {
+    float lox, loy, loz, hix, hiy, hiz;
+};
+
+DRT_HD Box box_empty() { return {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}; }
+DRT_HD Box box_union(Box a, Box b) {
+    return {fminf(a.lox, b.lox), fminf(a.loy, b.loy), fminf(a.loz, b.loz),
+            fmaxf(a.hix, b.hix), fmaxf(a.hiy, b.hiy), fmaxf(a.hiz, b.hiz)};
+}
+DRT_HD Box box_of_tri(f3 a, f3 b, f3 c, float pad) {
+    Box r;
+    r.lox = fminf(a.x, fminf(b.x, c.x)) - pad; r.hix = fmaxf(a.x, fmaxf(b.x, c.x)) + pad;
+    r.loy = fminf(a.y, fminf(b.y, c.y)) - pad; r.hiy = fmaxf(a.y, fmaxf(b.y, c.y)) + pad;
+    r.loz = fminf(a.z, fminf(b.z, c.z)) - pad; r.hiz = fmaxf(a.z, fmaxf(b.z, c.z)) + pad;
+    return r;
+}
+DRT_HD bool box_contains(Box outer, Box inner) {
+    return outer.lox <= inner.lox && outer.loy <= inner.loy && outer.loz <= inner.loz &&
+           outer.hix >= inner.hix && outer.hiy >= inner.hiy && outer.hiz >= inner.hiz;
+}
+
+DRT_HD void node_set_child_box(Node& n, int slot, Box b) {
+    if (slot == 0) {
+        n.c0lox = b.lox; n.c0hix = b.hix; n.c0loy = b.loy; n.c0hiy = b.hiy; n.c0loz = b.loz; n.c0hiz = b.hiz;
+    } else {
+        n.c1lox = b.lox; n.c1hix = b.hix; n.c1loy = b.loy; n.c1hiy = b.hiy; n.c1loz = b.loz; n.c1hiz = b.hiz;
+    }
+}
+DRT_HD Box node_child_box(const Node& n, int slot) {
+    return slot == 0 ? Box{n.c0lox, n.c0loy, n.c0loz, n.c0hix, n.c0hiy, n.c0hiz}
+                     : Box{n.c1lox, n.c1loy, n.c1loz, n.c1hix, n.c1hiy, n.c1hiz};
+}
+
+// Leaf boxes are grown by this much on every side.  The float32 Moller-Trumbore test
+// accepts rays that pass a triangle's exact outline by a rounding-error margin
+// (~1e-4 of the scene extent at most for the camera distances used); 2^-13 of the
+// largest scene extent (0.024 mm on a 200 mm object) is two orders above that and
+// also covers the rounding of the slab arithmetic in the traversal.
+DRT_HD float pad_for_extent(float ext) { return ext * (1.0f / 8192.0f); }
+
+DRT_HD uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// 30-bit Morton code of the triangle centroid inside the scene box [lo, lo + 1/inv_ext].
+DRT_HD uint32_t morton30(f3 a, f3 b, f3 c, f3 lo, f3 inv_ext) {
+    const float third = 1.0f / 3.0f;
+    float x = (((a.x + b.x) + c.x) * third - lo.x) * inv_ext.x;
+    float y = (((a.y + b.y) + c.y) * third - lo.y) * inv_ext.y;
+    float z = (((a.z + b.z) + c.z) * third - lo.z) * inv_ext.z;
+    x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+    y = fminf(fmaxf(y * 1024.0f, 0.0f), 1023.0f);
+    z = fminf(fmaxf(z * 1024.0f, 0.0f), 1023.0f);
+    return (expand_bits10((uint32_t)x) << 2) | (expand_bits10((uint32_t)y) << 1) | expand_bits10((uint32_t)z);
+}
+
+DRT_HD int clz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz((int)v);
+#else
+    return v ? __builtin_clz(v) : 32;
+#endif
+}
+
+// Length of the common prefix of (key_i, i) and (key_j, j); -1 when j is out of range.
+DRT_HD int lbvh_delta(const uint32_t* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = keys[i], b = keys[j];
+    if (a != b) return clz32(a ^ b);
+    return 32 + clz32((uint32_t)i ^ (uint32_t)j);
+}
+
+// Karras 2012 ("Maximizing parallelism in the construction of BVHs, octrees and k-d
+// trees"): children of inner node i over n sorted keys.  Returns child encodings
+// (>= 0 inner, < 0 leaf ~slot).
+DRT_HD void lbvh_children(const uint32_t* keys, int n, int i, int32_t& left, int32_t& right) {
+    const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) / 2;
+        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    left = (lo == gamma) ? ~gamma : gamma;
+    right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+}
+
+}  // namespace drt

@@ -1,0 +1,223 @@
+"""Boundary B2: the ``Scene`` surface of the reference's DiffRender.py, on the HIP path.
+
+``import drt_amd.diffrender as Render`` is a drop-in for the reference's
+``import DiffRender as Render`` (optim.py:6) for everything its optimisation loop
+touches:
+
+    Scene(mesh_path, cuda_device=0)                   DiffRender.py:298-301
+    .update_mesh(path) / .update_verticex(vertices)   DiffRender.py:303-317, 378-384
+    .render_transparent(origin, ray_dir)              DiffRender.py:420-432
+    .optix_intersect(ray) / .render_mask(...)         DiffRender.py:386-392, 434-438
+    .silhouette_edge / .primary_visibility            DiffRender.py:445-479
+    .dihedral_angle() / .mean_len / .vertices / .mesh DiffRender.py:440-443, 345
+    module globals intIOR, extIOR, resy, resx, device, Float   DiffRender.py:15-21
+
+All per-ray and per-edge work runs in hand-written gfx950 kernels (libdrt_hip.so);
+PyTorch only owns the tensors and the autograd plumbing.  Gradients reach
+``vertices`` -- hidden in ``self`` by the reference -- through
+``torch.autograd.Function``s that take it as an explicit input.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, mesh_io
+from .optix_mesh import optix_mesh, _stream
+
+debug = False
+resy = 960
+resx = 1280
+Float = torch.float64
+device = "cuda"
+extIOR, intIOR = 1.00029, 1.5
+
+
+class Ray:
+    """Ray bundle record (reference DiffRender.py:269-283); ray_ind defaults to arange."""
+
+    def __init__(self, origin, direction, ray_ind=None):
+        self.origin = origin
+        self.direction = direction
+        self.ray_ind = torch.arange(len(origin), device=origin.device) if ray_ind is None else ray_ind
+        assert len(self.direction) == len(self.ray_ind)
+
+    def select(self, mask):
+        return Ray(self.origin[mask], self.direction[mask], self.ray_ind[mask])
+
+    def __len__(self):
+        return len(self.ray_ind)
+
+
+def _f64c(t, name):
+    if t.dtype != torch.float64:
+        raise RuntimeError(f"{name} must be float64, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor")
+    return t.contiguous()
+
+
+class _RenderTransparent(torch.autograd.Function):
+    """render_transparent as a function of the vertices (the reference's implicit input)."""
+
+    @staticmethod
+    def forward(ctx, vertices, origin, ray_dir, scene, ior_int, ior_ext):
+        v = _f64c(vertices.detach(), "vertices")
+        o = _f64c(origin.detach(), "origin")
+        d = _f64c(ray_dir.detach(), "ray_dir")
+        n = o.shape[0]
+        out_ori = torch.empty((n, 3), dtype=torch.float64, device=o.device)
+        out_dir = torch.empty((n, 3), dtype=torch.float64, device=o.device)
+        mask = torch.empty((n, 3), dtype=torch.uint8, device=o.device)
+        face1 = torch.empty(n, dtype=torch.int32, device=o.device)
+        face2 = torch.empty(n, dtype=torch.int32, device=o.device)
+        with torch.cuda.device(o.device):
+            _lib.check(_lib.lib().drt_render_forward(
+                scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
+                out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(), _stream()))
+        ctx.scene = scene
+        ctx.ior = (float(ior_int), float(ior_ext))
+        ctx.save_for_backward(v, o, d, face1, face2)
+        mask_b = mask.view(torch.bool)
+        ctx.mark_non_differentiable(mask_b)
+        scene.last_face1, scene.last_face2 = face1, face2
+        return out_ori, out_dir, mask_b
+
+    @staticmethod
+    def backward(ctx, g_ori, g_dir, g_mask):
+        v, o, d, face1, face2 = ctx.saved_tensors
+        grad_v = torch.zeros_like(v)
+        g_ori = None if g_ori is None else _f64c(g_ori, "grad_out_ori")
+        g_dir = None if g_dir is None else _f64c(g_dir, "grad_out_dir")
+        with torch.cuda.device(o.device):
+            _lib.check(_lib.lib().drt_render_backward(
+                ctx.scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1],
+                face1.data_ptr(), face2.data_ptr(), _lib.ptr(g_ori), _lib.ptr(g_dir), grad_v.data_ptr(), _stream()))
+        return grad_v, None, None, None, None, None
+
+
+class _RayLoss(torch.autograd.Function):
+    """Loss_calculator.ray_loss (reference optim.py:100-106) in one pass over the rays."""
+
+    @staticmethod
+    def forward(ctx, out_ori, out_dir, mask, screen_pixel, valid):
+        oo = _f64c(out_ori.detach(), "out_ori")
+        od = _f64c(out_dir.detach(), "out_dir")
+        sp = _f64c(screen_pixel, "screen_pixel")
+        m = mask.contiguous().view(torch.uint8)
+        va = valid.contiguous().view(torch.uint8)
+        n = oo.shape[0]
+        loss = torch.zeros((), dtype=torch.float64, device=oo.device)
+        g = torch.empty_like(od) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(oo.device):
+            _lib.check(_lib.lib().drt_ray_loss(oo.data_ptr(), od.data_ptr(), m.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
+                                               loss.data_ptr(), _lib.ptr(g), _stream()))
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g,) = ctx.saved_tensors
+        # out_ori is detached in the reference's loss (optim.py:100): no gradient for it
+        return None, (None if g is None else g * g_loss), None, None, None
+
+
+class _RenderRayLossFused(torch.autograd.Function):
+    """render_transparent + ray_loss + d/d vertices in ONE kernel pass (nothing dense written)."""
+
+    @staticmethod
+    def forward(ctx, vertices, origin, ray_dir, screen_pixel, valid, scene, ior_int, ior_ext):
+        v = _f64c(vertices.detach(), "vertices")
+        o = _f64c(origin, "origin")
+        d = _f64c(ray_dir, "ray_dir")
+        sp = _f64c(screen_pixel, "screen_pixel")
+        va = valid.contiguous().view(torch.uint8)
+        loss = torch.zeros((), dtype=torch.float64, device=o.device)
+        grad_v = torch.zeros_like(v)
+        with torch.cuda.device(o.device):
+            _lib.check(_lib.lib().drt_render_ray_loss_fused(
+                scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), o.shape[0],
+                float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, _stream()))
+        ctx.save_for_backward(grad_v)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad_v,) = ctx.saved_tensors
+        return grad_v * g_loss, None, None, None, None, None, None, None
+
+
+def ray_loss(out_ori, out_dir, mask, screen_pixel, valid):
+    """sum over valid & mask rays of |out_dir - normalize(screen_pixel - out_ori.detach())|^2."""
+    return _RayLoss.apply(out_ori, out_dir, mask, screen_pixel, valid)
+
+
+class Scene:
+    def __init__(self, mesh_path, cuda_device=0):
+        self.cuda_device = int(cuda_device)
+        self.optix_mesh = optix_mesh(self.cuda_device)
+        self._mesh_stale = False
+        self.update_mesh(mesh_path)
+
+    # ------------------------------------------------------------------ mesh state
+    @property
+    def _dev(self):
+        return torch.device("cuda", self.cuda_device)
+
+    def update_mesh(self, mesh_path):
+        mesh = mesh_path if isinstance(mesh_path, mesh_io.TriMesh) else mesh_io.load(mesh_path, process=False)
+        assert mesh.is_watertight
+        self._mesh = mesh
+        self._mesh_stale = False
+        self.vertices = torch.tensor(mesh.vertices, dtype=Float, device=self._dev)
+        self.faces = torch.tensor(mesh.faces, dtype=torch.long, device=self._dev)
+        opt_v = self.vertices.detach().to(torch.float32)
+        opt_F = self.faces.to(torch.int32)
+        self.optix_mesh.update_mesh(opt_F, opt_v)
+        self.init_edge()
+
+    def init_edge(self):
+        edges, e2f, mean_len = mesh_io.edge_tables(self._mesh)
+        self.mean_len = mean_len
+        self.Edges = torch.tensor(edges, device=self._dev)
+        self.E2F = torch.tensor(e2f, device=self._dev)
+
+    @property
+    def mesh(self):
+        """Host-side mesh record; vertex positions are copied back lazily (the reference pays a
+        device->host sync on every iteration for this, DiffRender.py:381)."""
+        if self._mesh_stale:
+            self._mesh.vertices = self.vertices.detach().cpu().numpy()
+            self._mesh_stale = False
+        return self._mesh
+
+    @property
+    def triangles(self):
+        return self.vertices[self.faces]
+
+    def update_verticex(self, vertices: torch.Tensor):
+        if vertices.shape != self.vertices.shape:
+            raise RuntimeError(f"vertices must have shape {tuple(self.vertices.shape)}")
+        self.vertices = vertices
+        self.optix_mesh.update_vert_f64(vertices)
+        self._mesh_stale = True
+
+    # ------------------------------------------------------------------ tracer access
+    def optix_intersect(self, ray: Ray):
+        optix_ray = torch.cat([ray.origin.detach().to(torch.float32), ray.direction.detach().to(torch.float32)], dim=1)
+        T, faces_ind = self.optix_mesh.intersect(optix_ray)
+        return faces_ind.to(torch.long), T > 0
+
+    def render_mask(self, origin, ray_dir):
+        optix_ray = torch.cat([origin.detach().to(torch.float32), ray_dir.detach().to(torch.float32)], dim=1)
+        return self.optix_mesh.intersect_any(optix_ray).to(Float)
+
+    # ------------------------------------------------------------------ refraction path
+    def render_transparent(self, origin: torch.Tensor, ray_dir: torch.Tensor):
+        return _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR)
+
+    def ray_loss_fused(self, origin, ray_dir, screen_pixel, valid):
+        """ray_loss of this view without materialising out_ori/out_dir/mask."""
+        return _RenderRayLossFused.apply(self.vertices, origin, ray_dir, screen_pixel, valid, self, intIOR, extIOR)

@@ -1,0 +1,139 @@
+"""Boundary B1: the reference's native tracer class, backed by the HIP LBVH.
+
+Same four members as the pybind11 class ``optix_mesh`` of the reference
+(optix_extend.cpp:77-83):
+
+    optix_mesh(cuda_device)                      optix_extend.cpp:8-12
+    update_mesh(F int32 [F,3], V float32 [V,3])  optix_extend.cpp:14-21
+    update_vert(V float32 [V,3])                 optix_extend.cpp:23-27
+    intersect(Ray float32 [N,6]) -> [T, ID]      optix_extend.cpp:29-57
+
+Differences, all deliberate: inputs are validated (the reference only has C asserts
+and misreads non-contiguous tensors), work is enqueued on torch's current stream
+without a host sync (the reference's ``execute(0)`` is synchronous), and the returned
+``T`` / ``ID`` are owning contiguous tensors (the reference returns strided aliases of
+one buffer, ``ID`` through a non-owning ``from_blob``).  A miss has ``T = -1``,
+``ID = -1``; callers test ``T > 0`` (reference DiffRender.py:391).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require(t, dtype, cols, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.dim() != 2 or t.size(1) != cols:
+        raise RuntimeError(f"{name} must have shape [N,{cols}], got {tuple(t.shape)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (there is no CPU tracer in the product path)")
+    return t.contiguous()
+
+
+class optix_mesh:
+    def __init__(self, cuda_device=0):
+        if not torch.cuda.is_available():
+            raise _lib.DrtError("no GPU visible: drt_amd needs an MI355X (gfx950) device")
+        self.device = int(cuda_device)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_create(self.device, ctypes.byref(h)))
+        self._h = h
+        self.builded = False
+        self.n_faces = 0
+        self.n_verts = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().drt_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _check_device(self, t, name):
+        if t.device.index != self.device:
+            raise RuntimeError(f"{name} is on {t.device}, this tracer is bound to cuda:{self.device}")
+
+    def update_mesh(self, F, V):
+        F = _require(F, torch.int32, 3, "F")
+        V = _require(V, torch.float32, 3, "V")
+        self._check_device(F, "F")
+        self._check_device(V, "V")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_update_mesh(self._h, F.data_ptr(), F.size(0), V.data_ptr(), V.size(0), _stream()))
+        self.n_faces, self.n_verts = F.size(0), V.size(0)
+        self.builded = True
+
+    def update_vert(self, V):
+        assert self.builded, "update_mesh must be called first"
+        V = _require(V, torch.float32, 3, "V")
+        self._check_device(V, "V")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_update_vert(self._h, V.data_ptr(), V.size(0), _stream()))
+
+    def update_vert_f64(self, V):
+        """Fused ``V.detach().to(float32)`` + update_vert (reference DiffRender.py:379-380)."""
+        assert self.builded, "update_mesh must be called first"
+        V = _require(V.detach(), torch.float64, 3, "V")
+        self._check_device(V, "V")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_update_vert_f64(self._h, V.data_ptr(), V.size(0), _stream()))
+
+    def intersect(self, Ray):
+        assert self.builded, "update_mesh must be called first"
+        Ray = _require(Ray, torch.float32, 6, "Ray")
+        self._check_device(Ray, "Ray")
+        n = Ray.size(0)
+        T = torch.empty(n, dtype=torch.float32, device=Ray.device)
+        ID = torch.empty(n, dtype=torch.int32, device=Ray.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_intersect(self._h, Ray.data_ptr(), n, T.data_ptr(), ID.data_ptr(), _stream()))
+        return [T, ID]
+
+    # ---- additions beyond the reference class -------------------------------------------
+    def intersect_any(self, Ray):
+        """Hit flags only (bool [N]); what the occlusion / silhouette callers need."""
+        assert self.builded, "update_mesh must be called first"
+        Ray = _require(Ray, torch.float32, 6, "Ray")
+        self._check_device(Ray, "Ray")
+        n = Ray.size(0)
+        hit = torch.empty(n, dtype=torch.uint8, device=Ray.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_intersect_any(self._h, Ray.data_ptr(), n, hit.data_ptr(), _stream()))
+        return hit.view(torch.bool)
+
+    def intersect_bruteforce(self, Ray):
+        """Same contract as intersect by testing every triangle (diagnostic)."""
+        Ray = _require(Ray, torch.float32, 6, "Ray")
+        n = Ray.size(0)
+        T = torch.empty(n, dtype=torch.float32, device=Ray.device)
+        ID = torch.empty(n, dtype=torch.int32, device=Ray.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_intersect_bruteforce(self._h, Ray.data_ptr(), n, T.data_ptr(), ID.data_ptr(), _stream()))
+        return [T, ID]
+
+    def check(self):
+        """(number of BVH containment/link violations, tree height); synchronises."""
+        v = ctypes.c_int64()
+        hgt = ctypes.c_int32()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_bvh_check(self._h, _stream(), ctypes.byref(v), ctypes.byref(hgt)))
+        return v.value, hgt.value
+
+    def sorted_faces(self):
+        out = torch.empty(self.n_faces, dtype=torch.int32, device=f"cuda:{self.device}")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_bvh_sorted_faces(self._h, out.data_ptr(), _stream()))
+        return out

@@ -1,0 +1,113 @@
+/*
+ * drt_hip.h -- C ABI of libdrt_hip.so, the MI355X (gfx950) implementation of DRT's
+ * differentiable refraction-tracing hot path.
+ *
+ * Plain pointers and sizes only: every `d_*` argument is a DEVICE pointer on the GPU
+ * the scene was created for, `stream` is a hipStream_t passed as void* (NULL = the
+ * null stream).  No call synchronises the host; all work is enqueued on `stream`.
+ * Every function returns 0 on success or a negative DRT_E_* code; drt_last_error()
+ * gives the message for the calling thread.
+ *
+ * Two nested boundaries of the reference are covered:
+ *   B1  the native tracer class `optix_mesh` (reference optix_extend.cpp:6-83), which
+ *       the reference builds on NVIDIA OptiX Prime 6.5;
+ *   B2  the per-view math of `Scene` in reference DiffRender.py that consumes the face
+ *       ids (render_transparent / silhouette / dihedral) and the ray loss of
+ *       reference optim.py:91-108, forward and backward.
+ */
+#ifndef DRT_HIP_H
+#define DRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRT_OK            0
+#define DRT_E_INVALID    -1   /* bad argument (null pointer, negative size, no mesh yet) */
+#define DRT_E_HIP        -2   /* a HIP runtime call failed */
+#define DRT_E_NOMEM      -3
+
+typedef struct drt_scene drt_scene_t;
+
+const char* drt_last_error(void);
+int drt_version(void);
+
+/* ---- lifetime: replaces optix_mesh::optix_mesh(cuda_device), optix_extend.cpp:8-12 ---- */
+int drt_create(int device, drt_scene_t** out);
+void drt_destroy(drt_scene_t* s);
+
+/* ---- B1: acceleration structure -------------------------------------------------------
+ * drt_update_mesh  <- optix_mesh::update_mesh(F int32 [F,3], V float32 [V,3]), optix_extend.cpp:14-21
+ * drt_update_vert  <- optix_mesh::update_vert(V float32 [V,3]),               optix_extend.cpp:23-27
+ * Both copy their inputs (the reference keeps tensor references alive instead) and rebuild
+ * the LBVH on `stream`: scene bounds -> 30-bit Morton codes -> radix sort -> Karras
+ * hierarchy -> bottom-up box refit.
+ * drt_update_vert_f64 fuses the reference's `vertices.detach().to(float32)`
+ * (DiffRender.py:379) into the rebuild. */
+int drt_update_mesh(drt_scene_t* s, const int32_t* d_faces, int64_t n_faces,
+                    const float* d_verts, int64_t n_verts, void* stream);
+int drt_update_vert(drt_scene_t* s, const float* d_verts, int64_t n_verts, void* stream);
+int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, void* stream);
+
+/* drt_intersect <- optix_mesh::intersect(Ray float32 [N,6]) -> T float32 [N], ID int32 [N],
+ * optix_extend.cpp:29-57.  Closest hit with t > 0; miss: T = -1, ID = -1.  Outputs are
+ * caller-owned contiguous arrays (the reference returns strided aliases of one buffer).
+ * drt_intersect_any writes only a hit flag (uint8) -- what Scene.optix_intersect's callers
+ * at DiffRender.py:426 and :224 use. */
+int drt_intersect(drt_scene_t* s, const float* d_rays, int64_t n_rays,
+                  float* d_T, int32_t* d_ID, void* stream);
+int drt_intersect_any(drt_scene_t* s, const float* d_rays, int64_t n_rays,
+                      uint8_t* d_hit, void* stream);
+/* Same results as drt_intersect by testing every triangle (no BVH); diagnostic used to
+ * check the traversal at full workload sizes. */
+int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays,
+                             float* d_T, int32_t* d_ID, void* stream);
+/* Diagnostic: number of BVH child boxes that fail to enclose their subtree (0 when the
+ * build is sound) and the tree height; host-synchronising. */
+int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height);
+/* Diagnostic: copy the Morton-sorted face order (int32 [F]) to d_order. */
+int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
+
+/* ---- B2: Scene.render_transparent, DiffRender.py:420-432 (trace2 :537-546, Dintersect
+ * :492-501, refract_ray :503-535) -------------------------------------------------------
+ * In : d_verts float64 [V,3] (the differentiable vertices; the BVH must have been built
+ *      from their float32 cast), origin/dir float64 [N,3].
+ * Out: out_ori, out_dir float64 [N,3] (zeros where the path is invalid), mask uint8 [N,3]
+ *      (the reference's bool [N,3]), face1/face2 int32 [N]: faces hit at bounce 1 / 2,
+ *      face2 >= 0 exactly for the rays with mask = 1 (saved for backward), face1 = -1 on
+ *      a primary miss. */
+int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
+                       const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
+                       double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
+                       int32_t* d_face1, int32_t* d_face2, void* stream);
+/* Adjoint of drt_render_forward w.r.t. the vertices: d_grad_verts float64 [V,3] += ...
+ * (atomic accumulation; zero it first).  Either incoming gradient may be NULL (= zeros). */
+int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin,
+                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
+                        const int32_t* d_face1, const int32_t* d_face2,
+                        const double* d_grad_out_ori, const double* d_grad_out_dir,
+                        double* d_grad_verts, void* stream);
+
+/* ---- Loss_calculator.ray_loss, optim.py:91-108 ------------------------------------------
+ * loss = sum over rays with valid & mask of |out_dir - normalize(screen_pixel - out_ori)|^2.
+ * Forward accumulates into *d_loss (float64 scalar, zero it first) and, when
+ * d_grad_out_dir is not NULL, writes d loss / d out_dir float64 [N,3] (zeros elsewhere). */
+int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t* d_mask,
+                 const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays,
+                 double* d_loss, double* d_grad_out_dir, void* stream);
+
+/* One pass: render_transparent + ray_loss + d ray_loss / d vertices, nothing dense written.
+ * *d_loss += loss, d_grad_verts [V,3] += gradient (both float64, zero them first);
+ * d_n_valid (int64, may be NULL) += number of contributing rays. */
+int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const double* d_origin,
+                              const double* d_dir, const double* d_screen_pixel,
+                              const uint8_t* d_valid, int64_t n_rays, double ior_int,
+                              double ior_ext, double* d_loss, double* d_grad_verts,
+                              int64_t* d_n_valid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRT_HIP_H */

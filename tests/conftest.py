@@ -1,0 +1,83 @@
+"""pytest configuration: `gpu` marker, repo on sys.path, shared helpers."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "data")
+IOR = 1.4723
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def data_path(name):
+    return os.path.join(DATA, name)
+
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_D = ctypes.c_double
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    """tests/hostsim: the device math headers compiled for the host with g++ (test-only)."""
+    src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
+    out_dir = os.path.join(ROOT, "tests", "hostsim", "_build")
+    so = os.path.join(out_dir, "libhostsim.so")
+    os.makedirs(out_dir, exist_ok=True)
+    deps = [src] + [os.path.join(ROOT, "drt_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "drt_amd", "csrc")) if f.endswith(".h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
+    hs = ctypes.CDLL(so)
+    hs.hs_create.restype = _P
+    hs.hs_create.argtypes = [_P, _I64, _P, _I64]
+    hs.hs_destroy.argtypes = [_P]
+    hs.hs_height.argtypes = [_P]
+    hs.hs_sorted_faces.argtypes = [_P, _P]
+    hs.hs_check.restype = _I64
+    hs.hs_check.argtypes = [_P]
+    hs.hs_intersect.argtypes = [_P, _P, _I64, _P, _P, ctypes.c_int, _P]
+    hs.hs_render_forward.argtypes = [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P]
+    hs.hs_render_backward.argtypes = [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P]
+    hs.hs_ray_loss.argtypes = [_P, _P, _P, _P, _P, _I64, _P, _P]
+    hs.hs_fused.argtypes = [_P, _P, _P, _P, _P, _P, _I64, _D, _D, _P, _P, _P]
+    hs.hs_bounce.argtypes = [_P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]
+    return hs
+
+
+def fixture_view(g):
+    """(origin, ray_dir, screen_pixel, valid, camera_M numpy tuple) of a render fixture, on the CPU."""
+    import torch
+    from drt_amd import views
+    res = int(g["res"])
+    o, d = views.generate_ray(res, res, g["Kinv"], g["Rinv"])
+    rng = np.random.default_rng(int(g["target_seed"]))
+    P = res * res
+    center, _ = mesh_frame_hand()
+    sp = rng.standard_normal((P, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0])
+    valid = rng.random(P) > 0.1
+    return o, d, torch.tensor(sp), torch.tensor(valid)
+
+
+_frame = {}
+
+
+def mesh_frame_hand():
+    if "hand" not in _frame:
+        from drt_amd import mesh_io, views
+        _frame["hand"] = views.mesh_frame(mesh_io.read_ply(data_path("hand_vh.ply")).vertices)
+    return _frame["hand"]

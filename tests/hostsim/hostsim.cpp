@@ -1,0 +1,237 @@
+// tests/hostsim/hostsim.cpp -- CPU unit-test harness for the device math.  TEST ONLY.
+//
+// Compiles the plain-C++ per-item headers of drt_amd/csrc (the same code the gfx950
+// kernels inline) with g++ and drives them with sequential loops, so the LBVH build
+// logic, the traversal and the hand-derived adjoints can be checked against the oracle
+// in the GPU-less CI container.  Nothing in drt_amd/ loads this library: the product
+// path is the HIP library and fails loudly without it.
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+#include "../../drt_amd/csrc/drt_lbvh.h"
+#include "../../drt_amd/csrc/drt_path.h"
+
+using namespace drt;
+
+struct HsScene {
+    std::vector<int32_t> faces;
+    std::vector<float> verts;
+    std::vector<Node> nodes;
+    std::vector<TriRec> tris;
+    std::vector<int32_t> parent_inner, parent_leaf;
+    std::vector<uint32_t> keys, idx;
+    float pad = 0.f;
+    int height = 0;
+};
+
+static f3 vert(const HsScene& s, int32_t i) { return f3{s.verts[3 * i], s.verts[3 * i + 1], s.verts[3 * i + 2]}; }
+
+static void build(HsScene& s) {
+    const int n = (int)(s.faces.size() / 3);
+    const int64_t nv = (int64_t)s.verts.size() / 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < nv; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], s.verts[3 * i + a]);
+            hi[a] = fmaxf(hi[a], s.verts[3 * i + a]);
+        }
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    const f3 inv{ex > 0 ? 1.0f / ex : 0.f, ey > 0 ? 1.0f / ey : 0.f, ez > 0 ? 1.0f / ez : 0.f};
+    s.pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
+    std::vector<uint32_t> key(n);
+    for (int i = 0; i < n; ++i)
+        key[i] = morton30(vert(s, s.faces[3 * i]), vert(s, s.faces[3 * i + 1]), vert(s, s.faces[3 * i + 2]), f3{lo[0], lo[1], lo[2]}, inv);
+    s.idx.resize(n);
+    std::iota(s.idx.begin(), s.idx.end(), 0u);
+    std::stable_sort(s.idx.begin(), s.idx.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    s.keys.resize(n);
+    for (int k = 0; k < n; ++k) s.keys[k] = key[s.idx[k]];
+    const int inner = n > 1 ? n - 1 : 1;
+    s.nodes.assign(inner, Node{});
+    s.parent_inner.assign(inner, -1);
+    s.parent_leaf.assign(n, -1);
+    s.tris.resize(n);
+    if (n == 0) return;
+    if (n == 1) {
+        node_set_child_box(s.nodes[0], 0, box_empty());
+        node_set_child_box(s.nodes[0], 1, box_empty());
+        s.nodes[0].child0 = ~0; s.nodes[0].child1 = ~0;
+        s.parent_leaf[0] = 0;
+    } else {
+        for (int i = 0; i < n - 1; ++i) {
+            int32_t l, r;
+            lbvh_children(s.keys.data(), n, i, l, r);
+            s.nodes[i].child0 = l; s.nodes[i].child1 = r;
+            if (l >= 0) s.parent_inner[l] = i * 2; else s.parent_leaf[~l] = i * 2;
+            if (r >= 0) s.parent_inner[r] = i * 2 + 1; else s.parent_leaf[~r] = i * 2 + 1;
+        }
+    }
+    std::vector<uint32_t> flags(inner, n == 1 ? 1u : 0u);
+    for (int k = 0; k < n; ++k) {
+        const int32_t face = (int32_t)s.idx[k];
+        const f3 a = vert(s, s.faces[3 * face]), b = vert(s, s.faces[3 * face + 1]), c = vert(s, s.faces[3 * face + 2]);
+        s.tris[k] = make_tri(a, b, c, face);
+        Box box = box_of_tri(a, b, c, s.pad);
+        int32_t link = s.parent_leaf[k];
+        while (link >= 0) {
+            const int p = link >> 1, slot = link & 1;
+            node_set_child_box(s.nodes[p], slot, box);
+            if (flags[p]++ == 0) break;
+            box = box_union(box, node_child_box(s.nodes[p], slot ^ 1));
+            link = s.parent_inner[p];
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        int depth = 0;
+        for (int32_t link = s.parent_leaf[k]; link >= 0; link = s.parent_inner[link >> 1]) ++depth;
+        s.height = std::max(s.height, depth);
+    }
+}
+
+struct HostStack {
+    int32_t fast[8];      // deliberately shallow so the overflow path is exercised
+    int32_t slow[kStackSlow + 64];
+    Stack st;
+    HostStack() { st.fast = fast; st.stride = 1; st.depth_fast = 8; st.slow = slow; st.sp = 0; }
+};
+
+static PathCtx path_ctx(const HsScene* s, const double* verts64, double ior_int, double ior_ext) {
+    return PathCtx{TraceCtx{s->nodes.data(), s->tris.data(), (int)s->tris.size(), nullptr}, s->faces.data(), verts64, ior_int, ior_ext};
+}
+
+extern "C" {
+
+void* hs_create(const int32_t* faces, int64_t n_faces, const float* verts, int64_t n_verts) {
+    HsScene* s = new HsScene();
+    s->faces.assign(faces, faces + 3 * n_faces);
+    s->verts.assign(verts, verts + 3 * n_verts);
+    build(*s);
+    return s;
+}
+void hs_destroy(void* h) { delete (HsScene*)h; }
+int hs_height(void* h) { return ((HsScene*)h)->height; }
+void hs_sorted_faces(void* h, int32_t* out) {
+    HsScene* s = (HsScene*)h;
+    for (size_t k = 0; k < s->idx.size(); ++k) out[k] = (int32_t)s->idx[k];
+}
+
+// Every ancestor box must enclose each leaf's padded box and the links must be consistent.
+int64_t hs_check(void* h) {
+    HsScene* s = (HsScene*)h;
+    const int n = (int)s->tris.size();
+    int64_t bad = 0;
+    for (int k = 0; k < n; ++k) {
+        const TriRec& t = s->tris[k];
+        const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, c{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+        const Box leaf = box_of_tri(a, b, c, 0.5f * s->pad);
+        int32_t link = s->parent_leaf[k], expect = ~k;
+        while (link >= 0) {
+            const int p = link >> 1, slot = link & 1;
+            const Node& nd = s->nodes[p];
+            if ((slot == 0 ? nd.child0 : nd.child1) != expect) ++bad;
+            if (!box_contains(node_child_box(nd, slot), leaf)) ++bad;
+            expect = p;
+            link = s->parent_inner[p];
+        }
+        if (n > 1 && expect != 0) ++bad;
+    }
+    return bad;
+}
+
+void hs_intersect(void* h, const float* rays, int64_t n, float* T, int32_t* ID, int any, uint32_t* visits) {
+    HsScene* s = (HsScene*)h;
+    HostStack hs;
+    for (int64_t i = 0; i < n; ++i) {
+        const f3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+        uint32_t v = 0;
+        const Hit r = any ? traverse<true>(s->nodes.data(), s->tris.data(), (int)s->tris.size(), o, d, hs.st, &v)
+                          : traverse<false>(s->nodes.data(), s->tris.data(), (int)s->tris.size(), o, d, hs.st, &v);
+        T[i] = r.t;
+        ID[i] = r.face;
+        if (visits) visits[i] = v;
+    }
+}
+
+void hs_render_forward(void* h, const double* verts64, const double* origin, const double* dir, int64_t n, double ior_int,
+                       double ior_ext, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2) {
+    const PathCtx c = path_ctx((HsScene*)h, verts64, ior_int, ior_ext);
+    HostStack hs;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t f1, f2;
+        d3 eo{0, 0, 0}, ed{0, 0, 0};
+        const bool ok = trace_path(c, hs.st, load_d3(origin, i), load_d3(dir, i), f1, f2, eo, ed);
+        const d3 z{0, 0, 0};
+        store_d3(out_ori, i, ok ? eo : z);
+        store_d3(out_dir, i, ok ? ed : z);
+        mask[3 * i] = mask[3 * i + 1] = mask[3 * i + 2] = ok ? 1 : 0;
+        face1[i] = f1;
+        face2[i] = f2;
+    }
+}
+
+struct HostAdd {
+    double* g;
+    void operator()(int32_t v, d3 a) const { g[3 * v] += a.x; g[3 * v + 1] += a.y; g[3 * v + 2] += a.z; }
+};
+
+void hs_render_backward(void* h, const double* verts64, const double* origin, const double* dir, int64_t n, double ior_int,
+                        double ior_ext, const int32_t* face1, const int32_t* face2, const double* g_ori, const double* g_dir,
+                        double* grad_verts) {
+    const PathCtx c = path_ctx((HsScene*)h, verts64, ior_int, ior_ext);
+    const d3 z{0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        if (face2[i] < 0) continue;
+        path_recompute_backward(c, load_d3(origin, i), load_d3(dir, i), face1[i], face2[i], g_ori ? load_d3(g_ori, i) : z,
+                                g_dir ? load_d3(g_dir, i) : z, HostAdd{grad_verts});
+    }
+}
+
+void hs_ray_loss(const double* out_ori, const double* out_dir, const uint8_t* mask, const double* screen_pixel,
+                 const uint8_t* valid, int64_t n, double* loss, double* g_out_dir) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        d3 g{0, 0, 0};
+        if (valid[i] && mask[3 * i]) acc += ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g);
+        if (g_out_dir) store_d3(g_out_dir, i, g);
+    }
+    *loss += acc;
+}
+
+void hs_fused(void* h, const double* verts64, const double* origin, const double* dir, const double* screen_pixel,
+              const uint8_t* valid, int64_t n, double ior_int, double ior_ext, double* loss, double* grad_verts, int64_t* n_valid) {
+    const PathCtx c = path_ctx((HsScene*)h, verts64, ior_int, ior_ext);
+    HostStack hs;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!valid[i]) continue;
+        int32_t f1, f2;
+        d3 eo, ed, g;
+        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+        if (!trace_path(c, hs.st, o, d, f1, f2, eo, ed)) continue;
+        *loss += ray_loss_term(eo, ed, load_d3(screen_pixel, i), g);
+        if (n_valid) ++*n_valid;
+        path_recompute_backward(c, o, d, f1, f2, d3{0, 0, 0}, g, HostAdd{grad_verts});
+    }
+}
+
+// Single bounce forward + adjoint on explicit triangles: unit test of drt_shade.h.
+void hs_bounce(const double* o, const double* d, const double* tri, int64_t n, double ior_int, double ior_ext,
+               const double* g_new_o, const double* g_wt, double* new_o, double* wt, uint8_t* tir, double* t_out,
+               double* g_tri, double* g_o, double* g_d) {
+    for (int64_t i = 0; i < n; ++i) {
+        Bounce b;
+        bounce_forward(load_d3(o, i), load_d3(d, i), load_d3(tri, 3 * i), load_d3(tri, 3 * i + 1), load_d3(tri, 3 * i + 2), ior_ext, ior_int, b);
+        store_d3(new_o, i, b.new_o);
+        store_d3(wt, i, b.wt);
+        tir[i] = b.tir;
+        t_out[i] = b.t;
+        d3 ga{0, 0, 0}, gb{0, 0, 0}, gc{0, 0, 0}, go, gd;
+        bounce_backward(b, load_d3(g_new_o, i), load_d3(g_wt, i), ga, gb, gc, go, gd);
+        store_d3(g_tri, 3 * i, ga); store_d3(g_tri, 3 * i + 1, gb); store_d3(g_tri, 3 * i + 2, gc);
+        store_d3(g_o, i, go);
+        store_d3(g_d, i, gd);
+    }
+}
+
+}  // extern "C"

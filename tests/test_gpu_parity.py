@@ -1,0 +1,248 @@
+"""Parity of the gfx950 kernels (through the C ABI) with the CPU oracle and the golden
+vectors of the reference.  Face ids / masks / T bit-exact; float64 rays within 1e-9;
+gradients within 1e-5 absolute (north_star bar), in practice ~1e-12 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import IOR, data_path, fixture_view, golden
+from drt_amd import mesh_io, views
+from oracle import diffrender_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Render():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from drt_amd import diffrender
+    diffrender.intIOR = IOR
+    return diffrender
+
+
+@pytest.fixture(scope="module")
+def hand():
+    return mesh_io.read_ply(data_path("hand_vh.ply"))
+
+
+@pytest.fixture(scope="module")
+def horse50k():
+    return mesh_io.subdivide_midpoint(mesh_io.read_ply(data_path("horse_vh.ply")))
+
+
+def _tracer(mesh):
+    from drt_amd.optix_mesh import optix_mesh
+    t = optix_mesh(0)
+    t.update_mesh(torch.tensor(mesh.faces, dtype=torch.int32, device="cuda"),
+                  torch.tensor(mesh.vertices, dtype=torch.float32, device="cuda"))
+    return t
+
+
+def _camera_rays(mesh, res, view):
+    c, ext = views.mesh_frame(mesh.vertices)
+    R, K, Rinv, Kinv = views.turntable_cameras(c, ext, 72, res, res)[view]
+    o, d = views.generate_ray(res, res, Kinv, Rinv)
+    return torch.cat([o.float(), d.float()], 1)
+
+
+def test_b1_intersect_equals_oracle_bruteforce(hand):
+    t = _tracer(hand)
+    bad, height = t.check()
+    assert bad == 0 and 12 <= height <= 48
+    f32 = hand.faces.astype(np.int32); v32 = hand.vertices.astype(np.float32)
+    rng = np.random.default_rng(3)
+    c, ext = views.mesh_frame(hand.vertices)
+    batches = [_camera_rays(hand, 128, v).numpy() for v in (0, 5, 23, 41)]
+    o = rng.uniform(-1, 1, (20000, 3)) * ext + c
+    d = rng.standard_normal((20000, 3)) * rng.uniform(0.1, 30, (20000, 1))
+    d[:300, 0] = 0; d[300:600, 1] = 0; d[600:900, 2] = 0; d[900:1000, :2] = 0
+    batches.append(np.concatenate([o, d], 1).astype(np.float32))
+    tgt = np.concatenate([hand.vertices, 0.5 * (hand.vertices[hand.faces[:, 0]] + hand.vertices[hand.faces[:, 1]])])
+    eye = c + np.array([0, 0, 2.5 * ext])
+    batches.append(np.concatenate([np.broadcast_to(eye, tgt.shape), tgt - eye], 1).astype(np.float32))
+    for rays in batches:
+        T, ID = t.intersect(torch.tensor(rays, device="cuda"))
+        To, IDo = orc.trace_closest(f32, v32, rays)
+        assert np.array_equal(ID.cpu().numpy(), IDo)
+        assert np.array_equal(T.cpu().numpy(), To)
+        assert T.is_contiguous() and ID.is_contiguous() and ID.dtype == torch.int32
+        hit = t.intersect_any(torch.tensor(rays, device="cuda"))
+        assert np.array_equal(hit.cpu().numpy(), IDo >= 0)
+        Tb, IDb = t.intersect_bruteforce(torch.tensor(rays, device="cuda"))
+        assert np.array_equal(IDb.cpu().numpy(), IDo) and np.array_equal(Tb.cpu().numpy(), To)
+
+
+def test_b1_edge_cases(hand):
+    from drt_amd.optix_mesh import optix_mesh
+    t = optix_mesh(0)
+    with pytest.raises(AssertionError):
+        t.intersect(torch.zeros((1, 6), device="cuda"))
+    verts = torch.tensor([[0, 0, 0], [1, 0, 0], [0, 1, 0.]], dtype=torch.float32, device="cuda")
+    rays = torch.tensor([[0.2, 0.2, 1, 0, 0, -1], [5, 5, 1, 0, 0, -1], [0.2, 0.2, -1, 0, 0, -1]], dtype=torch.float32, device="cuda")
+    for faces in ([[0, 1, 2]], [[0, 1, 2], [0, 1, 2], [0, 1, 2]], [[0, 1, 2], [0, 0, 0]]):
+        t.update_mesh(torch.tensor(faces, dtype=torch.int32, device="cuda"), verts)
+        assert t.check()[0] == 0
+        T, ID = t.intersect(rays)
+        assert ID.tolist() == [0, -1, -1] and T.tolist() == [1.0, -1.0, -1.0]
+    T, ID = t.intersect(torch.zeros((0, 6), dtype=torch.float32, device="cuda"))      # empty ray set
+    assert T.shape == (0,) and ID.shape == (0,)
+    t.update_mesh(torch.zeros((0, 3), dtype=torch.int32, device="cuda"), verts)        # empty mesh: all miss
+    T, ID = t.intersect(rays)
+    assert ID.tolist() == [-1, -1, -1]
+    with pytest.raises(RuntimeError):
+        t.intersect(rays.double())
+    with pytest.raises(RuntimeError):
+        t.intersect(rays.cpu())
+    with pytest.raises(RuntimeError):
+        t.update_vert(torch.zeros((7, 3), dtype=torch.float32, device="cuda"))   # wrong vertex count
+    # non-contiguous input is handled (the reference misreads it)
+    t.update_mesh(torch.tensor([[0, 1, 2]], dtype=torch.int32, device="cuda"), verts)
+    wide = torch.zeros((3, 12), dtype=torch.float32, device="cuda"); wide[:, ::2] = rays
+    assert t.intersect(wide[:, ::2])[1].tolist() == [0, -1, -1]
+
+
+def test_lbvh_rebuild_is_sound_and_stable_under_load(horse50k):
+    """Many rebuilds back to back with traversal launches in flight: the inter-workgroup box
+    hand-off of the refit (agent-scope release/acquire) must never leave a stale box."""
+    t = _tracer(horse50k)
+    V = torch.tensor(horse50k.vertices, dtype=torch.float32, device="cuda")
+    rays = _camera_rays(horse50k, 512, 7).cuda()
+    ref_T, ref_ID = t.intersect(rays)
+    order0 = t.sorted_faces().clone()
+    assert torch.equal(torch.sort(order0).values, torch.arange(len(horse50k.faces), device="cuda", dtype=torch.int32))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for it in range(25):
+        jitter = V + 1e-3 * torch.randn(V.shape, device="cuda", generator=g)
+        t.update_vert(jitter)
+        t.intersect(rays)                       # keep the chip busy between builds
+        bad, height = t.check()
+        assert bad == 0, f"iteration {it}: {bad} BVH violations"
+        assert height <= 48
+    t.update_vert(V)
+    T, ID = t.intersect(rays)
+    assert torch.equal(ID, ref_ID) and torch.equal(T, ref_T)
+    assert torch.equal(t.sorted_faces(), order0)
+
+
+@pytest.mark.parametrize("res", [512, 1024])
+def test_full_size_traversal_equals_gpu_bruteforce(horse50k, res):
+    """BASELINE workload size (50 248 triangles, up to 1024x1024 rays): BVH result == exhaustive test."""
+    t = _tracer(horse50k)
+    for view in (3, 40):
+        rays = _camera_rays(horse50k, res, view).cuda()
+        T, ID = t.intersect(rays)
+        hit = ID >= 0
+        assert 0.05 < hit.float().mean().item() < 0.6
+        sel = torch.nonzero(hit).squeeze(1)
+        # every hit ray + an equal number of misses, exhaustively
+        miss = torch.nonzero(~hit).squeeze(1)[:: max(1, int((~hit).sum()) // max(1, len(sel)))]
+        idx = torch.cat([sel, miss])
+        Tb, IDb = t.intersect_bruteforce(rays[idx].contiguous())
+        assert torch.equal(ID[idx], IDb)
+        assert torch.equal(T[idx], Tb)
+
+
+@pytest.mark.parametrize("name", [f"hand_r{r}_v{v}" for r in (64, 128) for v in (5, 23, 41)])
+def test_render_transparent_vs_golden(Render, hand, name):
+    g = golden(name)
+    o, d, sp, valid = fixture_view(g)
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+    V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    out_ori, out_dir, mask = scene.render_transparent(o.cuda(), d.cuda())
+    assert out_ori.dtype == torch.float64 and out_ori.shape == o.shape and mask.dtype == torch.bool and mask.shape == o.shape
+    vi = torch.nonzero(mask[:, 0]).squeeze(1).cpu().numpy()
+    assert np.array_equal(vi, g["valid_ind"])
+    assert torch.equal(mask[:, 0], mask[:, 1]) and torch.equal(mask[:, 0], mask[:, 2])
+    f1 = np.full(len(o), -1, np.int64); f1[g["b1_ind"]] = g["b1_face"]
+    assert np.array_equal(scene.last_face1.cpu().numpy(), f1)           # hit ids bit-exact
+    np.testing.assert_allclose(out_ori[vi].detach().cpu().numpy(), g["out_ori"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(out_dir[vi].detach().cpu().numpy(), g["out_dir"], rtol=1e-10, atol=1e-11)
+    assert float(out_ori.detach()[~mask[:, 0]].abs().sum()) == 0.0
+    loss = Render.ray_loss(out_ori, out_dir, mask, sp.cuda(), valid.cuda())
+    assert loss.item() == pytest.approx(float(g["ray_loss"]), rel=1e-10)
+    g_ray, = torch.autograd.grad(loss, V, retain_graph=True)
+    ref = g["grad_ray_loss"]
+    assert np.abs(g_ray.cpu().numpy() - ref).max() <= 1e-5
+    np.testing.assert_allclose(g_ray.cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    rng = np.random.default_rng(int(g["lin_seed"]))
+    w_ori = torch.tensor(rng.standard_normal(o.shape), device="cuda"); w_dir = torch.tensor(rng.standard_normal(o.shape), device="cuda")
+    lin = (out_ori * w_ori).sum() + (out_dir * w_dir).sum()
+    assert lin.item() == pytest.approx(float(g["lin"]), rel=1e-9)
+    g_lin, = torch.autograd.grad(lin, V)
+    ref = g["grad_lin"]
+    np.testing.assert_allclose(g_lin.cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    # fused one-pass loss + gradient
+    V2 = V.detach().clone().requires_grad_(True)
+    scene.update_verticex(V2)
+    lf = scene.ray_loss_fused(o.cuda(), d.cuda(), sp.cuda(), valid.cuda())
+    assert lf.item() == pytest.approx(float(g["ray_loss"]), rel=1e-10)
+    (3.0 * lf).backward()
+    ref = 3.0 * g["grad_ray_loss"]
+    np.testing.assert_allclose(V2.grad.cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+
+
+def test_render_50k_vs_oracle_sample(Render, horse50k):
+    """50k-triangle mesh: the HIP path vs the oracle on a 96x96 view (the oracle is O(rays x faces))."""
+    scene = Render.Scene(horse50k, 0)
+    c, ext = views.mesh_frame(horse50k.vertices)
+    R, K, Rinv, Kinv = views.turntable_cameras(c, ext, 72, 96, 96)[11]
+    o, d = views.generate_ray(96, 96, Kinv, Rinv)
+    V = torch.tensor(horse50k.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    out_ori, out_dir, mask = scene.render_transparent(o.cuda(), d.cuda())
+    Vc = torch.tensor(horse50k.vertices, dtype=torch.float64, requires_grad=True)
+    oo, od, mk, aux = orc.render_transparent(orc.Mesh(horse50k.faces, Vc), o, d, IOR, return_aux=True)
+    assert torch.equal(mask.cpu(), mk)
+    assert torch.equal(scene.last_face1.cpu().long(), aux["face1"])
+    f2 = aux["face2"].clone(); f2[~mk[:, 0]] = -1
+    assert torch.equal(scene.last_face2.cpu().long(), f2)
+    assert mk[:, 0].sum() > 200
+    torch.testing.assert_close(out_dir.detach().cpu(), od.detach(), rtol=1e-10, atol=1e-11)
+    torch.testing.assert_close(out_ori.detach().cpu(), oo.detach(), rtol=1e-10, atol=1e-9)
+    w = torch.tensor(np.random.default_rng(5).standard_normal(o.shape))
+    ((out_dir * w.cuda()).sum() + (out_ori * w.cuda()).sum()).backward()
+    ((od * w).sum() + (oo * w).sum()).backward()
+    assert (V.grad.cpu() - Vc.grad).abs().max().item() <= 1e-5 * max(1.0, Vc.grad.abs().max().item())
+
+
+def test_properties_at_full_size(Render, horse50k):
+    """Size-independent properties on 1024x1024 rays x 50k triangles."""
+    scene = Render.Scene(horse50k, 0)
+    c, ext = views.mesh_frame(horse50k.vertices)
+    R, K, Rinv, Kinv = views.turntable_cameras(c, ext, 72, 1024, 1024)[20]
+    o, d = views.generate_ray(1024, 1024, Kinv, Rinv, device="cuda")
+    V = torch.tensor(horse50k.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    out_ori, out_dir, mask = scene.render_transparent(o, d)
+    m = mask[:, 0]
+    f1, f2 = scene.last_face1, scene.last_face2
+    assert 0.03 < m.float().mean().item() < 0.5
+    assert torch.all(f2[m] >= 0) and torch.all(f2[~m] == -1) and torch.all(f1[m] >= 0)
+    assert torch.all(out_ori[~m] == 0) and torch.all(out_dir[~m] == 0)
+    nrm = out_dir.detach()[m].norm(dim=1)
+    assert (nrm - 1).abs().max().item() < 1e-12                      # exit directions are unit vectors
+    # primary face ids agree with the B1 query of the same rays
+    ids, hitted = scene.optix_intersect(Render.Ray(o, d))
+    assert torch.equal(hitted, f1 >= 0) and torch.equal(ids[hitted].int(), f1[hitted])
+    # exit rays leave the object: re-tracing them hits nothing (that is the occlusion test)
+    _, again = scene.optix_intersect(Render.Ray(out_ori.detach()[m], out_dir.detach()[m]))
+    assert not again.any()
+    # determinism of the forward, run-to-run
+    o2, d2, m2 = scene.render_transparent(o, d)
+    assert torch.equal(o2, out_ori) and torch.equal(d2, out_dir) and torch.equal(m2, mask)
+    # linearity of the adjoint in the incoming gradient, and fused == two-pass
+    w = torch.randn(o.shape, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    g1, = torch.autograd.grad((out_dir * w).sum(), V, retain_graph=True)
+    g2, = torch.autograd.grad((out_dir * (2.5 * w)).sum(), V, retain_graph=True)
+    torch.testing.assert_close(g2, 2.5 * g1, rtol=1e-9, atol=1e-9 * g1.abs().max().item())
+    sp = out_ori.detach() + 100.0 * out_dir.detach() + 0.3
+    valid = m.clone()
+    loss = Render.ray_loss(out_ori, out_dir, mask, sp, valid)
+    ga, = torch.autograd.grad(loss, V)
+    V2 = V.detach().clone().requires_grad_(True)
+    scene.update_verticex(V2)
+    lf = scene.ray_loss_fused(o, d, sp, valid)
+    lf.backward()
+    assert lf.item() == pytest.approx(loss.item(), rel=1e-10)
+    torch.testing.assert_close(V2.grad, ga, rtol=1e-8, atol=1e-10 * ga.abs().max().item())

@@ -1,0 +1,194 @@
+"""Device math (drt_amd/csrc/*.h compiled for the host by tests/hostsim) against the oracle.
+
+This is how the LBVH build logic, the traversal and the hand-derived adjoint are
+checked in the GPU-less container; the `-m gpu` tests repeat the comparisons on the
+real kernels."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import IOR, data_path, fixture_view, golden
+from drt_amd import mesh_io, views
+from oracle import diffrender_oracle as orc
+
+
+class HostScene:
+    def __init__(self, hs, faces, verts64):
+        self.hs = hs
+        self.f32 = np.ascontiguousarray(faces, dtype=np.int32)
+        self.v64 = np.ascontiguousarray(verts64, dtype=np.float64)
+        self.v32 = self.v64.astype(np.float32)
+        self.h = hs.hs_create(self.f32.ctypes.data, len(self.f32), self.v32.ctypes.data, len(self.v32))
+
+    def __del__(self):
+        self.hs.hs_destroy(self.h)
+
+    def intersect(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        n = len(rays)
+        T = np.empty(n, np.float32); ID = np.empty(n, np.int32); vis = np.empty(n, np.uint32)
+        self.hs.hs_intersect(self.h, rays.ctypes.data, n, T.ctypes.data, ID.ctypes.data, int(any_hit), vis.ctypes.data)
+        return T, ID, vis
+
+    def render(self, o, d, ior=IOR):
+        n = len(o)
+        o = np.ascontiguousarray(o); d = np.ascontiguousarray(d)
+        out = dict(out_ori=np.zeros((n, 3)), out_dir=np.zeros((n, 3)), mask=np.zeros((n, 3), np.uint8),
+                   f1=np.zeros(n, np.int32), f2=np.zeros(n, np.int32))
+        self.hs.hs_render_forward(self.h, self.v64.ctypes.data, o.ctypes.data, d.ctypes.data, n, ior, orc.EXT_IOR,
+                                  out["out_ori"].ctypes.data, out["out_dir"].ctypes.data, out["mask"].ctypes.data,
+                                  out["f1"].ctypes.data, out["f2"].ctypes.data)
+        return out
+
+    def backward(self, o, d, f1, f2, g_ori, g_dir, ior=IOR):
+        o = np.ascontiguousarray(o); d = np.ascontiguousarray(d)
+        gv = np.zeros_like(self.v64)
+        self.hs.hs_render_backward(self.h, self.v64.ctypes.data, o.ctypes.data, d.ctypes.data, len(o), ior, orc.EXT_IOR,
+                                   f1.ctypes.data, f2.ctypes.data, None if g_ori is None else g_ori.ctypes.data,
+                                   None if g_dir is None else g_dir.ctypes.data, gv.ctypes.data)
+        return gv
+
+
+@pytest.fixture(scope="module")
+def hand():
+    return mesh_io.read_ply(data_path("hand_vh.ply"))
+
+
+def _camera_rays(mesh, res, view):
+    c, ext = views.mesh_frame(mesh.vertices)
+    R, K, Rinv, Kinv = views.turntable_cameras(c, ext, 72, res, res)[view]
+    return views.generate_ray(res, res, Kinv, Rinv)
+
+
+def _rays32(o, d):
+    return torch.cat([o.float(), d.float()], 1).numpy()
+
+
+@pytest.mark.parametrize("name,subdiv", [("hand_vh.ply", 0), ("hand_vh.ply", 1), ("horse_vh.ply", 0), ("mouse_vh.ply", 0)])
+def test_lbvh_is_sound(hostsim, name, subdiv):
+    m = mesh_io.read_ply(data_path(name))
+    for _ in range(subdiv):
+        m = mesh_io.subdivide_midpoint(m)
+    assert m.is_watertight
+    s = HostScene(hostsim, m.faces, m.vertices)
+    assert hostsim.hs_check(s.h) == 0
+    order = np.empty(len(m.faces), np.int32)
+    hostsim.hs_sorted_faces(s.h, order.ctypes.data)
+    assert np.array_equal(np.sort(order), np.arange(len(m.faces)))       # a permutation
+    h = hostsim.hs_height(s.h)
+    assert np.log2(len(m.faces)) <= h <= 30 + np.ceil(np.log2(len(m.faces)))
+
+
+def test_traversal_equals_bruteforce(hostsim, hand):
+    s = HostScene(hostsim, hand.faces, hand.vertices)
+    rng = np.random.default_rng(3)
+    c, ext = views.mesh_frame(hand.vertices)
+    batches = []
+    for view in (0, 17, 44):
+        batches.append(_rays32(*_camera_rays(hand, 96, view)))
+    # random rays from inside and outside, un-normalised directions, axis-aligned directions (zero components)
+    o = rng.uniform(-1, 1, (4000, 3)) * ext + c
+    d = rng.standard_normal((4000, 3)) * rng.uniform(0.1, 30, (4000, 1))
+    d[:300, 0] = 0; d[300:600, 1] = 0; d[600:900, 2] = 0; d[900:1000, :2] = 0
+    batches.append(np.concatenate([o, d], 1).astype(np.float32))
+    # rays starting exactly on vertices / aimed at vertices and edge midpoints (ties between faces)
+    tgt = np.concatenate([hand.vertices[:1500], 0.5 * (hand.vertices[hand.faces[:1500, 0]] + hand.vertices[hand.faces[:1500, 1]])])
+    eye = c + np.array([0, 0, 2.5 * ext])
+    batches.append(np.concatenate([np.broadcast_to(eye, tgt.shape), tgt - eye], 1).astype(np.float32))
+    for rays in batches:
+        T, ID, _ = s.intersect(rays)
+        To, IDo = orc.trace_closest(s.f32, s.v32, rays)
+        assert np.array_equal(ID, IDo)
+        assert np.array_equal(T, To)          # bit-exact t
+        _, IDa, _ = s.intersect(rays, any_hit=True)
+        assert np.array_equal(IDa >= 0, IDo >= 0)
+
+
+def test_traversal_degenerate_meshes(hostsim):
+    rays = np.array([[0.2, 0.2, 1, 0, 0, -1], [5, 5, 1, 0, 0, -1]], np.float32)
+    for faces, verts in [
+        (np.zeros((0, 3), np.int32), np.zeros((0, 3))),                                      # empty mesh
+        (np.array([[0, 1, 2]], np.int32), np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.]])),      # one triangle
+        (np.array([[0, 1, 2], [0, 1, 2], [0, 1, 2]], np.int32), np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.]])),  # duplicates: equal keys
+        (np.array([[0, 1, 2], [0, 0, 0]], np.int32), np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.]])),  # zero-area triangle
+    ]:
+        s = HostScene(hostsim, faces, verts)
+        assert hostsim.hs_check(s.h) == 0
+        T, ID, _ = s.intersect(rays)
+        To, IDo = orc.trace_closest(s.f32, s.v32, rays)
+        assert np.array_equal(ID, IDo) and np.array_equal(T, To)
+
+
+@pytest.mark.parametrize("name", ["hand_r64_v5", "hand_r128_v23", "hand_r128_v41"])
+def test_render_path_vs_golden_and_oracle(hostsim, hand, name):
+    g = golden(name)
+    o, d, sp, valid = fixture_view(g)
+    s = HostScene(hostsim, hand.faces, hand.vertices)
+    r = s.render(o.numpy(), d.numpy())
+    vi = np.flatnonzero(r["mask"][:, 0])
+    assert np.array_equal(vi, g["valid_ind"])
+    f1 = np.full(len(o), -1, np.int64); f1[g["b1_ind"]] = g["b1_face"]
+    assert np.array_equal(r["f1"], f1)
+    np.testing.assert_allclose(r["out_ori"][vi], g["out_ori"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(r["out_dir"][vi], g["out_dir"], rtol=1e-10, atol=1e-11)
+    assert not r["out_ori"][r["mask"][:, 0] == 0].any() and np.all(r["f2"][r["mask"][:, 0] == 0] == -1)
+    # ray loss + its gradient (golden), then the linear functional that exercises grad_out_ori
+    loss = np.zeros(1); gdir = np.zeros((len(o), 3))
+    spn = sp.numpy().copy(); vn = valid.numpy().astype(np.uint8)
+    hostsim.hs_ray_loss(r["out_ori"].ctypes.data, r["out_dir"].ctypes.data, r["mask"].ctypes.data, spn.ctypes.data, vn.ctypes.data,
+                        len(o), loss.ctypes.data, gdir.ctypes.data)
+    assert loss[0] == pytest.approx(float(g["ray_loss"]), rel=1e-11)
+    gv = s.backward(o.numpy(), d.numpy(), r["f1"], r["f2"], None, gdir)
+    np.testing.assert_allclose(gv, g["grad_ray_loss"], rtol=1e-8, atol=1e-10 * np.abs(g["grad_ray_loss"]).max())
+    rng = np.random.default_rng(int(g["lin_seed"]))
+    w_ori = rng.standard_normal(o.shape); w_dir = rng.standard_normal(o.shape)
+    gv = s.backward(o.numpy(), d.numpy(), r["f1"], r["f2"], w_ori, w_dir)
+    np.testing.assert_allclose(gv, g["grad_lin"], rtol=1e-8, atol=1e-10 * np.abs(g["grad_lin"]).max())
+    # fused single pass == two-pass
+    loss_f = np.zeros(1); gv_f = np.zeros_like(s.v64); nv = ctypes.c_int64(0)
+    on, dn = o.numpy().copy(), d.numpy().copy()
+    hostsim.hs_fused(s.h, s.v64.ctypes.data, on.ctypes.data, dn.ctypes.data, spn.ctypes.data, vn.ctypes.data, len(o), IOR, orc.EXT_IOR,
+                     loss_f.ctypes.data, gv_f.ctypes.data, ctypes.byref(nv))
+    assert loss_f[0] == pytest.approx(float(g["ray_loss"]), rel=1e-11)
+    np.testing.assert_allclose(gv_f, g["grad_ray_loss"], rtol=1e-8, atol=1e-10 * np.abs(g["grad_ray_loss"]).max())
+    assert nv.value == int((valid.numpy() & (r["mask"][:, 0] == 1)).sum())
+
+
+def test_bounce_adjoint_vs_autograd(hostsim):
+    """drt_shade.h forward + hand-derived reverse mode against autograd of the oracle's graph,
+    entering and exiting hits, including total internal reflection flags."""
+    rng = np.random.default_rng(11)
+    n = 400
+    tri = rng.standard_normal((n, 3, 3)) * 10
+    centroid = tri.mean(1)
+    d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = centroid - d * rng.uniform(5, 50, (n, 1)) + rng.standard_normal((n, 3)) * 0.5
+    g_no = rng.standard_normal((n, 3)); g_wt = rng.standard_normal((n, 3))
+    new_o = np.zeros((n, 3)); wt = np.zeros((n, 3)); tir = np.zeros(n, np.uint8); t = np.zeros(n)
+    g_tri = np.zeros((n, 3, 3)); g_o = np.zeros((n, 3)); g_d = np.zeros((n, 3))
+    hostsim.hs_bounce(o.ctypes.data, d.ctypes.data, tri.ctypes.data, n, IOR, orc.EXT_IOR, g_no.ctypes.data, g_wt.ctypes.data,
+                      new_o.ctypes.data, wt.ctypes.data, tir.ctypes.data, t.ctypes.data, g_tri.ctypes.data, g_o.ctypes.data, g_d.ctypes.data)
+    to, td, ttri = (torch.tensor(a, requires_grad=True) for a in (o, d, tri))
+    u, v, tt, nn = orc.moller_trumbore(to, td, ttri)
+    wo = -td
+    cos_i = orc._dot(wo, nn).clamp(-1, 1)
+    exc = torch.logical_not(cos_i > 0)
+    sgn = torch.where(exc, -torch.ones_like(tt), torch.ones_like(tt))
+    eta_i = torch.where(exc, torch.full_like(tt, IOR), torch.full_like(tt, orc.EXT_IOR))
+    eta_t = torch.where(exc, torch.full_like(tt, orc.EXT_IOR), torch.full_like(tt, IOR))
+    nn = nn * sgn.view(-1, 1)
+    ref_tir = orc.fresnel_tir(cos_i * sgn, eta_i, eta_t)
+    ref_wt = orc.refract_dir(wo, nn, eta_i / eta_t)
+    ref_no = to + tt.view(-1, 1) * td + 1e-5 * ref_wt
+    assert exc.sum() > 50 and (~exc).sum() > 50 and ref_tir.sum() > 5
+    assert np.array_equal(tir.astype(bool), ref_tir.numpy())
+    np.testing.assert_allclose(t, tt.detach().numpy(), rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(wt, ref_wt.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(new_o, ref_no.detach().numpy(), rtol=1e-10, atol=1e-10)
+    scalar = (ref_no * torch.tensor(g_no)).sum() + (ref_wt * torch.tensor(g_wt)).sum()
+    go, gd, gt = torch.autograd.grad(scalar, (to, td, ttri))
+    for mine, ref in ((g_tri, gt), (g_o, go), (g_d, gd)):
+        ref = ref.numpy()
+        np.testing.assert_allclose(mine, ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())

@@ -1,0 +1,203 @@
+"""The CPU oracle against golden vectors produced by the reference's own Python
+(tests/golden/make_golden.py).  Integer results exact, float64 within 1e-12 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import IOR, data_path, fixture_view, golden
+from drt_amd import mesh_io, views
+from oracle import diffrender_oracle as orc
+
+RTOL = 1e-10   # float64 fields: the oracle is not bit-identical to TorchScript (op order inside cross/norm); 1e-10 covers cancellation in t
+FIXTURES = [f"hand_r{r}_v{v}" for r in (64, 128) for v in (5, 23, 41)]
+
+
+def close(a, b, rtol=RTOL, atol=1e-11):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+@pytest.fixture(scope="module")
+def hand():
+    return mesh_io.read_ply(data_path("hand_vh.ply"))
+
+
+def test_topology_tables(hand):
+    g = golden("hand_topology")
+    edges, e2f, mean_len = mesh_io.edge_tables(hand)
+    assert hand.is_watertight
+    assert np.array_equal(edges, g["Edges"])
+    assert np.array_equal(e2f, g["E2F"])
+    assert mean_len == pytest.approx(float(g["mean_len"]), rel=1e-14)
+    assert len(hand.faces) == 2 * len(hand.vertices) - 4
+
+
+def test_unit_tables():
+    g = golden("unit_tables")
+    wt = orc.refract_dir(torch.tensor(g["wo"]), torch.tensor(g["n"]), torch.tensor(g["eta"]))
+    close(wt, g["refract_wt"])
+    tir = orc.fresnel_tir(torch.tensor(g["fr_cos"]), torch.tensor(g["fr_etaI"]), torch.tensor(g["fr_etaT"]))
+    assert np.array_equal(tir.numpy(), g["fr_tir"])
+    u, v, t, n = orc.moller_trumbore(torch.tensor(g["mt_o"]), torch.tensor(g["mt_d"]), torch.tensor(g["mt_tri"]))
+    close(u, g["mt_u"]); close(v, g["mt_v"]); close(t, g["mt_t"]); close(n, g["mt_n"])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_render_path(hand, name):
+    g = golden(name)
+    o, d, sp, valid = fixture_view(g)
+    V = torch.tensor(hand.vertices, dtype=torch.float64, requires_grad=True)
+    mesh = orc.Mesh(hand.faces, V)
+    out_ori, out_dir, mask, aux = orc.render_transparent(mesh, o, d, IOR, return_aux=True)
+    b1, b2 = aux["b1"], aux["b2"]
+    # bounce 1
+    assert np.array_equal(aux["ind1"].numpy(), g["b1_ind"])
+    assert np.array_equal(b1["face"].numpy(), g["b1_face"])
+    close(b1["u"], g["b1_u"], rtol=1e-9); close(b1["v"], g["b1_v"], rtol=1e-9)
+    close(b1["t"], g["b1_t"]); close(b1["n"], g["b1_n"])
+    assert np.array_equal(b1["refracted"].numpy(), g["b1_refracted"])
+    close(b1["new_o"], g["b1_new_o"]); close(b1["new_d"], g["b1_new_d"])
+    # bounce 2 (rays that refracted at bounce 1)
+    assert np.array_equal(aux["ind2"].numpy()[b2["hitted"].numpy()], g["b2_ind"])
+    assert np.array_equal(b2["hitted"].numpy(), g["b2_hitted"])
+    assert np.array_equal(b2["face"].numpy(), g["b2_face"])
+    close(b2["t"], g["b2_t"]); close(b2["n"], g["b2_n"])
+    assert np.array_equal(b2["refracted"].numpy(), g["b2_refracted"])
+    close(b2["new_o"], g["b2_new_o"]); close(b2["new_d"], g["b2_new_d"])
+    assert np.array_equal(aux["occluded"].numpy(), g["occluded"])
+    # outputs
+    vi = torch.nonzero(mask[:, 0]).squeeze(1)
+    assert np.array_equal(vi.numpy(), g["valid_ind"])
+    assert mask.dtype == torch.bool and mask.shape == o.shape
+    assert torch.equal(mask[:, 0], mask[:, 1]) and torch.equal(mask[:, 0], mask[:, 2])
+    close(out_ori[vi], g["out_ori"]); close(out_dir[vi], g["out_dir"])
+    assert float(out_ori[~mask[:, 0]].abs().sum()) == 0.0 and float(out_dir[~mask[:, 0]].abs().sum()) == 0.0
+    # loss and gradients
+    loss = orc.ray_loss(out_ori, out_dir, mask, sp, valid)
+    assert loss.item() == pytest.approx(float(g["ray_loss"]), rel=1e-12)
+    g_ray, = torch.autograd.grad(loss, V, retain_graph=True)
+    scale = np.abs(g["grad_ray_loss"]).max()
+    close(g_ray, g["grad_ray_loss"], rtol=1e-9, atol=1e-11 * scale)
+    rng = np.random.default_rng(int(g["lin_seed"]))
+    w_ori = rng.standard_normal(o.shape); w_dir = rng.standard_normal(o.shape)
+    lin = (out_ori * torch.tensor(w_ori)).sum() + (out_dir * torch.tensor(w_dir)).sum()
+    assert lin.item() == pytest.approx(float(g["lin"]), rel=1e-11)
+    g_lin, = torch.autograd.grad(lin, V)
+    close(g_lin, g["grad_lin"], rtol=1e-9, atol=1e-11 * np.abs(g["grad_lin"]).max())
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_silhouette_branch(hand, name):
+    g = golden(name)
+    topo = golden("hand_topology")
+    res = int(g["res"])
+    o, d, _, _ = fixture_view(g)
+    V = torch.tensor(hand.vertices, dtype=torch.float64, requires_grad=True)
+    mesh = orc.Mesh(hand.faces, V)
+    Edges, E2F = torch.tensor(topo["Edges"]), torch.tensor(topo["E2F"])
+    cam = tuple(torch.tensor(g[k]) for k in ("R", "K", "Rinv", "Kinv"))
+    sil = orc.silhouette_edges(V, Edges, E2F, o[0])
+    assert np.array_equal(sil.numpy(), g["sil_edges"])
+    index, output = orc.primary_visibility(mesh, sil, cam, o[0], res, res, detach_depth=True)
+    assert np.array_equal(index.numpy(), g["vh_index"])
+    assert str(output.dtype) == str(g["vh_output_dtype"]) == "torch.float32"
+    close(output, g["vh_output"])
+    hit = np.zeros(res * res, dtype=np.uint8)
+    hit[g["b1_ind"]] = 1          # the fixture stores the soft mask in float32; rebuild the float64 one
+    soft = torch.tensor(views.process_mask(hit.reshape(res, res)), dtype=torch.float64).reshape(-1)
+    vh = orc.vh_loss_view(mesh, Edges, E2F, cam, o[0], soft, res, res)
+    assert vh.item() == pytest.approx(float(g["vh_loss"]), rel=1e-12)
+    g_vh, = torch.autograd.grad(vh, V)
+    close(g_vh, g["grad_vh"], rtol=1e-9, atol=1e-11 * np.abs(g["grad_vh"]).max())
+
+
+def test_process_mask_matches_fixture(hand):
+    g = golden("hand_r64_v5")
+    hit = np.zeros(64 * 64, dtype=np.uint8)
+    hit[g["b1_ind"]] = 1
+    soft = views.process_mask(hit.reshape(64, 64))
+    np.testing.assert_allclose(soft, g["soft_mask"], rtol=0, atol=1e-7)
+    assert np.all(soft[-1] == 0.5) and soft.min() >= 0 and soft.max() <= 1
+
+
+def test_dihedral_and_sm_loss(hand):
+    g = golden("hand_smooth_sm")
+    V = torch.tensor(g["vertices"].astype(np.float64), requires_grad=True)
+    E2F = torch.tensor(g["E2F"])
+    cosang = orc.dihedral_cos(V, E2F)
+    close(cosang, g["dihedral_cos"])
+    sm = orc.sm_loss(V, E2F)
+    assert sm.item() == pytest.approx(float(g["sm_loss"]), rel=1e-12)
+    g_sm, = torch.autograd.grad(sm, V)
+    close(g_sm, g["grad_sm"], rtol=1e-9, atol=1e-11 * np.abs(g["grad_sm"]).max())
+
+
+def test_raw_hull_sm_loss_is_infinite(hand):
+    """some dihedral cosine of raw hand_vh is exactly -1 -> the reference always remeshes first."""
+    _, e2f, _ = mesh_io.edge_tables(hand)
+    sm = orc.sm_loss(torch.tensor(hand.vertices), torch.tensor(e2f))
+    assert torch.isinf(sm) or torch.isnan(sm)
+
+
+def test_two_optimisation_steps(hand):
+    """all_loss weights + limit_hook + SGD(nesterov) over two iterations (reference optim.py:110-130, 155-171, 198-215)."""
+    g = golden("hand_smooth_steps")
+    topo = golden("hand_topology")
+    res = int(g["res"])
+    center, extent = views.mesh_frame(hand.vertices)
+    cams = views.turntable_cameras(center, extent, 72, res, res)
+    Vs = torch.tensor(g["vertices"].astype(np.float64))
+    Edges, E2F = torch.tensor(topo["Edges"]), torch.tensor(topo["E2F"])
+    base = orc.Mesh(hand.faces, Vs)
+
+    def view(k):
+        R, K, Rinv, Kinv = cams[k]
+        o, d = views.generate_ray(res, res, Kinv, Rinv)
+        rng = np.random.default_rng(100 + k)
+        sp = rng.standard_normal((res * res, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0])
+        valid = rng.random(res * res) > 0.1
+        _, hit = orc.intersect_ids(base, o, d)
+        soft = torch.tensor(views.process_mask(hit.numpy().reshape(res, res)), dtype=torch.float64).reshape(-1)
+        cam = tuple(torch.tensor(a, dtype=torch.float64) for a in (R, K, Rinv, Kinv))
+        return o, d, torch.tensor(sp), torch.tensor(valid), soft, cam
+
+    cache = {k: view(k) for k in list(g["ray_views"]) + list(g["sil_views"])}
+    param = torch.zeros_like(Vs)
+    buf = None
+    for it in range(2):
+        p = param.clone().requires_grad_(True)
+        V = Vs + p
+        mesh = orc.Mesh(hand.faces, V)
+        o, d, sp, valid, _, _ = cache[int(g["ray_views"][it])]
+        oo, od, mk = orc.render_transparent(mesh, o, d, float(g["ior"]))
+        ray = orc.ray_loss(oo, od, mk, sp, valid)
+        vh = 0
+        for k in g["sil_views"]:
+            o_k, _, _, _, soft, cam = cache[int(k)]
+            vh = vh + orc.vh_loss_view(mesh, Edges, E2F, cam, o_k[0], soft, res, res)
+        sm = orc.sm_loss(V, E2F)
+        loss = orc.total_loss(ray, vh, sm, res, float(g["mean_len"]))
+        assert loss.item() == pytest.approx(float(g[f"loss{it}"]), rel=1e-11)
+        assert f"ray={ray:g} vh={vh:g} sm={sm:g}" == str(g[f"loss_str{it}"])
+        grad, = torch.autograd.grad(loss, p)
+        grad = orc.limit_grad(grad)
+        close(grad, g[f"grad{it}"], rtol=1e-8, atol=1e-12)
+        param, buf = orc.sgd_nesterov_step(param, grad, buf, float(g["lr"]), float(g["momentum"]))
+        close(param, g[f"param{it}"], rtol=1e-8, atol=1e-13)
+
+
+def test_tracer_edge_cases():
+    # empty ray set, single triangle, miss encoding, t <= 0 rejected, tie -> lowest face id
+    faces = np.array([[0, 1, 2]], dtype=np.int32)
+    verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    T, ID = orc.trace_closest(faces, verts, np.zeros((0, 6), np.float32))
+    assert T.shape == (0,) and ID.shape == (0,)
+    rays = np.array([[0.2, 0.2, 1, 0, 0, -1], [0.2, 0.2, -1, 0, 0, -1], [2, 2, 1, 0, 0, -1], [0.2, 0.2, 0, 0, 0, -1]], np.float32)
+    T, ID = orc.trace_closest(faces, verts, rays)
+    assert list(ID) == [0, -1, -1, -1] and T[0] == 1.0 and np.all(T[1:] == -1.0)
+    faces2 = np.array([[0, 1, 2], [0, 1, 2]], dtype=np.int32)     # coincident duplicates: equal t
+    T, ID = orc.trace_closest(faces2, verts, rays[:1])
+    assert ID[0] == 0
+    # un-normalised direction: t scales inversely (silhouette probes use such rays, DiffRender.py:222-224)
+    T2, _ = orc.trace_closest(faces, verts, np.array([[0.2, 0.2, 1, 0, 0, -4]], np.float32))
+    assert T2[0] == 0.25
