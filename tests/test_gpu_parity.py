@@ -132,7 +132,7 @@ def test_full_size_traversal_equals_gpu_bruteforce(horse50k, res):
         rays = _camera_rays(horse50k, res, view).cuda()
         T, ID = t.intersect(rays)
         hit = ID >= 0
-        assert 0.05 < hit.float().mean().item() < 0.6
+        assert 0.01 < hit.float().mean().item() < 0.6
         sel = torch.nonzero(hit).squeeze(1)
         # every hit ray + an equal number of misses, exhaustively
         miss = torch.nonzero(~hit).squeeze(1)[:: max(1, int((~hit).sum()) // max(1, len(sel)))]
@@ -217,7 +217,7 @@ def test_properties_at_full_size(Render, horse50k):
     out_ori, out_dir, mask = scene.render_transparent(o, d)
     m = mask[:, 0]
     f1, f2 = scene.last_face1, scene.last_face2
-    assert 0.03 < m.float().mean().item() < 0.5
+    assert 0.005 < m.float().mean().item() < 0.5
     assert torch.all(f2[m] >= 0) and torch.all(f2[~m] == -1) and torch.all(f1[m] >= 0)
     assert torch.all(out_ori[~m] == 0) and torch.all(out_dir[~m] == 0)
     nrm = out_dir.detach()[m].norm(dim=1)
