@@ -40,9 +40,10 @@ static int fail(int code, const char* fmt, ...) {
 // scene object
 // ------------------------------------------------------------------------------------------
 constexpr int kTraceBlock = 128;       // threads per block in traversal kernels (2 waves)
-constexpr int kStackFast = 32;         // LDS stack entries per lane
-constexpr int kStackSlowDev = 32;      // global overflow entries per thread (height <= 30 + log2 F)
-constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (grid-stride beyond)
+constexpr int kStackFast = 20;         // LDS stack entries per lane (10 KB per block -> 16 blocks = 32 waves per CU)
+constexpr int kStackSlowDev = 44;      // global overflow entries per thread (LBVH height <= 30 + log2 F <= 64)
+constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
+constexpr int64_t kChunkRays = 1 << 24; // rays per pipeline pass; bounds the queue workspace (40 B per ray)
 
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
 
@@ -68,6 +69,16 @@ struct drt_scene {
     BuildParams* params = nullptr;
     int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev]
     unsigned long long* scratch = nullptr;  // small counters
+    // wavefront-pipeline workspace, sized for one chunk of rays, allocated on first use
+    int32_t *q1 = nullptr, *q2 = nullptr;
+    float* exit32 = nullptr;       // [cap,6] float32 exit rays of the fused path
+    int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;   // fused path keeps face ids here
+    unsigned* qcount = nullptr;    // [2]
+    int64_t q_cap = 0, fused_cap = 0;
+    int n_cu = 256;
+    int grid_trace = 2048;         // resident blocks of the pure-traversal kernels
+    int grid_bounce = 2048;        // resident blocks of k_bounce (more registers)
+
     bool built = false;
 };
 
@@ -375,23 +386,135 @@ __global__ void __launch_bounds__(256) k_bruteforce(const TriRec* __restrict__ t
     if (live) { T[i] = best_face >= 0 ? best : -1.0f; ID[i] = best_face; }
 }
 
-__global__ void __launch_bounds__(kTraceBlock) k_render_fwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                             int64_t n, double* __restrict__ out_ori, double* __restrict__ out_dir,
-                                                             uint8_t* __restrict__ mask, int32_t* __restrict__ face1, int32_t* __restrict__ face2) {
+// ---- the two-bounce refraction path as a compacted wavefront pipeline ---------------------
+//
+// Only ~5-25 % of camera rays hit the object and the three traversals of a path have very
+// different lengths, so one thread per ray start-to-end leaves most lanes of a wave idle
+// (measured: 25 % VALU lane utilisation, 67 % of wave time waiting).  Instead each stage
+// appends the indices of its surviving rays to a queue with ONE wave-aggregated atomic per
+// wave, and the next stage runs over the queue with full waves:
+//   k_primary   all rays           : closest hit #1 -> face1; miss: write zeros; hit: push Q1
+//   k_bounce    Q1                 : shade #1, closest hit #2, shade #2 -> provisional
+//                                    out_ori/out_dir/mask/face2, push Q2; dead paths: zeros
+//   k_occlusion Q2                 : any-hit of the exit ray; occluded -> zeros, face2 = -1
+// Queues hold int32 ray indices of the current chunk; counters live next to them.
+struct Queues {
+    int32_t* q1;
+    int32_t* q2;
+    unsigned* count;   // [0] = |Q1|, [1] = |Q2|
+};
+
+__device__ __forceinline__ int queue_push(bool pred, unsigned* counter) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    return pred ? (int)(base + __popcll(m & ((1ull << lane) - 1ull))) : -1;
+}
+
+__device__ __forceinline__ void write_dead(int64_t i, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face2) {
+    const d3 z{0.0, 0.0, 0.0};
+    store_d3(out_ori, i, z);
+    store_d3(out_dir, i, z);
+    mask[3 * i] = 0; mask[3 * i + 1] = 0; mask[3 * i + 2] = 0;
+    face2[i] = -1;
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kTraceBlock) k_primary(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                          const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
+                                                          double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                          int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        int32_t f1 = -1;
+        // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
+        if (!FUSED || valid[i]) {
+            const f3 o = to_f32(load_d3(origin, i)), d = to_f32(load_d3(dir, i));
+            f1 = traverse<false>(c.nodes, c.tris, c.n_tris, o, d, st).face;
+        }
+        face1[i] = f1;
+        if (!FUSED && f1 < 0) write_dead(i, out_ori, out_dir, mask, face2);
+        const int slot = queue_push(f1 >= 0, &q.count[0]);
+        if (slot >= 0) q.q1[slot] = (int32_t)i;
+    }
+}
+
+// FUSED: nothing dense is written; survivors carry (ray, face2) in Q2 and the float32 exit ray in `exit32`.
+template <bool FUSED>
+__global__ void __launch_bounds__(kTraceBlock) k_bounce(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                         const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q,
+                                                         float* __restrict__ exit32) {
     __shared__ int32_t lds[kStackFast][kTraceBlock];
     Stack st = make_stack(lds, c.tc);
-    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+    const unsigned n1 = q.count[0];
+    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n1; k += gridDim.x * kTraceBlock) {
+        const int64_t i = q.q1[k];
         const d3 o = load_d3(origin, i), d = load_d3(dir, i);
-        int32_t f1, f2;
-        d3 eo{0.0, 0.0, 0.0}, ed{0.0, 0.0, 0.0};
-        const bool ok = trace_path(c, st, o, d, f1, f2, eo, ed);
-        const d3 z{0.0, 0.0, 0.0};
-        store_d3(out_ori, i, ok ? eo : z);
-        store_d3(out_dir, i, ok ? ed : z);
-        const uint8_t m = ok ? 1 : 0;
-        mask[3 * i] = m; mask[3 * i + 1] = m; mask[3 * i + 2] = m;
-        face1[i] = f1;
-        face2[i] = f2;
+        d3 v0, v1, v2;
+        int32_t vid[3];
+        Bounce b;
+        load_tri64(c, face1[i], v0, v1, v2, vid);
+        bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b);
+        bool ok = !b.tir;
+        int32_t f2 = -1;
+        d3 o2 = b.new_o, d2 = b.wt;
+        if (ok) {
+            f2 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(o2), to_f32(d2), st).face;
+            ok = f2 >= 0;
+        }
+        if (ok) {
+            load_tri64(c, f2, v0, v1, v2, vid);
+            bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
+            ok = !b.tir;
+        }
+        if (!FUSED) {
+            if (ok) {
+                store_d3(out_ori, i, b.new_o);
+                store_d3(out_dir, i, b.wt);
+                mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
+                face2[i] = f2;
+            } else {
+                write_dead(i, out_ori, out_dir, mask, face2);
+            }
+        }
+        const int slot = queue_push(ok, &q.count[1]);
+        if (slot >= 0) {
+            q.q2[slot] = (int32_t)i;
+            if (FUSED) {
+                face2[i] = f2;
+                const f3 eo = to_f32(b.new_o), ed = to_f32(b.wt);
+                float* e = exit32 + 6 * (int64_t)slot;
+                e[0] = eo.x; e[1] = eo.y; e[2] = eo.z; e[3] = ed.x; e[4] = ed.y; e[5] = ed.z;
+            }
+        }
+    }
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kTraceBlock) k_occlusion(TraceCtx c, double* __restrict__ out_ori, double* __restrict__ out_dir,
+                                                            uint8_t* __restrict__ mask, int32_t* __restrict__ face2, Queues q,
+                                                            const float* __restrict__ exit32) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    const unsigned n2 = q.count[1];
+    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n2; k += gridDim.x * kTraceBlock) {
+        const int64_t i = q.q2[k];
+        f3 o, d;
+        if (FUSED) {
+            const float* e = exit32 + 6 * (int64_t)k;
+            o = f3{e[0], e[1], e[2]}; d = f3{e[3], e[4], e[5]};
+        } else {
+            o = to_f32(load_d3(out_ori, i)); d = to_f32(load_d3(out_dir, i));
+        }
+        if (traverse<true>(c.nodes, c.tris, c.n_tris, o, d, st).face >= 0) {
+            if (FUSED) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2);
+        }
     }
 }
 
@@ -404,19 +527,26 @@ struct AtomicAdd3 {
     }
 };
 
-__global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir, int64_t n,
+// Backward, stage 1: compact the rays whose path completed (face2 >= 0) into Q1.
+__global__ void __launch_bounds__(256) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, Queues q) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = queue_push(face2[i] >= 0, &q.count[0]);
+        if (slot >= 0) q.q1[slot] = (int32_t)i;
+    }
+}
+
+// Backward, stage 2 (full waves): recompute both bounces from (face1, face2), reverse, scatter.
+__global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                     const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
                                                     const double* __restrict__ g_out_ori, const double* __restrict__ g_out_dir,
-                                                    double* grad_verts) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t f2 = face2[i];
-        if (f2 < 0) continue;
-        const int32_t f1 = face1[i];
-        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+                                                    double* grad_verts, Queues q) {
+    const unsigned n1 = q.count[0];
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += gridDim.x * blockDim.x) {
+        const int64_t i = q.q1[k];
         const d3 z{0.0, 0.0, 0.0};
         const d3 g_ori = g_out_ori ? load_d3(g_out_ori, i) : z;
         const d3 g_dir = g_out_dir ? load_d3(g_out_dir, i) : z;
-        path_recompute_backward(c, o, d, f1, f2, g_ori, g_dir, AtomicAdd3{grad_verts});
+        path_recompute_backward(c, load_d3(origin, i), load_d3(dir, i), face1[i], face2[i], g_ori, g_dir, AtomicAdd3{grad_verts});
     }
 }
 
@@ -439,23 +569,37 @@ __global__ void __launch_bounds__(256) k_ray_loss(const double* __restrict__ out
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
 }
 
-__global__ void __launch_bounds__(kTraceBlock) k_render_loss_fused(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                                    const double* __restrict__ screen_pixel, const uint8_t* __restrict__ valid,
-                                                                    int64_t n, double* loss, double* grad_verts, unsigned long long* n_valid) {
-    __shared__ int32_t lds[kStackFast][kTraceBlock];
-    Stack st = make_stack(lds, c.tc);
+// Fused loss, last stage (full waves over Q2): recompute the path in float64, loss term, adjoint.
+__global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                        const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
+                                                        const int32_t* __restrict__ face2, Queues q, double* loss, double* grad_verts,
+                                                        unsigned long long* n_valid) {
+    const unsigned n2 = q.count[1];
     double acc = 0.0;
     unsigned cnt = 0;
-    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
-        if (!valid[i]) continue;   // the loss ignores these pixels (reference optim.py:105), so does the trace
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += gridDim.x * blockDim.x) {
+        const int64_t i = q.q2[k];
+        const int32_t f2 = face2[i];
+        if (f2 < 0) continue;   // occluded exit ray
         const d3 o = load_d3(origin, i), d = load_d3(dir, i);
-        int32_t f1, f2;
-        d3 eo, ed;
-        if (!trace_path(c, st, o, d, f1, f2, eo, ed)) continue;
+        d3 v0, v1, v2;
+        int32_t vid1[3], vid2[3];
+        Bounce b1, b2;
+        load_tri64(c, face1[i], v0, v1, v2, vid1);
+        bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b1);
+        load_tri64(c, f2, v0, v1, v2, vid2);
+        bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
         d3 g_dir;
-        acc += ray_loss_term(eo, ed, load_d3(screen_pixel, i), g_dir);
+        acc += ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
         ++cnt;
-        path_recompute_backward(c, o, d, f1, f2, d3{0.0, 0.0, 0.0}, g_dir, AtomicAdd3{grad_verts});
+        const d3 z{0.0, 0.0, 0.0};
+        d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
+        bounce_backward(b2, z, g_dir, ga, gb, gc, g_o, g_d);
+        const AtomicAdd3 add{grad_verts};
+        add(vid2[0], ga); add(vid2[1], gb); add(vid2[2], gc);
+        ga = z; gb = z; gc = z;
+        bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
+        add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
@@ -547,6 +691,18 @@ int drt_create(int device, drt_scene_t** out) {
     hipError_t e = hipMalloc(&s->params, sizeof(BuildParams));
     if (e == hipSuccess) e = hipMalloc(&s->slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
     if (e == hipSuccess) e = hipMalloc(&s->scratch, sizeof(unsigned long long) * 8);
+    if (e == hipSuccess) e = hipMalloc(&s->qcount, sizeof(unsigned) * 4);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_primary<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        s->grid_trace = s->n_cu * per_cu;
+        if (s->grid_trace > kTraceGridMax) s->grid_trace = kTraceGridMax;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bounce<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        s->grid_bounce = s->n_cu * per_cu;
+        if (s->grid_bounce > kTraceGridMax) s->grid_bounce = kTraceGridMax;
+    }
     if (e != hipSuccess) {
         drt_destroy(s);
         return fail(DRT_E_HIP, "hipMalloc: %s", hipGetErrorString(e));
@@ -562,6 +718,8 @@ void drt_destroy(drt_scene_t* s) {
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
     (void)hipFree(s->scratch);
+    (void)hipFree(s->q1); (void)hipFree(s->q2); (void)hipFree(s->exit32);
+    (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2); (void)hipFree(s->qcount);
     delete s;
 }
 
@@ -599,7 +757,7 @@ int drt_intersect(drt_scene_t* s, const float* d_rays, int64_t n_rays, float* d_
     CHECK_BUILT(s);
     if (n_rays < 0 || (n_rays && (!d_rays || !d_T || !d_ID))) return fail(DRT_E_INVALID, "bad ray arguments");
     if (n_rays == 0) return DRT_OK;
-    k_intersect<false><<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, d_T, d_ID, nullptr);
+    k_intersect<false><<<grid_for(n_rays, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, d_T, d_ID, nullptr);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -608,7 +766,7 @@ int drt_intersect_any(drt_scene_t* s, const float* d_rays, int64_t n_rays, uint8
     CHECK_BUILT(s);
     if (n_rays < 0 || (n_rays && (!d_rays || !d_hit))) return fail(DRT_E_INVALID, "bad ray arguments");
     if (n_rays == 0) return DRT_OK;
-    k_intersect<true><<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, nullptr, nullptr, d_hit);
+    k_intersect<true><<<grid_for(n_rays, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, nullptr, nullptr, d_hit);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -649,6 +807,27 @@ static PathCtx path_ctx(const drt_scene* s, const double* d_verts, double ior_in
     return PathCtx{trace_ctx(s), s->faces, d_verts, ior_int, ior_ext};
 }
 
+// Queue workspace for one chunk of `n` rays (grown, never shrunk).  Growing frees the old buffers,
+// which synchronises the device once; steady-state calls allocate nothing.
+static int ensure_queues(drt_scene* s, int64_t n, bool fused) {
+    if (n > s->q_cap) {
+        (void)hipFree(s->q1); (void)hipFree(s->q2);
+        s->q1 = s->q2 = nullptr; s->q_cap = 0;
+        HIP_TRY(hipMalloc(&s->q1, sizeof(int32_t) * n));
+        HIP_TRY(hipMalloc(&s->q2, sizeof(int32_t) * n));
+        s->q_cap = n;
+    }
+    if (fused && n > s->fused_cap) {
+        (void)hipFree(s->exit32); (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2);
+        s->exit32 = nullptr; s->tmp_face1 = s->tmp_face2 = nullptr; s->fused_cap = 0;
+        HIP_TRY(hipMalloc(&s->exit32, sizeof(float) * 6 * n));
+        HIP_TRY(hipMalloc(&s->tmp_face1, sizeof(int32_t) * n));
+        HIP_TRY(hipMalloc(&s->tmp_face2, sizeof(int32_t) * n));
+        s->fused_cap = n;
+    }
+    return DRT_OK;
+}
+
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
                        int32_t* d_face1, int32_t* d_face2, void* stream) {
@@ -656,8 +835,22 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
-    k_render_fwd<<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(
-        path_ctx(s, d_verts, ior_int, ior_ext), d_origin, d_dir, n_rays, d_out_ori, d_out_dir, d_mask, d_face1, d_face2);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+    int rc = ensure_queues(s, chunk, false);
+    if (rc) return rc;
+    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    const Queues q{s->q1, s->q2, s->qcount};
+    for (int64_t b = 0; b < n_rays; b += chunk) {
+        const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
+        HIP_TRY(hipMemsetAsync(s->qcount, 0, 2 * sizeof(unsigned), st));
+        const int g = grid_for(n, kTraceBlock, s->grid_trace);
+        k_primary<false><<<g, kTraceBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                                                     d_mask + 3 * b, d_face1 + b, d_face2 + b, q);
+        k_bounce<false><<<s->grid_bounce, kTraceBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                                                                d_mask + 3 * b, d_face1 + b, d_face2 + b, q, nullptr);
+        k_occlusion<false><<<s->grid_trace, kTraceBlock, 0, st>>>(pc.tc, d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, q, nullptr);
+    }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -669,8 +862,20 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
     if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
     if (n_rays == 0 || (!d_grad_out_ori && !d_grad_out_dir)) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_face1 || !d_face2 || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
-    k_render_bwd<<<grid_for(n_rays, 256, 8192), 256, 0, (hipStream_t)stream>>>(
-        path_ctx(s, d_verts, ior_int, ior_ext), d_origin, d_dir, n_rays, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+    int rc = ensure_queues(s, chunk, false);
+    if (rc) return rc;
+    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    const Queues q{s->q1, s->q2, s->qcount};
+    for (int64_t b = 0; b < n_rays; b += chunk) {
+        const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
+        HIP_TRY(hipMemsetAsync(s->qcount, 0, 2 * sizeof(unsigned), st));
+        k_collect_valid<<<grid_for(n, 256, 8 * s->n_cu), 256, 0, st>>>(d_face2 + b, n, q);
+        k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_face1 + b, d_face2 + b,
+                                                   d_grad_out_ori ? d_grad_out_ori + 3 * b : nullptr,
+                                                   d_grad_out_dir ? d_grad_out_dir + 3 * b : nullptr, d_grad_verts, q);
+    }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -692,9 +897,24 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
-    k_render_loss_fused<<<grid_for(n_rays, kTraceBlock, kTraceGridMax), kTraceBlock, 0, (hipStream_t)stream>>>(
-        path_ctx(s, d_verts, ior_int, ior_ext), d_origin, d_dir, d_screen_pixel, d_valid, n_rays, d_loss, d_grad_verts,
-        reinterpret_cast<unsigned long long*>(d_n_valid));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+    int rc = ensure_queues(s, chunk, true);
+    if (rc) return rc;
+    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    const Queues q{s->q1, s->q2, s->qcount};
+    for (int64_t b = 0; b < n_rays; b += chunk) {
+        const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
+        HIP_TRY(hipMemsetAsync(s->qcount, 0, 2 * sizeof(unsigned), st));
+        const int g = grid_for(n, kTraceBlock, s->grid_trace);
+        k_primary<true><<<g, kTraceBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr,
+                                                    s->tmp_face1, s->tmp_face2, q);
+        k_bounce<true><<<s->grid_bounce, kTraceBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr,
+                                                               s->tmp_face1, s->tmp_face2, q, s->exit32);
+        k_occlusion<true><<<s->grid_trace, kTraceBlock, 0, st>>>(pc.tc, nullptr, nullptr, nullptr, s->tmp_face2, q, s->exit32);
+        k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, q,
+                                                       d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid));
+    }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

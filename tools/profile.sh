@@ -1,0 +1,46 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of bench.py.
+# Big raw outputs stay in /tmp; only summaries land in gpurun_out/<tag>/.
+# usage: tools/profile.sh <tag> [bench args...]
+set -u
+TAG=${1:-prof}; shift || true
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+export TMPDIR=/tmp
+W=/tmp/prof_$TAG; rm -rf "$W"; mkdir -p "$W"
+cd "$R"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$W/kt" -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$O/bench_under_rocprof.log" 2>&1
+find "$W/kt" -name '*kernel_stats.csv' -exec cp {} "$O/kernel_stats.csv" \;
+python - "$W/kt" "$O" <<'PY'
+import csv, glob, sys, collections
+src, out = sys.argv[1], sys.argv[2]
+files = glob.glob(src + '/**/*kernel_trace.csv', recursive=True)
+agg = collections.defaultdict(list)
+meta = {}
+for f in files:
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0]
+        agg[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        meta[k] = (r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'), r.get('Workgroup_Size'), r.get('Grid_Size'))
+tot = sum(sum(v) for v in agg.values()) or 1
+with open(out + '/kernel_summary.txt', 'w') as o:
+    o.write(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}  vgpr sgpr lds wg grid\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        o.write(f"{k[:60]:60s} {len(v):6d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:10.2f} {100*sum(v)/tot:6.2f}  {meta[k]}\n")
+PY
+run_pmc () {  # name counters...
+  local name=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "${BARGS[@]}" > "$O/$name.log" 2>&1
+  local f=$(find "$W/$name" -name '*counter_collection.csv' | head -1)
+  if [ -n "$f" ]; then python tools/pmc_summary.py "$f" k_ > "$O/$name.txt"; else echo "no counter file" > "$O/$name.txt"; fi
+}
+BARGS=("$@")
+run_pmc pmc_sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+run_pmc pmc_sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR
+run_pmc pmc_tcc TCC_HIT_sum TCC_MISS_sum
+run_pmc pmc_tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
+run_pmc pmc_fetch FETCH_SIZE
+run_pmc pmc_write WRITE_SIZE
+run_pmc pmc_grbm GRBM_GUI_ACTIVE
+du -sh "$O"; cat "$O/kernel_summary.txt" | head -25
