@@ -40,8 +40,8 @@ static int fail(int code, const char* fmt, ...) {
 // scene object
 // ------------------------------------------------------------------------------------------
 constexpr int kTraceBlock = 128;       // threads per block in traversal kernels (2 waves)
-constexpr int kStackFast = 20;         // LDS stack entries per lane (10 KB per block -> 16 blocks = 32 waves per CU)
-constexpr int kStackSlowDev = 44;      // global overflow entries per thread (LBVH height <= 30 + log2 F <= 64)
+constexpr int kStackFast = 19;         // LDS stack entries per lane (19.5 KB per 256-thread block -> 8 blocks = 32 waves per CU)
+constexpr int kStackSlowDev = 45;      // global overflow entries per thread (LBVH height <= 30 + log2 F <= 64)
 constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
 constexpr int64_t kChunkRays = 1 << 24; // rays per pipeline pass; bounds the queue workspace (40 B per ray)
 
@@ -70,14 +70,15 @@ struct drt_scene {
     int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev]
     unsigned long long* scratch = nullptr;  // small counters
     // wavefront-pipeline workspace, sized for one chunk of rays, allocated on first use
-    int32_t *q1 = nullptr, *q2 = nullptr;
+    int32_t *q0 = nullptr, *q1 = nullptr, *q2 = nullptr;
     float* exit32 = nullptr;       // [cap,6] float32 exit rays of the fused path
     int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;   // fused path keeps face ids here
-    unsigned* qcount = nullptr;    // [2]
+    unsigned* qcount = nullptr;    // [4]
     int64_t q_cap = 0, fused_cap = 0;
     int n_cu = 256;
     int grid_trace = 2048;         // resident blocks of the pure-traversal kernels
-    int grid_bounce = 2048;        // resident blocks of k_bounce (more registers)
+    int grid_bounce = 1024;        // resident blocks of k_bounce (more registers)
+    int grid_path = 2048;          // resident 256-thread blocks of k_primary / k_occlusion
 
     bool built = false;
 };
@@ -390,29 +391,54 @@ __global__ void __launch_bounds__(256) k_bruteforce(const TriRec* __restrict__ t
 //
 // Only ~5-25 % of camera rays hit the object and the three traversals of a path have very
 // different lengths, so one thread per ray start-to-end leaves most lanes of a wave idle
-// (measured: 25 % VALU lane utilisation, 67 % of wave time waiting).  Instead each stage
-// appends the indices of its surviving rays to a queue with ONE wave-aggregated atomic per
-// wave, and the next stage runs over the queue with full waves:
-//   k_primary   all rays           : closest hit #1 -> face1; miss: write zeros; hit: push Q1
-//   k_bounce    Q1                 : shade #1, closest hit #2, shade #2 -> provisional
-//                                    out_ori/out_dir/mask/face2, push Q2; dead paths: zeros
-//   k_occlusion Q2                 : any-hit of the exit ray; occluded -> zeros, face2 = -1
-// Queues hold int32 ray indices of the current chunk; counters live next to them.
+// (measured: 25 % VALU lane utilisation, 67 % of wave time waiting), and a static ray->wave
+// map leaves most waves with nothing but misses.  Instead every stage appends the indices of
+// its surviving rays to a queue and the next stage runs over the queue with full waves:
+//   k_cull      all rays : slab test against the two top-level boxes; definite miss -> write
+//                          zeros (pure streaming); candidate -> push Q0
+//   k_primary   Q0       : closest hit #1 -> face1; miss: zeros; hit: push Q1
+//   k_bounce    Q1       : shade #1, closest hit #2, shade #2 -> provisional
+//                          out_ori/out_dir/mask/face2, push Q2; dead paths: zeros
+//   k_occlusion Q2       : any-hit of the exit ray; occluded -> zeros, face2 = -1
+// Queues hold int32 ray indices of the current chunk.  A push costs ONE returning atomic per
+// 256-thread block iteration (a single counter word sustains only ~90 returning atomics per
+// microsecond on MI355X, so per-wave pushes would cap the pipeline).
+constexpr int kPathBlock = 256;
+constexpr int kPathWaves = kPathBlock / 64;
+
 struct Queues {
+    int32_t* q0;
     int32_t* q1;
     int32_t* q2;
-    unsigned* count;   // [0] = |Q1|, [1] = |Q2|
+    unsigned* count;   // [0] = |Q0|, [1] = |Q1|, [2] = |Q2|
 };
 
-__device__ __forceinline__ int queue_push(bool pred, unsigned* counter) {
+// Block-wide ordered compaction: returns the queue slot of this thread's item, or -1.
+// Must be reached by every thread of the block (contains barriers).
+__device__ __forceinline__ int block_push(bool pred, unsigned* counter, unsigned* s_tmp /* [kPathWaves + 1] */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(pred);
-    if (m == 0) return -1;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-    base = __shfl(base, leader);
-    return pred ? (int)(base + __popcll(m & ((1ull << lane) - 1ull))) : -1;
+    if (lane == 0) s_tmp[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < kPathWaves; ++w) { const unsigned c = s_tmp[w]; s_tmp[w] = tot; tot += c; }
+        s_tmp[kPathWaves] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const int slot = pred ? (int)(s_tmp[kPathWaves] + s_tmp[wave] + __popcll(m & ((1ull << lane) - 1ull))) : -1;
+    __syncthreads();
+    return slot;
+}
+
+__device__ __forceinline__ Stack make_stack256(int32_t (*lds)[kPathBlock], const TraceCtx& c) {
+    Stack st;
+    st.fast = &lds[0][threadIdx.x];
+    st.stride = kPathBlock;
+    st.depth_fast = kStackFast;
+    st.slow = c.slow_stack + ((int64_t)blockIdx.x * kPathBlock + threadIdx.x) * kStackSlowDev;
+    st.sp = 0;
+    return st;
 }
 
 __device__ __forceinline__ void write_dead(int64_t i, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face2) {
@@ -423,67 +449,118 @@ __device__ __forceinline__ void write_dead(int64_t i, double* out_ori, double* o
     face2[i] = -1;
 }
 
+// Conservative "can this ray touch the mesh at all": the root node's two child boxes.
+__device__ __forceinline__ bool hits_top_boxes(const Node* __restrict__ nodes, f3 o, f3 d) {
+    const F4* np = reinterpret_cast<const F4*>(nodes);
+    const F4 a = np[0], b = np[1], c = np[2];
+    const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
+    const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
+    float t0 = fmaf(a.x, inv.x, oi.x), t1 = fmaf(a.y, inv.x, oi.x);
+    float tmin0 = fminf(t0, t1), tmax0 = fmaxf(t0, t1);
+    t0 = fmaf(a.z, inv.y, oi.y); t1 = fmaf(a.w, inv.y, oi.y);
+    tmin0 = fmaxf(tmin0, fminf(t0, t1)); tmax0 = fminf(tmax0, fmaxf(t0, t1));
+    t0 = fmaf(c.x, inv.z, oi.z); t1 = fmaf(c.y, inv.z, oi.z);
+    tmin0 = fmaxf(tmin0, fminf(t0, t1)); tmax0 = fminf(tmax0, fmaxf(t0, t1));
+    t0 = fmaf(b.x, inv.x, oi.x); t1 = fmaf(b.y, inv.x, oi.x);
+    float tmin1 = fminf(t0, t1), tmax1 = fmaxf(t0, t1);
+    t0 = fmaf(b.z, inv.y, oi.y); t1 = fmaf(b.w, inv.y, oi.y);
+    tmin1 = fmaxf(tmin1, fminf(t0, t1)); tmax1 = fminf(tmax1, fmaxf(t0, t1));
+    t0 = fmaf(c.z, inv.z, oi.z); t1 = fmaf(c.w, inv.z, oi.z);
+    tmin1 = fmaxf(tmin1, fminf(t0, t1)); tmax1 = fminf(tmax1, fmaxf(t0, t1));
+    return (fmaxf(tmin0, 0.0f) <= tmax0) | (fmaxf(tmin1, 0.0f) <= tmax1);
+}
+
 template <bool FUSED>
-__global__ void __launch_bounds__(kTraceBlock) k_primary(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                          const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
-                                                          double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                          int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q) {
-    __shared__ int32_t lds[kStackFast][kTraceBlock];
-    Stack st = make_stack(lds, c);
-    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
-        int32_t f1 = -1;
-        // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
-        if (!FUSED || valid[i]) {
-            const f3 o = to_f32(load_d3(origin, i)), d = to_f32(load_d3(dir, i));
-            f1 = traverse<false>(c.nodes, c.tris, c.n_tris, o, d, st).face;
+__global__ void __launch_bounds__(kPathBlock) k_cull(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                      const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
+                                                      double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        const int64_t i = base + threadIdx.x;
+        bool cand = false;
+        if (i < n) {
+            // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
+            if (!FUSED || valid[i]) cand = c.n_tris > 0 && hits_top_boxes(c.nodes, to_f32(load_d3(origin, i)), to_f32(load_d3(dir, i)));
+            if (!cand) {
+                face1[i] = -1;
+                if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
+            }
         }
-        face1[i] = f1;
-        if (!FUSED && f1 < 0) write_dead(i, out_ori, out_dir, mask, face2);
-        const int slot = queue_push(f1 >= 0, &q.count[0]);
+        const int slot = block_push(cand, &q.count[0], s_tmp);
+        if (slot >= 0) q.q0[slot] = (int32_t)i;
+    }
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock) k_primary(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                         int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q) {
+    __shared__ int32_t lds[kStackFast][kPathBlock];
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    Stack st = make_stack256(lds, c);
+    const unsigned n0 = q.count[0];
+    for (unsigned base = blockIdx.x * kPathBlock; base < n0; base += gridDim.x * kPathBlock) {
+        const unsigned k = base + threadIdx.x;
+        int64_t i = 0;
+        int32_t f1 = -1;
+        if (k < n0) {
+            i = q.q0[k];
+            f1 = traverse<false>(c.nodes, c.tris, c.n_tris, to_f32(load_d3(origin, i)), to_f32(load_d3(dir, i)), st).face;
+            face1[i] = f1;
+            if (!FUSED && f1 < 0) write_dead(i, out_ori, out_dir, mask, face2);
+        }
+        const int slot = block_push(f1 >= 0, &q.count[1], s_tmp);
         if (slot >= 0) q.q1[slot] = (int32_t)i;
     }
 }
 
 // FUSED: nothing dense is written; survivors carry (ray, face2) in Q2 and the float32 exit ray in `exit32`.
 template <bool FUSED>
-__global__ void __launch_bounds__(kTraceBlock) k_bounce(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                         const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q,
-                                                         float* __restrict__ exit32) {
-    __shared__ int32_t lds[kStackFast][kTraceBlock];
-    Stack st = make_stack(lds, c.tc);
-    const unsigned n1 = q.count[0];
-    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n1; k += gridDim.x * kTraceBlock) {
-        const int64_t i = q.q1[k];
-        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
-        d3 v0, v1, v2;
-        int32_t vid[3];
-        Bounce b;
-        load_tri64(c, face1[i], v0, v1, v2, vid);
-        bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b);
-        bool ok = !b.tir;
+__global__ void __launch_bounds__(kPathBlock) k_bounce(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                        double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q,
+                                                        float* __restrict__ exit32) {
+    __shared__ int32_t lds[kStackFast][kPathBlock];
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    Stack st = make_stack256(lds, c.tc);
+    const unsigned n1 = q.count[1];
+    for (unsigned base = blockIdx.x * kPathBlock; base < n1; base += gridDim.x * kPathBlock) {
+        const unsigned k = base + threadIdx.x;
+        bool ok = false;
+        int64_t i = 0;
         int32_t f2 = -1;
-        d3 o2 = b.new_o, d2 = b.wt;
-        if (ok) {
-            f2 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(o2), to_f32(d2), st).face;
-            ok = f2 >= 0;
-        }
-        if (ok) {
-            load_tri64(c, f2, v0, v1, v2, vid);
-            bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
+        Bounce b;
+        if (k < n1) {
+            i = q.q1[k];
+            const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+            d3 v0, v1, v2;
+            int32_t vid[3];
+            load_tri64(c, face1[i], v0, v1, v2, vid);
+            bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b);
             ok = !b.tir;
-        }
-        if (!FUSED) {
+            const d3 o2 = b.new_o, d2 = b.wt;
             if (ok) {
-                store_d3(out_ori, i, b.new_o);
-                store_d3(out_dir, i, b.wt);
-                mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
-                face2[i] = f2;
-            } else {
-                write_dead(i, out_ori, out_dir, mask, face2);
+                f2 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(o2), to_f32(d2), st).face;
+                ok = f2 >= 0;
+            }
+            if (ok) {
+                load_tri64(c, f2, v0, v1, v2, vid);
+                bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
+                ok = !b.tir;
+            }
+            if (!FUSED) {
+                if (ok) {
+                    store_d3(out_ori, i, b.new_o);
+                    store_d3(out_dir, i, b.wt);
+                    mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
+                    face2[i] = f2;
+                } else {
+                    write_dead(i, out_ori, out_dir, mask, face2);
+                }
             }
         }
-        const int slot = queue_push(ok, &q.count[1]);
+        const int slot = block_push(ok, &q.count[2], s_tmp);
         if (slot >= 0) {
             q.q2[slot] = (int32_t)i;
             if (FUSED) {
@@ -497,13 +574,13 @@ __global__ void __launch_bounds__(kTraceBlock) k_bounce(PathCtx c, const double*
 }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(kTraceBlock) k_occlusion(TraceCtx c, double* __restrict__ out_ori, double* __restrict__ out_dir,
-                                                            uint8_t* __restrict__ mask, int32_t* __restrict__ face2, Queues q,
-                                                            const float* __restrict__ exit32) {
-    __shared__ int32_t lds[kStackFast][kTraceBlock];
-    Stack st = make_stack(lds, c);
-    const unsigned n2 = q.count[1];
-    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n2; k += gridDim.x * kTraceBlock) {
+__global__ void __launch_bounds__(kPathBlock) k_occlusion(TraceCtx c, double* __restrict__ out_ori, double* __restrict__ out_dir,
+                                                           uint8_t* __restrict__ mask, int32_t* __restrict__ face2, Queues q,
+                                                           const float* __restrict__ exit32) {
+    __shared__ int32_t lds[kStackFast][kPathBlock];
+    Stack st = make_stack256(lds, c);
+    const unsigned n2 = q.count[2];
+    for (unsigned k = blockIdx.x * kPathBlock + threadIdx.x; k < n2; k += gridDim.x * kPathBlock) {
         const int64_t i = q.q2[k];
         f3 o, d;
         if (FUSED) {
@@ -528,9 +605,11 @@ struct AtomicAdd3 {
 };
 
 // Backward, stage 1: compact the rays whose path completed (face2 >= 0) into Q1.
-__global__ void __launch_bounds__(256) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, Queues q) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int slot = queue_push(face2[i] >= 0, &q.count[0]);
+__global__ void __launch_bounds__(kPathBlock) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, Queues q) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        const int64_t i = base + threadIdx.x;
+        const int slot = block_push(i < n && face2[i] >= 0, &q.count[1], s_tmp);
         if (slot >= 0) q.q1[slot] = (int32_t)i;
     }
 }
@@ -540,7 +619,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __r
                                                     const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
                                                     const double* __restrict__ g_out_ori, const double* __restrict__ g_out_dir,
                                                     double* grad_verts, Queues q) {
-    const unsigned n1 = q.count[0];
+    const unsigned n1 = q.count[1];
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += gridDim.x * blockDim.x) {
         const int64_t i = q.q1[k];
         const d3 z{0.0, 0.0, 0.0};
@@ -574,7 +653,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
                                                         const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
                                                         const int32_t* __restrict__ face2, Queues q, double* loss, double* grad_verts,
                                                         unsigned long long* n_valid) {
-    const unsigned n2 = q.count[1];
+    const unsigned n2 = q.count[2];
     double acc = 0.0;
     unsigned cnt = 0;
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += gridDim.x * blockDim.x) {
@@ -699,9 +778,12 @@ int drt_create(int device, drt_scene_t** out) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_primary<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
         s->grid_trace = s->n_cu * per_cu;
         if (s->grid_trace > kTraceGridMax) s->grid_trace = kTraceGridMax;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bounce<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bounce<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         s->grid_bounce = s->n_cu * per_cu;
-        if (s->grid_bounce > kTraceGridMax) s->grid_bounce = kTraceGridMax;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_primary<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        s->grid_path = s->n_cu * per_cu;
+        if (s->grid_bounce * 2 > kTraceGridMax) s->grid_bounce = kTraceGridMax / 2;
+        if (s->grid_path * 2 > kTraceGridMax) s->grid_path = kTraceGridMax / 2;
     }
     if (e != hipSuccess) {
         drt_destroy(s);
@@ -718,7 +800,7 @@ void drt_destroy(drt_scene_t* s) {
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
     (void)hipFree(s->scratch);
-    (void)hipFree(s->q1); (void)hipFree(s->q2); (void)hipFree(s->exit32);
+    (void)hipFree(s->q0); (void)hipFree(s->q1); (void)hipFree(s->q2); (void)hipFree(s->exit32);
     (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2); (void)hipFree(s->qcount);
     delete s;
 }
@@ -811,8 +893,9 @@ static PathCtx path_ctx(const drt_scene* s, const double* d_verts, double ior_in
 // which synchronises the device once; steady-state calls allocate nothing.
 static int ensure_queues(drt_scene* s, int64_t n, bool fused) {
     if (n > s->q_cap) {
-        (void)hipFree(s->q1); (void)hipFree(s->q2);
-        s->q1 = s->q2 = nullptr; s->q_cap = 0;
+        (void)hipFree(s->q0); (void)hipFree(s->q1); (void)hipFree(s->q2);
+        s->q0 = s->q1 = s->q2 = nullptr; s->q_cap = 0;
+        HIP_TRY(hipMalloc(&s->q0, sizeof(int32_t) * n));
         HIP_TRY(hipMalloc(&s->q1, sizeof(int32_t) * n));
         HIP_TRY(hipMalloc(&s->q2, sizeof(int32_t) * n));
         s->q_cap = n;
@@ -840,16 +923,17 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     int rc = ensure_queues(s, chunk, false);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Queues q{s->q1, s->q2, s->qcount};
+    const Queues q{s->q0, s->q1, s->q2, s->qcount};
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-        HIP_TRY(hipMemsetAsync(s->qcount, 0, 2 * sizeof(unsigned), st));
-        const int g = grid_for(n, kTraceBlock, s->grid_trace);
-        k_primary<false><<<g, kTraceBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                                                     d_mask + 3 * b, d_face1 + b, d_face2 + b, q);
-        k_bounce<false><<<s->grid_bounce, kTraceBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
+        HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
+        k_cull<false><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b,
+                                                                                   d_out_dir + 3 * b, d_mask + 3 * b, d_face1 + b, d_face2 + b, q);
+        k_primary<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                                                               d_mask + 3 * b, d_face1 + b, d_face2 + b, q);
+        k_bounce<false><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
                                                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, q, nullptr);
-        k_occlusion<false><<<s->grid_trace, kTraceBlock, 0, st>>>(pc.tc, d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, q, nullptr);
+        k_occlusion<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, q, nullptr);
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -867,11 +951,11 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
     int rc = ensure_queues(s, chunk, false);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Queues q{s->q1, s->q2, s->qcount};
+    const Queues q{s->q0, s->q1, s->q2, s->qcount};
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-        HIP_TRY(hipMemsetAsync(s->qcount, 0, 2 * sizeof(unsigned), st));
-        k_collect_valid<<<grid_for(n, 256, 8 * s->n_cu), 256, 0, st>>>(d_face2 + b, n, q);
+        HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
+        k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, q);
         k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_face1 + b, d_face2 + b,
                                                    d_grad_out_ori ? d_grad_out_ori + 3 * b : nullptr,
                                                    d_grad_out_dir ? d_grad_out_dir + 3 * b : nullptr, d_grad_verts, q);
@@ -902,16 +986,16 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     int rc = ensure_queues(s, chunk, true);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Queues q{s->q1, s->q2, s->qcount};
+    const Queues q{s->q0, s->q1, s->q2, s->qcount};
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-        HIP_TRY(hipMemsetAsync(s->qcount, 0, 2 * sizeof(unsigned), st));
-        const int g = grid_for(n, kTraceBlock, s->grid_trace);
-        k_primary<true><<<g, kTraceBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr,
-                                                    s->tmp_face1, s->tmp_face2, q);
-        k_bounce<true><<<s->grid_bounce, kTraceBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr,
+        HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
+        k_cull<true><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr,
+                                                                                  nullptr, s->tmp_face1, s->tmp_face2, q);
+        k_primary<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2, q);
+        k_bounce<true><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr,
                                                                s->tmp_face1, s->tmp_face2, q, s->exit32);
-        k_occlusion<true><<<s->grid_trace, kTraceBlock, 0, st>>>(pc.tc, nullptr, nullptr, nullptr, s->tmp_face2, q, s->exit32);
+        k_occlusion<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, nullptr, nullptr, nullptr, s->tmp_face2, q, s->exit32);
         k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, q,
                                                        d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid));
     }

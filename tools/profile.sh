@@ -25,9 +25,27 @@ for f in files:
         meta[k] = (r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'), r.get('Workgroup_Size'), r.get('Grid_Size'))
 tot = sum(sum(v) for v in agg.values()) or 1
 with open(out + '/kernel_summary.txt', 'w') as o:
-    o.write(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}  vgpr sgpr lds wg grid\n")
+    o.write(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'max_us':>10s} {'pct':>6s}  vgpr sgpr lds wg grid\n")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-        o.write(f"{k[:60]:60s} {len(v):6d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:10.2f} {100*sum(v)/tot:6.2f}  {meta[k]}\n")
+        o.write(f"{k[:60]:60s} {len(v):6d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:10.2f} {max(v)/1e3:10.2f} {100*sum(v)/tot:6.2f}  {meta[k]}\n")
+    # the timed region of bench.py is the tail of the trace: per-kernel totals over the last `steps` steps
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0]))
+    rows.sort()
+    # a step starts with k_cast_verts (update_verticex); keep the last 3 steps
+    starts = [i for i, r in enumerate(rows) if r[2].startswith('k_cast_verts')]
+    if len(starts) >= 3:
+        sel = rows[starts[-3]:]
+        span = (sel[-1][1] - sel[0][0]) / 1e6
+        per = collections.defaultdict(lambda: [0, 0])
+        for a, b, k in sel:
+            per[k][0] += 1; per[k][1] += b - a
+        busy = sum(v[1] for v in per.values()) / 1e6
+        o.write(f"\n== last 3 steps: wall span {span:.3f} ms, sum of kernel time {busy:.3f} ms ({span/3:.3f} ms/step)\n")
+        for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            o.write(f"{k[:60]:60s} {c:6d} {t/1e6:10.3f} ms  {t/c/1e3:10.2f} us/call  {100*t/1e6/span:6.2f}% of span\n")
 PY
 run_pmc () {  # name counters...
   local name=$1; shift
@@ -43,4 +61,4 @@ run_pmc pmc_tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 run_pmc pmc_fetch FETCH_SIZE
 run_pmc pmc_write WRITE_SIZE
 run_pmc pmc_grbm GRBM_GUI_ACTIVE
-du -sh "$O"; cat "$O/kernel_summary.txt" | head -25
+du -sh "$O"; grep -A30 "last 3 steps" "$O/kernel_summary.txt"
