@@ -60,7 +60,9 @@ struct drt_scene {
     int64_t cap_faces = 0, cap_verts = 0;
     int32_t* faces = nullptr;      // [F,3] copy
     float* verts = nullptr;        // [V,3] float32 copy (tracer precision)
-    Node* nodes = nullptr;         // [max(F-1,1)]
+    Node* nodes = nullptr;         // [max(F-1,1)] binary radix tree (build intermediate)
+    Node4* wide = nullptr;         // [max(F-1,1)] 4-wide tree read by the traversal, indexed by binary root
+    int32_t *range_lo = nullptr, *range_hi = nullptr;   // sorted-slot range of each binary node
     TriRec* tris = nullptr;        // [F] Morton order
     uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
     uint32_t* hist = nullptr;      // [kRadix * tiles]
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_scatter(const uint32_t* __r
 // ---- hierarchy ---------------------------------------------------------------------------
 __global__ void k_hierarchy(const uint32_t* __restrict__ keys, int n, Node* __restrict__ nodes,
                             int32_t* __restrict__ parent_inner, int32_t* __restrict__ parent_leaf,
-                            uint32_t* __restrict__ flags) {
+                            uint32_t* __restrict__ flags, int32_t* __restrict__ range_lo, int32_t* __restrict__ range_hi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) parent_inner[0] = -1;
     if (n == 1) {   // degenerate: one triangle under a root whose second child is an empty box
@@ -245,13 +247,15 @@ __global__ void k_hierarchy(const uint32_t* __restrict__ keys, int n, Node* __re
             nd.child0 = ~0; nd.child1 = ~0; nd.pad0 = nd.pad1 = 0;
             nodes[0] = nd;
             parent_leaf[0] = 0;
+            range_lo[0] = 0; range_hi[0] = 0;
             flags[0] = 1;   // the single leaf is the "second" arrival: it stops at the root
         }
         return;
     }
     if (i >= n - 1) return;
-    int32_t l, r;
-    lbvh_children(keys, n, i, l, r);
+    int32_t l, r, lo, hi;
+    lbvh_children(keys, n, i, l, r, lo, hi);
+    range_lo[i] = lo; range_hi[i] = hi;
     nodes[i].child0 = l; nodes[i].child1 = r; nodes[i].pad0 = 0; nodes[i].pad1 = 0;
     if (l >= 0) parent_inner[l] = i * 2 + 0; else parent_leaf[~l] = i * 2 + 0;
     if (r >= 0) parent_inner[r] = i * 2 + 1; else parent_leaf[~r] = i * 2 + 1;
@@ -299,6 +303,61 @@ __global__ void k_refit(const uint32_t* __restrict__ sorted_idx, const int32_t* 
         box = box_union(box, sib);
         link = parent_inner[p];
     }
+}
+
+// Binary -> 4-wide collapse (drt_lbvh.h): one thread per binary node; nodes at even depth with
+// more than kLeafMax triangles (and the root) become wide nodes.  Runs after k_refit (kernel
+// boundary = all boxes visible).
+__global__ void k_collapse4(const Node* __restrict__ nodes, const int32_t* __restrict__ parent_inner,
+                            const int32_t* __restrict__ range_lo, const int32_t* __restrict__ range_hi, int n,
+                            Node4* __restrict__ wide) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int inner = n > 1 ? n - 1 : 1;
+    if (i >= inner) return;
+    if (i != 0) {
+        if (range_hi[i] - range_lo[i] + 1 <= kLeafMax) return;
+        int depth = 0;
+        for (int32_t link = parent_inner[i]; link >= 0; link = parent_inner[link >> 1]) ++depth;
+        if (depth & 1) return;
+    }
+    Node4 out;
+    collapse4(nodes, range_lo, range_hi, n, i, out);
+    wide[i] = out;
+}
+
+// Diagnostic for the wide tree: every leaf marks its triangle slots and checks its box.
+__global__ void k_wide_check(const Node4* __restrict__ wide, const int32_t* __restrict__ parent_inner,
+                             const int32_t* __restrict__ range_lo, const int32_t* __restrict__ range_hi,
+                             const TriRec* __restrict__ tris, int n, const BuildParams* __restrict__ bp,
+                             uint32_t* seen, unsigned long long* violations) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int inner = n > 1 ? n - 1 : 1;
+    if (i >= inner) return;
+    if (i != 0) {
+        if (range_hi[i] - range_lo[i] + 1 <= kLeafMax) return;
+        int depth = 0;
+        for (int32_t link = parent_inner[i]; link >= 0; link = parent_inner[link >> 1]) ++depth;
+        if (depth & 1) return;
+    }
+    const Node4 nd = wide[i];
+    unsigned long long bad = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int32_t c = nd.child[k];
+        if (c == kEmptyChild || c >= 0) continue;
+        const int first = (~c) >> 2, count = ((~c) & 3) + 1;
+        for (int j = first; j < first + count; ++j) {
+            if (j < 0 || j >= n) { ++bad; continue; }
+            atomicAdd(&seen[j], 1u);
+            const TriRec t = tris[j];
+            const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, cc{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+            if (!box_contains(node4_box(nd, k), box_of_tri(a, b, cc, 0.5f * bp->pad))) ++bad;
+        }
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+__global__ void k_seen_check(const uint32_t* __restrict__ seen, int n, unsigned long long* violations) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && seen[j] != 1u) atomicAdd(violations, 1ull);
 }
 
 // Diagnostic: every ancestor's child box must enclose the padded box of leaf k.
@@ -449,25 +508,19 @@ __device__ __forceinline__ void write_dead(int64_t i, double* out_ori, double* o
     face2[i] = -1;
 }
 
-// Conservative "can this ray touch the mesh at all": the root node's two child boxes.
-__device__ __forceinline__ bool hits_top_boxes(const Node* __restrict__ nodes, f3 o, f3 d) {
+// Conservative "can this ray touch the mesh at all": the four child boxes of the wide root.
+__device__ __forceinline__ bool hits_top_boxes(const Node4* __restrict__ nodes, f3 o, f3 d) {
     const F4* np = reinterpret_cast<const F4*>(nodes);
-    const F4 a = np[0], b = np[1], c = np[2];
+    const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
+    const int32_t* ch = nodes[0].child;
     const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
     const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
-    float t0 = fmaf(a.x, inv.x, oi.x), t1 = fmaf(a.y, inv.x, oi.x);
-    float tmin0 = fminf(t0, t1), tmax0 = fmaxf(t0, t1);
-    t0 = fmaf(a.z, inv.y, oi.y); t1 = fmaf(a.w, inv.y, oi.y);
-    tmin0 = fmaxf(tmin0, fminf(t0, t1)); tmax0 = fminf(tmax0, fmaxf(t0, t1));
-    t0 = fmaf(c.x, inv.z, oi.z); t1 = fmaf(c.y, inv.z, oi.z);
-    tmin0 = fmaxf(tmin0, fminf(t0, t1)); tmax0 = fminf(tmax0, fmaxf(t0, t1));
-    t0 = fmaf(b.x, inv.x, oi.x); t1 = fmaf(b.y, inv.x, oi.x);
-    float tmin1 = fminf(t0, t1), tmax1 = fmaxf(t0, t1);
-    t0 = fmaf(b.z, inv.y, oi.y); t1 = fmaf(b.w, inv.y, oi.y);
-    tmin1 = fmaxf(tmin1, fminf(t0, t1)); tmax1 = fminf(tmax1, fmaxf(t0, t1));
-    t0 = fmaf(c.z, inv.z, oi.z); t1 = fmaf(c.w, inv.z, oi.z);
-    tmin1 = fmaxf(tmin1, fminf(t0, t1)); tmax1 = fminf(tmax1, fmaxf(t0, t1));
-    return (fmaxf(tmin0, 0.0f) <= tmax0) | (fmaxf(tmin1, 0.0f) <= tmax1);
+    bool h0, h1, h2, h3;
+    slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, inv, oi, INFINITY, h0);
+    slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, inv, oi, INFINITY, h1);
+    slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, inv, oi, INFINITY, h2);
+    slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, inv, oi, INFINITY, h3);
+    return (h0 & (ch[0] != kEmptyChild)) | (h1 & (ch[1] != kEmptyChild)) | (h2 & (ch[2] != kEmptyChild)) | (h3 & (ch[3] != kEmptyChild));
 }
 
 template <bool FUSED>
@@ -703,6 +756,9 @@ static int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
     HIP_TRY(hipMalloc(&s->faces, sizeof(int32_t) * 3 * F));
     HIP_TRY(hipMalloc(&s->verts, sizeof(float) * 3 * V));
     HIP_TRY(hipMalloc(&s->nodes, sizeof(Node) * F));
+    HIP_TRY(hipMalloc(&s->wide, sizeof(Node4) * F));
+    HIP_TRY(hipMalloc(&s->range_lo, sizeof(int32_t) * F));
+    HIP_TRY(hipMalloc(&s->range_hi, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->tris, sizeof(TriRec) * F));
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&s->keys[k], sizeof(uint32_t) * F));
@@ -733,14 +789,15 @@ static int rebuild(drt_scene* s, hipStream_t st) {
     }
     // four passes -> result is back in buffer 0
     const int inner = n > 1 ? n - 1 : 1;
-    k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags);
+    k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags, s->range_lo, s->range_hi);
     k_refit<<<(n + 255) / 256, 256, 0, st>>>(s->idx[cur], s->faces, s->verts, n, s->params, s->tris, s->nodes,
                                              s->parent_inner, s->parent_leaf, s->flags);
+    k_collapse4<<<(inner + 255) / 256, 256, 0, st>>>(s->nodes, s->parent_inner, s->range_lo, s->range_hi, n, s->wide);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
-static TraceCtx trace_ctx(const drt_scene* s) { return TraceCtx{s->nodes, s->tris, (int)s->n_faces, s->slow_stack}; }
+static TraceCtx trace_ctx(const drt_scene* s) { return TraceCtx{s->wide, s->tris, (int)s->n_faces, s->slow_stack}; }
 
 #define CHECK_SCENE(s)                                                        \
     do {                                                                      \
@@ -870,6 +927,11 @@ int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* 
         HIP_TRY(hipMemsetAsync(s->scratch, 0, 2 * sizeof(unsigned long long), st));
         const int n = (int)s->n_faces;
         k_bvh_check<<<(n + 255) / 256, 256, 0, st>>>(s->tris, n, s->params, s->nodes, s->parent_inner, s->parent_leaf, s->scratch);
+        // the refit counters are dead after a build: reuse them as per-slot reference counts
+        HIP_TRY(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * n, st));
+        const int inner = n > 1 ? n - 1 : 1;
+        k_wide_check<<<(inner + 255) / 256, 256, 0, st>>>(s->wide, s->parent_inner, s->range_lo, s->range_hi, s->tris, n, s->params, s->flags, s->scratch);
+        k_seen_check<<<(n + 255) / 256, 256, 0, st>>>(s->flags, n, s->scratch);
         HIP_TRY(hipMemcpyAsync(v, s->scratch, sizeof(v), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }

@@ -104,7 +104,7 @@ DRT_HD int lbvh_delta(const uint32_t* keys, int n, int i, int j) {
 // Karras 2012 ("Maximizing parallelism in the construction of BVHs, octrees and k-d
 // trees"): children of inner node i over n sorted keys.  Returns child encodings
 // (>= 0 inner, < 0 leaf ~slot).
-DRT_HD void lbvh_children(const uint32_t* keys, int n, int i, int32_t& left, int32_t& right) {
+DRT_HD void lbvh_children(const uint32_t* keys, int n, int i, int32_t& left, int32_t& right, int32_t& range_lo, int32_t& range_hi) {
     const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
     const int dmin = lbvh_delta(keys, n, i, i - d);
     int lmax = 2;
@@ -124,6 +124,71 @@ DRT_HD void lbvh_children(const uint32_t* keys, int n, int i, int32_t& left, int
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     left = (lo == gamma) ? ~gamma : gamma;
     right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    range_lo = lo;
+    range_hi = hi;   // node i covers the sorted triangle slots [lo, hi]
+}
+
+// ---- 4-wide tree read by the traversal ------------------------------------------------------
+// The binary radix tree is collapsed by skipping every other level (a node at even depth adopts
+// its grandchildren) and by turning every subtree of <= kLeafMax triangles into one leaf; such
+// a subtree covers a CONTIGUOUS run of Morton-sorted triangle slots, so a leaf is (first, count).
+// Fewer, fatter steps: traversal on MI355X is bound by the latency of the dependent node
+// fetches, not by ALU or bytes.  One node = 128 bytes = one L2 line, SoA so that each 16-byte
+// load brings one bound of all four children.
+constexpr int kLeafMax = 4;
+
+struct alignas(16) Node4 {
+    float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];
+    int32_t child[4];   // >= 0: Node4 index; < 0: leaf, ~child = (first_slot << 2) | (count - 1); kEmptyChild: none
+    int32_t pad[4];
+};
+constexpr int32_t kEmptyChild = INT32_MIN;   // an inverted box still passes a slab test (inf - inf), so empties are flagged
+
+DRT_HD int32_t leaf_ref(int first, int count) { return ~((first << 2) | (count - 1)); }
+
+DRT_HD bool wide_leaf_of(int32_t c, const int32_t* range_lo, const int32_t* range_hi, int& first, int& count) {
+    if (c < 0) { first = ~c; count = 1; return true; }
+    const int cnt = range_hi[c] - range_lo[c] + 1;
+    if (cnt <= kLeafMax) { first = range_lo[c]; count = cnt; return true; }
+    return false;
+}
+
+DRT_HD void node4_clear(Node4& o) {
+    for (int k = 0; k < 4; ++k) {
+        o.lox[k] = o.loy[k] = o.loz[k] = INFINITY;
+        o.hix[k] = o.hiy[k] = o.hiz[k] = -INFINITY;
+        o.child[k] = kEmptyChild;
+        o.pad[k] = 0;
+    }
+}
+DRT_HD void node4_set(Node4& o, int k, Box b, int32_t child) {
+    o.lox[k] = b.lox; o.hix[k] = b.hix; o.loy[k] = b.loy; o.hiy[k] = b.hiy; o.loz[k] = b.loz; o.hiz[k] = b.hiz;
+    o.child[k] = child;
+}
+DRT_HD Box node4_box(const Node4& o, int k) { return Box{o.lox[k], o.loy[k], o.loz[k], o.hix[k], o.hiy[k], o.hiz[k]}; }
+
+// Wide node rooted at binary node i (which must be at even depth with more than kLeafMax
+// triangles below it, or be the root).  Wide nodes keep the index of their binary root.
+DRT_HD void collapse4(const Node* bin, const int32_t* range_lo, const int32_t* range_hi, int n_tris, int i, Node4& out) {
+    node4_clear(out);
+    if (n_tris <= kLeafMax) {   // whole mesh in one leaf under the root
+        node4_set(out, 0, box_union(node_child_box(bin[0], 0), node_child_box(bin[0], 1)), leaf_ref(0, n_tris));
+        return;
+    }
+    int k = 0, first, count;
+    for (int s = 0; s < 2; ++s) {
+        const int32_t c = s == 0 ? bin[i].child0 : bin[i].child1;
+        if (wide_leaf_of(c, range_lo, range_hi, first, count)) {
+            node4_set(out, k++, node_child_box(bin[i], s), leaf_ref(first, count));
+            continue;
+        }
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int32_t g = s2 == 0 ? bin[c].child0 : bin[c].child1;
+            const Box gb = node_child_box(bin[c], s2);
+            if (wide_leaf_of(g, range_lo, range_hi, first, count)) node4_set(out, k++, gb, leaf_ref(first, count));
+            else node4_set(out, k++, gb, g);
+        }
+    }
 }
 
 }  // namespace drt

@@ -54,8 +54,25 @@ DRT_HD float safe_inv(float d) {
     return 1.0f / (fabsf(d) > eps ? d : copysignf(eps, d));
 }
 
+// One slab test against child k of a wide node, given its six bounds.
+DRT_HD float slab4(float lox, float hix, float loy, float hiy, float loz, float hiz, f3 inv, f3 oi, float best_t, bool& hit) {
+    float t0 = fmaf(lox, inv.x, oi.x), t1 = fmaf(hix, inv.x, oi.x);
+    float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
+    t0 = fmaf(loy, inv.y, oi.y); t1 = fmaf(hiy, inv.y, oi.y);
+    tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+    t0 = fmaf(loz, inv.z, oi.z); t1 = fmaf(hiz, inv.z, oi.z);
+    tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+    tmin = fmaxf(tmin, 0.0f);
+    hit = tmin <= fminf(tmax, best_t);
+    return tmin;
+}
+
+DRT_HD void sort2(float& ka, int32_t& va, float& kb, int32_t& vb) {
+    if (kb < ka) { const float k = ka; ka = kb; kb = k; const int32_t v = va; va = vb; vb = v; }
+}
+
 template <bool ANY>
-DRT_HD Hit traverse(const Node* __restrict__ nodes, const TriRec* __restrict__ tris, int n_tris,
+DRT_HD Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, int n_tris,
                     f3 o, f3 d, Stack& st, uint32_t* visits = nullptr) {
     Hit best{INFINITY, -1};
     if (n_tris <= 0) return Hit{-1.0f, -1};
@@ -67,49 +84,44 @@ DRT_HD Hit traverse(const Node* __restrict__ nodes, const TriRec* __restrict__ t
     for (;;) {
         if (cur >= 0) {
             const F4* np = reinterpret_cast<const F4*>(nodes + cur);
-            const F4 a = np[0], b = np[1], c = np[2], ch = np[3];
+            const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], chf = np[6];
             ++nvis;
-            // child 0
-            float t0 = fmaf(a.x, inv.x, oi.x), t1 = fmaf(a.y, inv.x, oi.x);
-            float tmin0 = fminf(t0, t1), tmax0 = fmaxf(t0, t1);
-            t0 = fmaf(a.z, inv.y, oi.y); t1 = fmaf(a.w, inv.y, oi.y);
-            tmin0 = fmaxf(tmin0, fminf(t0, t1)); tmax0 = fminf(tmax0, fmaxf(t0, t1));
-            t0 = fmaf(c.x, inv.z, oi.z); t1 = fmaf(c.y, inv.z, oi.z);
-            tmin0 = fmaxf(tmin0, fminf(t0, t1)); tmax0 = fminf(tmax0, fmaxf(t0, t1));
-            tmin0 = fmaxf(tmin0, 0.0f); tmax0 = fminf(tmax0, best.t);
-            // child 1
-            t0 = fmaf(b.x, inv.x, oi.x); t1 = fmaf(b.y, inv.x, oi.x);
-            float tmin1 = fminf(t0, t1), tmax1 = fmaxf(t0, t1);
-            t0 = fmaf(b.z, inv.y, oi.y); t1 = fmaf(b.w, inv.y, oi.y);
-            tmin1 = fmaxf(tmin1, fminf(t0, t1)); tmax1 = fminf(tmax1, fmaxf(t0, t1));
-            t0 = fmaf(c.z, inv.z, oi.z); t1 = fmaf(c.w, inv.z, oi.z);
-            tmin1 = fmaxf(tmin1, fminf(t0, t1)); tmax1 = fminf(tmax1, fmaxf(t0, t1));
-            tmin1 = fmaxf(tmin1, 0.0f); tmax1 = fminf(tmax1, best.t);
-            const bool h0 = tmin0 <= tmax0, h1 = tmin1 <= tmax1;
-            int32_t c0, c1;
-            memcpy(&c0, &ch.x, 4);
-            memcpy(&c1, &ch.y, 4);
-            if (h0 & h1) {
-                const bool swap = tmin1 < tmin0;
-                st.push(swap ? c0 : c1);
-                cur = swap ? c1 : c0;
+            int32_t c0, c1, c2, c3;
+            memcpy(&c0, &chf.x, 4); memcpy(&c1, &chf.y, 4); memcpy(&c2, &chf.z, 4); memcpy(&c3, &chf.w, 4);
+            bool h0, h1, h2, h3;
+            float k0 = slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, inv, oi, best.t, h0);
+            float k1 = slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, inv, oi, best.t, h1);
+            float k2 = slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, inv, oi, best.t, h2);
+            float k3 = slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, inv, oi, best.t, h3);
+            h0 &= c0 != kEmptyChild; h1 &= c1 != kEmptyChild; h2 &= c2 != kEmptyChild; h3 &= c3 != kEmptyChild;
+            const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+            if (nh > 0) {
+                // misses sort to the end (key = +inf); 5-comparator network; visit nearest, push the rest far-first
+                k0 = h0 ? k0 : INFINITY; k1 = h1 ? k1 : INFINITY; k2 = h2 ? k2 : INFINITY; k3 = h3 ? k3 : INFINITY;
+                sort2(k0, c0, k1, c1); sort2(k2, c2, k3, c3); sort2(k0, c0, k2, c2); sort2(k1, c1, k3, c3); sort2(k1, c1, k2, c2);
+                if (nh > 3) st.push(c3);
+                if (nh > 2) st.push(c2);
+                if (nh > 1) st.push(c1);
+                cur = c0;
                 continue;
             }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
         } else {
-            const F4* tp = reinterpret_cast<const F4*>(tris + (~cur));
-            const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+            const int32_t ref = ~cur;
+            const int first = ref >> 2, count = (ref & 3) + 1;
             ++nvis;
-            float t;
-            if (tri_hit(o, d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
-                int32_t face;
-                memcpy(&face, &p0.w, 4);
-                if (ANY) {
-                    if (visits) *visits = nvis;
-                    return Hit{t, face};
+            for (int j = 0; j < count; ++j) {
+                const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
+                const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                float t;
+                if (tri_hit(o, d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
+                    int32_t face;
+                    memcpy(&face, &p0.w, 4);
+                    if (ANY) {
+                        if (visits) *visits = nvis;
+                        return Hit{t, face};
+                    }
+                    if (t < best.t || (t == best.t && face < best.face)) { best.t = t; best.face = face; }
                 }
-                if (t < best.t || (t == best.t && face < best.face)) { best.t = t; best.face = face; }
             }
         }
         if (st.empty()) break;

@@ -18,7 +18,9 @@ using namespace drt;
 struct HsScene {
     std::vector<int32_t> faces;
     std::vector<float> verts;
-    std::vector<Node> nodes;
+    std::vector<Node> nodes;       // binary radix tree (build intermediate)
+    std::vector<Node4> wide;       // what the traversal reads
+    std::vector<int32_t> range_lo, range_hi;
     std::vector<TriRec> tris;
     std::vector<int32_t> parent_inner, parent_leaf;
     std::vector<uint32_t> keys, idx;
@@ -52,6 +54,9 @@ static void build(HsScene& s) {
     s.nodes.assign(inner, Node{});
     s.parent_inner.assign(inner, -1);
     s.parent_leaf.assign(n, -1);
+    s.range_lo.assign(inner, 0);
+    s.range_hi.assign(inner, n - 1);
+    s.wide.assign(inner, Node4{});
     s.tris.resize(n);
     if (n == 0) return;
     if (n == 1) {
@@ -62,7 +67,7 @@ static void build(HsScene& s) {
     } else {
         for (int i = 0; i < n - 1; ++i) {
             int32_t l, r;
-            lbvh_children(s.keys.data(), n, i, l, r);
+            lbvh_children(s.keys.data(), n, i, l, r, s.range_lo[i], s.range_hi[i]);
             s.nodes[i].child0 = l; s.nodes[i].child1 = r;
             if (l >= 0) s.parent_inner[l] = i * 2; else s.parent_leaf[~l] = i * 2;
             if (r >= 0) s.parent_inner[r] = i * 2 + 1; else s.parent_leaf[~r] = i * 2 + 1;
@@ -88,6 +93,12 @@ static void build(HsScene& s) {
         for (int32_t link = s.parent_leaf[k]; link >= 0; link = s.parent_inner[link >> 1]) ++depth;
         s.height = std::max(s.height, depth);
     }
+    for (int i = 0; i < inner; ++i) {
+        int depth = 0;
+        for (int32_t link = s.parent_inner[i]; link >= 0; link = s.parent_inner[link >> 1]) ++depth;
+        const bool wide_root = i == 0 || ((depth & 1) == 0 && s.range_hi[i] - s.range_lo[i] + 1 > kLeafMax);
+        if (wide_root) collapse4(s.nodes.data(), s.range_lo.data(), s.range_hi.data(), n, i, s.wide[i]);
+    }
 }
 
 struct HostStack {
@@ -98,7 +109,7 @@ struct HostStack {
 };
 
 static PathCtx path_ctx(const HsScene* s, const double* verts64, double ior_int, double ior_ext) {
-    return PathCtx{TraceCtx{s->nodes.data(), s->tris.data(), (int)s->tris.size(), nullptr}, s->faces.data(), verts64, ior_int, ior_ext};
+    return PathCtx{TraceCtx{s->wide.data(), s->tris.data(), (int)s->tris.size(), nullptr}, s->faces.data(), verts64, ior_int, ior_ext};
 }
 
 extern "C" {
@@ -137,6 +148,28 @@ int64_t hs_check(void* h) {
         }
         if (n > 1 && expect != 0) ++bad;
     }
+    // wide tree: every triangle slot is referenced by exactly one leaf, inside a box that encloses it
+    std::vector<int> seen(n, 0);
+    std::vector<int32_t> todo;
+    if (n > 0) todo.push_back(0);
+    while (!todo.empty()) {
+        const Node4& nd = s->wide[todo.back()];
+        todo.pop_back();
+        for (int k = 0; k < 4; ++k) {
+            const int32_t c = nd.child[k];
+            if (c == kEmptyChild) continue;
+            if (c >= 0) { todo.push_back(c); continue; }
+            const int first = (~c) >> 2, count = ((~c) & 3) + 1;
+            for (int j = first; j < first + count; ++j) {
+                if (j < 0 || j >= n) { ++bad; continue; }
+                ++seen[j];
+                const TriRec& t = s->tris[j];
+                const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, c2{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+                if (!box_contains(node4_box(nd, k), box_of_tri(a, b, c2, 0.5f * s->pad))) ++bad;
+            }
+        }
+    }
+    for (int j = 0; j < n; ++j) if (seen[j] != 1) ++bad;
     return bad;
 }
 
@@ -146,8 +179,8 @@ void hs_intersect(void* h, const float* rays, int64_t n, float* T, int32_t* ID, 
     for (int64_t i = 0; i < n; ++i) {
         const f3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
         uint32_t v = 0;
-        const Hit r = any ? traverse<true>(s->nodes.data(), s->tris.data(), (int)s->tris.size(), o, d, hs.st, &v)
-                          : traverse<false>(s->nodes.data(), s->tris.data(), (int)s->tris.size(), o, d, hs.st, &v);
+        const Hit r = any ? traverse<true>(s->wide.data(), s->tris.data(), (int)s->tris.size(), o, d, hs.st, &v)
+                          : traverse<false>(s->wide.data(), s->tris.data(), (int)s->tris.size(), o, d, hs.st, &v);
         T[i] = r.t;
         ID[i] = r.face;
         if (visits) visits[i] = v;
