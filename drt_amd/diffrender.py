@@ -221,3 +221,114 @@ class Scene:
     def ray_loss_fused(self, origin, ray_dir, screen_pixel, valid):
         """ray_loss of this view without materialising out_ori/out_dir/mask."""
         return _RenderRayLossFused.apply(self.vertices, origin, ray_dir, screen_pixel, valid, self, intIOR, extIOR)
+
+    # ------------------------------------------------------------------ smoothness branch
+    def dihedral_angle(self):
+        """cos of the dihedral angle of every unique edge, differentiable w.r.t. vertices (DiffRender.py:440-443)."""
+        return _Dihedral.apply(self.vertices, self.E2F)
+
+    def sm_loss_fused(self):
+        """sum -log(1 + cos dihedral) (reference optim.py:82-89) with its gradient in one kernel pass."""
+        return _SmLossFused.apply(self.vertices, self.E2F)
+
+    # ------------------------------------------------------------------ silhouette branch
+    def silhouette_edge(self, origin: torch.Tensor):
+        assert origin.dim() == 1
+        v = _f64c(self.vertices.detach(), "vertices")
+        o = _f64c(origin.detach(), "origin")
+        n = self.E2F.shape[0]
+        flags = torch.empty(n, dtype=torch.uint8, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().drt_silhouette_flags(v.data_ptr(), self.E2F.data_ptr(), n, o.data_ptr(), flags.data_ptr(), _stream()))
+        return self.Edges[flags.view(torch.bool)]
+
+    def primary_visibility(self, silhouette_edge, camera_M, origin, detach_depth=False):
+        """(index int64 [M,2] (x, y), output float32 [M]) of the in-view silhouette samples (DiffRender.py:459-479)."""
+        index, output = _EdgeSample.apply(self.vertices, silhouette_edge, camera_M, origin, self, bool(detach_depth))
+        keep = (index[:, 0] < resx - 1) * (index[:, 1] < resy - 1) * (index[:, 0] >= 0) * (index[:, 1] >= 0)
+        return index[keep], output[keep]
+
+
+
+def pack_camera(camera_M):
+    """camera_M = (R 4x4, K 3x3, R^-1, K^-1) -> one float64 [50] device tensor (layout of drt_edge.h Camera)."""
+    R, K, R_inverse, K_inverse = camera_M
+    return torch.cat([R.reshape(-1), K.reshape(-1), R_inverse.reshape(-1), K_inverse.reshape(-1)]).to(torch.float64).contiguous()
+
+
+class _Dihedral(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices, E2F):
+        v = _f64c(vertices.detach(), "vertices")
+        e2f = E2F.contiguous()
+        assert e2f.dtype == torch.long and e2f.shape[1:] == (2, 3)
+        n = e2f.shape[0]
+        out = torch.empty(n, dtype=torch.float64, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().drt_dihedral_forward(v.data_ptr(), e2f.data_ptr(), n, out.data_ptr(), _stream()))
+        ctx.save_for_backward(v, e2f)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_cos):
+        v, e2f = ctx.saved_tensors
+        grad_v = torch.zeros_like(v)
+        g = _f64c(g_cos, "grad")
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().drt_dihedral_backward(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], g.data_ptr(), grad_v.data_ptr(), _stream()))
+        return grad_v, None
+
+
+class _SmLossFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices, E2F):
+        v = _f64c(vertices.detach(), "vertices")
+        e2f = E2F.contiguous()
+        loss = torch.zeros((), dtype=torch.float64, device=v.device)
+        grad_v = torch.zeros_like(v)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().drt_sm_loss_fused(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], loss.data_ptr(), grad_v.data_ptr(), _stream()))
+        ctx.save_for_backward(grad_v)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad_v,) = ctx.saved_tensors
+        return grad_v * g_loss, None
+
+
+class _EdgeSample(torch.autograd.Function):
+    """primary_visibility's projection + primary_edge_sample (reference DiffRender.py:189-267, 464-475)
+    as one function of the vertices."""
+
+    @staticmethod
+    def forward(ctx, vertices, sil_edges, camera_M, origin, scene, detach_depth):
+        v = _f64c(vertices.detach(), "vertices")
+        edges = sil_edges.contiguous()
+        assert edges.dtype == torch.long and edges.dim() == 2 and edges.shape[1] == 2
+        cam = pack_camera(camera_M)
+        o = _f64c(origin.detach(), "origin")
+        n = edges.shape[0]
+        index = torch.empty((n, 2), dtype=torch.long, device=v.device)
+        f = torch.empty(n, dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), n, cam.data_ptr(),
+                                                          o.data_ptr(), index.data_ptr(), f.data_ptr(), _stream()))
+        valid_edge = f.abs() > 1e-5
+        index = index[valid_edge]
+        output = 0.5 * torch.ones(len(index), device=v.device)       # float32, like the reference (DiffRender.py:251)
+        ctx.mark_non_differentiable(index)
+        ctx.save_for_backward(v, edges, cam, f, valid_edge)
+        ctx.detach_depth = detach_depth
+        return index, output
+
+    @staticmethod
+    def backward(ctx, grad_index, grad_output):
+        v, edges, cam, f, valid_edge = ctx.saved_tensors
+        coef = torch.zeros(edges.shape[0], dtype=torch.float64, device=v.device)
+        coef[valid_edge] = grad_output.to(torch.float64)
+        grad_v = torch.zeros_like(v)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().drt_edge_sample_backward(v.data_ptr(), edges.data_ptr(), edges.shape[0], cam.data_ptr(), f.data_ptr(),
+                                                           coef.data_ptr(), int(ctx.detach_depth), grad_v.data_ptr(), _stream()))
+        return grad_v, None, None, None, None, None

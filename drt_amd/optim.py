@@ -1,0 +1,198 @@
+"""The optimisation loop the refraction path plugs into -- host-side mirror of the
+reference's optim.py, on the HIP-backed ``drt_amd.diffrender``.
+
+    Loss_calculator.ray_loss / vh_loss / sm_loss / all_loss   reference optim.py:59-130
+    limit_hook, setup_opt, interp_L / interp_R, optimize       reference optim.py:145-219
+
+Differences from the reference, all outside the per-view math:
+  * the capture comes from any object with the reference's ``Data`` interface (``get_view``,
+    ``ray_view_generator``, ``silh_view_generator``, ``resx``, ``resy``) -- ``SyntheticData``
+    below stands in for the HDF5 captures, which are not distributed (captured_data.py:84-165);
+  * the MeshLab remesh between passes (optim.py:12-52, an external GUI tool) is a pluggable
+    ``remesh`` callable, default: keep the topology;
+  * multi-GPU: ``full_batch_step`` shards views over ranks and all-reduces the vertex gradient
+    once per step (drt_amd.dist); the reference is single-GPU and one view per step.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import diffrender as Render
+from . import dist as ddist
+from . import mesh_io, views
+
+Float = torch.float64
+
+HyperParams = {          # reference config.py:18-39
+    "name": "hand", "IOR": 1.4723, "Pass": 20, "Iters": 200,
+    "ray_w": 40, "sm_w": 0.08, "vh_w": 2e-3,
+    "momentum": 0.95, "start_lr": 0.1, "lr_decay": 0.5, "start_len": 10, "end_len": 1, "num_view": 72,
+}
+
+
+class SyntheticData:
+    """72 turntable views of a ground-truth mesh with the tuple layout of Data.get_view
+    (reference captured_data.py:44-59); everything stays resident on the GPU."""
+
+    def __init__(self, scene_gt, center, extent, resx, resy, num_view=72, device="cuda", n_total=72, view_ids=None, seed=0):
+        self.resx, self.resy, self.num_view, self.n_total = resx, resy, num_view, n_total
+        self.rng = np.random.default_rng(seed)
+
+        def render_gt(o, d):
+            with torch.no_grad():
+                return scene_gt.render_transparent(o, d)
+
+        def hit_gt(o, d):
+            return scene_gt.render_mask(o, d) > 0
+
+        ids = list(range(n_total)) if view_ids is None else list(view_ids)
+        vs = views.make_views(render_gt, hit_gt, center, extent, n_total, resx, resy, device=device, view_ids=ids)
+        self.Views = dict(zip(ids, vs))
+
+    def get_view(self, V_index):
+        return self.Views[V_index]
+
+    def ray_view_generator(self):
+        index = list(np.arange(0, self.n_total, self.n_total // self.num_view))
+        while True:
+            self.rng.shuffle(index)
+            for i in index:
+                yield int(i) % self.n_total
+
+    def silh_view_generator(self):
+        index = list(np.arange(self.n_total))
+        while True:
+            self.rng.shuffle(index)
+            for i in index:
+                yield int(i) % self.n_total
+
+
+class Loss_calculator:
+    def __init__(self, scene, data, HyperParams, fused=False):
+        self.scene = scene
+        self.data = data
+        self.HyperParams = HyperParams
+        self.fused = fused
+        self.ray_view = data.ray_view_generator()
+        self.silh_view = data.silh_view_generator()
+
+    def vh_loss(self, n_views=8):
+        scene, data = self.scene, self.data
+        vh_loss = 0
+        for _ in range(n_views):                       # reference: for v in np.arange(0, 72, 9)
+            index = next(self.silh_view)
+            screen_pixel, valid, mask, origin, ray_dir, camera_M = data.get_view(index)
+            silhouette_edge = scene.silhouette_edge(origin[0])
+            index, output = scene.primary_visibility(silhouette_edge, camera_M, origin[0], detach_depth=True)
+            vh_loss = vh_loss + (mask.view((data.resy, data.resx))[index[:, 1], index[:, 0]] - output).abs().sum()
+        return vh_loss
+
+    def sm_loss(self):
+        if self.fused:
+            return self.scene.sm_loss_fused()
+        return (-torch.log(1 + self.scene.dihedral_angle())).sum()
+
+    def ray_loss(self):
+        V_index = next(self.ray_view)
+        target, valid, mask, origin, ray_dir, camera_M = self.data.get_view(V_index)
+        if self.fused:
+            return self.scene.ray_loss_fused(origin, ray_dir, target, valid)
+        out_ori, out_dir, render_mask = self.scene.render_transparent(origin, ray_dir)
+        return Render.ray_loss(out_ori, out_dir, render_mask, target, valid)
+
+    def all_loss(self):
+        hp, data, scene = self.HyperParams, self.data, self.scene
+        zero = torch.zeros((), dtype=Float, device=scene.vertices.device)
+        ray_loss = self.ray_loss() if hp["ray_w"] != 0 else zero
+        vh_loss = self.vh_loss() if hp["vh_w"] != 0 else zero
+        sm_loss = self.sm_loss() if hp["sm_w"] != 0 else zero
+        LOSS = hp["ray_w"] * 217.5 / data.resy / data.resy * ray_loss \
+            + hp["vh_w"] * 217.5 / data.resy * vh_loss \
+            + hp["sm_w"] * scene.mean_len / 10 * sm_loss
+        return LOSS, (ray_loss, vh_loss, sm_loss)
+
+
+def loss_string(parts):
+    ray_loss, vh_loss, sm_loss = parts
+    return f"ray={float(ray_loss.detach()):g} vh={float(vh_loss.detach()):g} sm={float(sm_loss.detach()):g}"
+
+
+def interp_L(start, end, it, Pass):
+    assert it <= Pass - 1
+    return it * ((end - start) / (Pass - 1)) + start
+
+
+def interp_R(start, end, it, Pass):
+    return 1 / interp_L(1 / start, 1 / end, it, Pass)
+
+
+def limit_hook(grad, max_abs=1.0):
+    """NaN -> 0, clamp to +-1 (reference optim.py:155-162); +-inf clamps like any large value."""
+    g = torch.nan_to_num(grad, nan=0.0, posinf=None, neginf=None)
+    return g.clamp_(-max_abs, max_abs)
+
+
+def setup_opt(scene, lr, HyperParams, hook=True):
+    init_vertices = scene.vertices.detach().clone()
+    parameter = torch.zeros(init_vertices.shape, dtype=Float, requires_grad=True, device=init_vertices.device)
+    if hook:
+        parameter.register_hook(limit_hook)
+    opt = torch.optim.SGD([parameter], lr=lr, momentum=HyperParams["momentum"], nesterov=True)
+    return init_vertices, parameter, opt
+
+
+def optimize(scene, data, HyperParams, remesh=None, output=True, fused=False):
+    """The reference's pass / iteration loop (optim.py:190-215) for an existing scene and data object."""
+    Render.intIOR = HyperParams["IOR"]
+    Render.resy, Render.resx = data.resy, data.resx
+    loss_calculator = Loss_calculator(scene, data, HyperParams, fused=fused)
+    start_time = time.time()
+    history = []
+    for i_pass in range(HyperParams["Pass"]):
+        if HyperParams["Pass"] > 1:
+            remesh_len = interp_R(HyperParams["start_len"], HyperParams["end_len"], i_pass, HyperParams["Pass"])
+            lr = interp_R(HyperParams["start_lr"], HyperParams["lr_decay"] * HyperParams["start_lr"], i_pass, HyperParams["Pass"])
+        else:
+            remesh_len, lr = HyperParams["start_len"], HyperParams["start_lr"]
+        if output:
+            print(f"remesh_len {remesh_len:g} lr {lr:g}")
+        if remesh is not None:
+            remesh(scene, remesh_len)
+        init_vertices, parameter, opt = setup_opt(scene, lr, HyperParams)
+        for it in range(HyperParams["Iters"]):
+            opt.zero_grad()
+            vertices = init_vertices + parameter
+            scene.update_verticex(vertices)
+            loss, parts = loss_calculator.all_loss()
+            loss.backward()
+            if it % 100 == 0 and output:
+                print(f"Iteration {it}: {loss_string(parts)} maxgrad={parameter.grad.abs().max():g}")
+            history.append(float(loss.detach())) if (it % 100 == 0) else None
+            opt.step()
+    if output:
+        print(f"optimize time : {time.time() - start_time}")
+    return scene, history
+
+
+def full_batch_step(scene, local_views, init_vertices, parameter, opt, ray_w, fused=False):
+    """One step over ALL views of this rank (BASELINE.json's '72 views forward+backward per iter'):
+    rebuild, per-view ray loss, backward, ONE all-reduce of grad[V,3], limit_hook, SGD step."""
+    opt.zero_grad(set_to_none=True)
+    vertices = init_vertices + parameter
+    scene.update_verticex(vertices)
+    loss = torch.zeros((), dtype=Float, device=vertices.device)
+    for target, valid, origin, ray_dir in local_views:
+        if fused:
+            loss = loss + scene.ray_loss_fused(origin, ray_dir, target, valid)
+        else:
+            out_ori, out_dir, mask = scene.render_transparent(origin, ray_dir)
+            loss = loss + Render.ray_loss(out_ori, out_dir, mask, target, valid)
+    (ray_w * loss).backward()
+    g = parameter.grad
+    ddist.allreduce_sum_(g)                 # the only exchange of the step
+    parameter.grad = limit_hook(g)          # clamp after the sum over views, as on one GPU
+    opt.step()
+    return loss

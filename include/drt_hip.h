@@ -107,6 +107,40 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
                               double ior_ext, double* d_loss, double* d_grad_verts,
                               int64_t* d_n_valid, void* stream);
 
+/* ---- smoothness branch: Scene.dihedral_angle (DiffRender.py:440-443, edge_face_norm :149-163)
+ * and Loss_calculator.sm_loss (optim.py:82-89) ---------------------------------------------------
+ * d_e2f int64 [E,2,3]: the three vertex ids of the two faces of every unique edge (Scene.E2F).
+ * forward: cos of the dihedral angle per edge, float64 [E].  backward: grad_verts [V,3] += adjoint
+ * for a given d loss / d cos [E].  drt_sm_loss_fused: *d_loss += sum -log(1 + cos) and
+ * grad_verts += its gradient in one pass.  (Atomic accumulation: zero the outputs first.) */
+int drt_dihedral_forward(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, double* d_cos, void* stream);
+int drt_dihedral_backward(const double* d_verts, const int64_t* d_e2f, int64_t n_edges,
+                          const double* d_grad_cos, double* d_grad_verts, void* stream);
+int drt_sm_loss_fused(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, double* d_loss,
+                      double* d_grad_verts, void* stream);
+
+/* ---- silhouette branch ---------------------------------------------------------------------------
+ * drt_silhouette_flags <- Scene.silhouette_edge (DiffRender.py:445-457): flags uint8 [E], 1 where the
+ * two faces of the edge face opposite ways seen from d_origin3 (float64 [3], device).
+ * drt_edge_sample_forward <- Scene.primary_visibility + primary_edge_sample.forward
+ * (DiffRender.py:459-479, 189-258) for d_edges int64 [Es,2] (vertex ids): projects both endpoints with
+ * d_camera = float64 [50] = R(4x4) | K(3x3) | R^-1(4x4) | K^-1(3x3) row-major on the device, probes one
+ * pixel either side of the projected midpoint with any-hit rays; writes index int64 [Es,2] =
+ * trunc(midpoint x, y) and f float32 [Es] = hit(+) - hit(-) in {-1, 0, 1}.  The caller keeps edges with
+ * |f| > 1e-5 (DiffRender.py:244) and in-view indices (:478).
+ * drt_edge_sample_backward <- primary_edge_sample.backward (DiffRender.py:263-267) chained through the
+ * projection (depth row detached when detach_depth != 0, DiffRender.py:470-471):
+ * grad_verts [V,3] += sum_e coef[e] * f[e] * d(-N_e . E_pos)/dV, coef float64 [Es] = incoming
+ * d loss / d output per edge (0 for dropped edges). */
+int drt_silhouette_flags(const double* d_verts, const int64_t* d_e2f, int64_t n_edges,
+                         const double* d_origin3, uint8_t* d_flags, void* stream);
+int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, int64_t n_edges,
+                            const double* d_camera, const double* d_origin3, int64_t* d_index,
+                            float* d_f, void* stream);
+int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int64_t n_edges,
+                             const double* d_camera, const float* d_f, const double* d_coef,
+                             int detach_depth, double* d_grad_verts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

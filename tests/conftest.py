@@ -56,6 +56,10 @@ def hostsim():
     hs.hs_ray_loss.argtypes = [_P, _P, _P, _P, _P, _I64, _P, _P]
     hs.hs_fused.argtypes = [_P, _P, _P, _P, _P, _P, _I64, _D, _D, _P, _P, _P]
     hs.hs_bounce.argtypes = [_P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]
+    hs.hs_dihedral.argtypes = [_P, _P, _I64, ctypes.c_int, _P, _P, _P, _P]
+    hs.hs_silhouette_flags.argtypes = [_P, _P, _I64, _P, _P]
+    hs.hs_edge_sample_forward.argtypes = [_P, _P, _P, _I64, _P, _P, _P, _P]
+    hs.hs_edge_sample_backward.argtypes = [_P, _P, _I64, _P, _P, _P, ctypes.c_int, _P]
     return hs
 
 

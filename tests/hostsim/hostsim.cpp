@@ -10,6 +10,7 @@
 #include <numeric>
 #include <vector>
 
+#include "../../drt_amd/csrc/drt_edge.h"
 #include "../../drt_amd/csrc/drt_lbvh.h"
 #include "../../drt_amd/csrc/drt_path.h"
 
@@ -264,6 +265,84 @@ void hs_bounce(const double* o, const double* d, const double* tri, int64_t n, d
         store_d3(g_tri, 3 * i, ga); store_d3(g_tri, 3 * i + 1, gb); store_d3(g_tri, 3 * i + 2, gc);
         store_d3(g_o, i, go);
         store_d3(g_d, i, gd);
+    }
+}
+
+// ---- silhouette / smoothness branches (drt_edge.h) ----
+static void face64(const double* verts, const int64_t* f, d3& v0, d3& v1, d3& v2) {
+    v0 = load_d3(verts, f[0]); v1 = load_d3(verts, f[1]); v2 = load_d3(verts, f[2]);
+}
+
+// mode 0: cos only; mode 1: + adjoint for g_cos; mode 2: sm_loss fused (loss += sum -log(1+cos), grad)
+void hs_dihedral(const double* verts, const int64_t* e2f, int64_t n, int mode, double* cos_out, const double* g_cos,
+                 double* loss, double* grad_verts) {
+    for (int64_t e = 0; e < n; ++e) {
+        d3 v0, v1, v2;
+        FaceNormal a, b;
+        const int64_t* fa = e2f + 6 * e;
+        const int64_t* fb = fa + 3;
+        face64(verts, fa, v0, v1, v2); face_normal(v0, v1, v2, a);
+        face64(verts, fb, v0, v1, v2); face_normal(v0, v1, v2, b);
+        const double c = dot(a.n, b.n);
+        if (cos_out) cos_out[e] = c;
+        if (mode == 0) continue;
+        double g = mode == 1 ? g_cos[e] : -1.0 / (1.0 + c);
+        if (mode == 2) *loss += -log(1.0 + c);
+        const d3 z{0, 0, 0};
+        d3 g0 = z, g1 = z, g2 = z;
+        const HostAdd add{grad_verts};
+        face_normal_backward(a, g * b.n, g0, g1, g2);
+        add((int32_t)fa[0], g0); add((int32_t)fa[1], g1); add((int32_t)fa[2], g2);
+        g0 = z; g1 = z; g2 = z;
+        face_normal_backward(b, g * a.n, g0, g1, g2);
+        add((int32_t)fb[0], g0); add((int32_t)fb[1], g1); add((int32_t)fb[2], g2);
+    }
+}
+
+void hs_silhouette_flags(const double* verts, const int64_t* e2f, int64_t n, const double* origin3, uint8_t* flags) {
+    const d3 o{origin3[0], origin3[1], origin3[2]};
+    for (int64_t e = 0; e < n; ++e) {
+        d3 a0, b0, v1, v2;
+        FaceNormal a, b;
+        face64(verts, e2f + 6 * e, a0, v1, v2); face_normal(a0, v1, v2, a);
+        face64(verts, e2f + 6 * e + 3, b0, v1, v2); face_normal(b0, v1, v2, b);
+        flags[e] = silhouette_flag(a, a0, b, b0, o) ? 1 : 0;
+    }
+}
+
+void hs_edge_sample_forward(void* h, const double* verts, const int64_t* edges, int64_t n, const double* camera50,
+                            const double* origin3, int64_t* index, float* f_out) {
+    HsScene* s = (HsScene*)h;
+    const Camera cm = *reinterpret_cast<const Camera*>(camera50);
+    const d3 o{origin3[0], origin3[1], origin3[2]};
+    HostStack hs;
+    for (int64_t e = 0; e < n; ++e) {
+        Projected pa, pb;
+        project_endpoint(cm, load_d3(verts, edges[2 * e]), pa);
+        project_endpoint(cm, load_d3(verts, edges[2 * e + 1]), pb);
+        EdgeSample es;
+        edge_sample(cm, pa, pb, o, es);
+        const bool hu = traverse<true>(s->wide.data(), s->tris.data(), (int)s->tris.size(), to_f32(o), to_f32(es.dir_up), hs.st).face >= 0;
+        const bool hl = traverse<true>(s->wide.data(), s->tris.data(), (int)s->tris.size(), to_f32(o), to_f32(es.dir_lo), hs.st).face >= 0;
+        f_out[e] = (hu ? 1.0f : 0.0f) - (hl ? 1.0f : 0.0f);
+        index[2 * e] = (int64_t)es.midx;
+        index[2 * e + 1] = (int64_t)es.midy;
+    }
+}
+
+void hs_edge_sample_backward(const double* verts, const int64_t* edges, int64_t n, const double* camera50, const float* f,
+                             const double* coef, int detach_depth, double* grad_verts) {
+    const Camera cm = *reinterpret_cast<const Camera*>(camera50);
+    const HostAdd add{grad_verts};
+    for (int64_t e = 0; e < n; ++e) {
+        const double w = (double)f[e] * coef[e];
+        if (w == 0.0) continue;
+        Projected pa, pb;
+        project_endpoint(cm, load_d3(verts, edges[2 * e]), pa);
+        project_endpoint(cm, load_d3(verts, edges[2 * e + 1]), pb);
+        const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
+        add((int32_t)edges[2 * e], project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
+        add((int32_t)edges[2 * e + 1], project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
     }
 }
 

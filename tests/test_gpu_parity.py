@@ -246,3 +246,119 @@ def test_properties_at_full_size(Render, horse50k):
     lf.backward()
     assert lf.item() == pytest.approx(loss.item(), rel=1e-10)
     torch.testing.assert_close(V2.grad, ga, rtol=1e-8, atol=1e-10 * ga.abs().max().item())
+
+
+# ----------------------------------------------------------------------------- silhouette / smoothness branches
+@pytest.mark.parametrize("name", [f"hand_r{r}_v{v}" for r in (64, 128) for v in (5, 23, 41)])
+def test_silhouette_branch_vs_golden(Render, hand, name):
+    g = golden(name)
+    res = int(g["res"])
+    Render.resx = Render.resy = res
+    o, d, _, _ = fixture_view(g)
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+    topo = golden("hand_topology")
+    assert np.array_equal(scene.Edges.cpu().numpy(), topo["Edges"]) and np.array_equal(scene.E2F.cpu().numpy(), topo["E2F"])
+    assert scene.mean_len == pytest.approx(float(topo["mean_len"]), rel=1e-14)
+    V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    origin3 = o[0].cuda()
+    sil = scene.silhouette_edge(origin3)
+    assert np.array_equal(sil.cpu().numpy(), g["sil_edges"])
+    cam = tuple(torch.tensor(g[k], dtype=torch.float64, device="cuda") for k in ("R", "K", "Rinv", "Kinv"))
+    index, output = scene.primary_visibility(sil, cam, origin3, detach_depth=True)
+    assert np.array_equal(index.cpu().numpy(), g["vh_index"])
+    assert output.dtype == torch.float32 and np.array_equal(output.detach().cpu().numpy(), g["vh_output"])
+    hit = np.zeros(res * res, dtype=np.uint8); hit[g["b1_ind"]] = 1
+    soft = torch.tensor(views.process_mask(hit.reshape(res, res)), dtype=torch.float64, device="cuda").reshape(-1)
+    vh = (soft.view((res, res))[index[:, 1], index[:, 0]] - output).abs().sum()
+    assert vh.item() == pytest.approx(float(g["vh_loss"]), rel=1e-12)
+    g_vh, = torch.autograd.grad(vh, V)
+    ref = g["grad_vh"]
+    assert np.abs(g_vh.cpu().numpy() - ref).max() <= 1e-5
+    np.testing.assert_allclose(g_vh.cpu().numpy(), ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+    # render_mask == primary hit flags of the fixture
+    rm = scene.render_mask(o.cuda(), d.cuda())
+    assert np.array_equal(np.flatnonzero(rm.cpu().numpy() > 0), g["b1_ind"])
+
+
+def test_dihedral_and_sm_loss_vs_golden(Render, hand):
+    g = golden("hand_smooth_sm")
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+    V = torch.tensor(g["vertices"].astype(np.float64), device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    cosang = scene.dihedral_angle()
+    np.testing.assert_allclose(cosang.detach().cpu().numpy(), g["dihedral_cos"], rtol=1e-10, atol=1e-12)
+    sm = (-torch.log(1 + cosang)).sum()
+    assert sm.item() == pytest.approx(float(g["sm_loss"]), rel=1e-12)
+    g_sm, = torch.autograd.grad(sm, V)
+    ref = g["grad_sm"]
+    np.testing.assert_allclose(g_sm.cpu().numpy(), ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+    smf = scene.sm_loss_fused()
+    assert smf.item() == pytest.approx(float(g["sm_loss"]), rel=1e-12)
+    g_f, = torch.autograd.grad(2.0 * smf, V)
+    np.testing.assert_allclose(g_f.cpu().numpy(), 2.0 * ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_optimisation_steps_vs_golden(Render, hand, fused):
+    """The reference's Loss_calculator.all_loss + limit_hook + SGD(nesterov) for two iterations
+    (golden from the imported optim.py), through drt_amd.optim on the GPU."""
+    from drt_amd import optim as O
+    g = golden("hand_smooth_steps")
+    res = int(g["res"])
+    Render.intIOR = float(g["ior"])
+    Render.resx = Render.resy = res
+    center, extent = views.mesh_frame(hand.vertices)
+    cams = views.turntable_cameras(center, extent, 72, res, res)
+    Vs = g["vertices"].astype(np.float64)
+    scene = Render.Scene(mesh_io.TriMesh(Vs, hand.faces), 0)
+    assert scene.mean_len != pytest.approx(float(g["mean_len"]))   # mean_len of the reference run is the RAW hull's
+    scene.mean_len = float(g["mean_len"])
+    base = orc.Mesh(hand.faces, torch.tensor(Vs))
+
+    class Data:
+        resx = resy = res
+
+        def __init__(self):
+            self.v = {}
+            for k in list(g["ray_views"]) + list(g["sil_views"]):
+                k = int(k)
+                R, K, Rinv, Kinv = cams[k]
+                o, d = views.generate_ray(res, res, Kinv, Rinv)
+                rng = np.random.default_rng(100 + k)
+                sp = rng.standard_normal((res * res, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0])
+                valid = rng.random(res * res) > 0.1
+                _, hit = orc.intersect_ids(base, o, d)
+                soft = torch.tensor(views.process_mask(hit.numpy().reshape(res, res)), dtype=torch.float64).reshape(-1)
+                cam = tuple(torch.tensor(a, dtype=torch.float64, device="cuda") for a in (R, K, Rinv, Kinv))
+                self.v[k] = (torch.tensor(sp).cuda(), torch.tensor(valid).cuda(), soft.cuda(), o.cuda(), d.cuda(), cam)
+
+        def get_view(self, k):
+            return self.v[k]
+
+        def ray_view_generator(self):
+            while True:
+                for k in g["ray_views"]:
+                    yield int(k)
+
+        def silh_view_generator(self):
+            while True:
+                for k in g["sil_views"]:
+                    yield int(k)
+
+    hp = dict(O.HyperParams, IOR=float(g["ior"]), momentum=float(g["momentum"]))
+    lc = O.Loss_calculator(scene, Data(), hp, fused=fused)
+    init_vertices, parameter, opt = O.setup_opt(scene, float(g["lr"]), hp)
+    for it in range(2):
+        opt.zero_grad()
+        vertices = init_vertices + parameter
+        scene.update_verticex(vertices)
+        loss, parts = lc.all_loss()
+        loss.backward()
+        assert loss.item() == pytest.approx(float(g[f"loss{it}"]), rel=1e-10)
+        assert O.loss_string(parts) == str(g[f"loss_str{it}"])
+        np.testing.assert_allclose(parameter.grad.cpu().numpy(), g[f"grad{it}"], rtol=1e-7, atol=1e-10)
+        opt.step()
+        np.testing.assert_allclose(parameter.detach().cpu().numpy(), g[f"param{it}"], rtol=1e-7, atol=1e-11)
+    assert scene.mesh.vertices.shape == Vs.shape     # lazy device->host copy of the optimised vertices
+    np.testing.assert_allclose(scene.mesh.vertices, vertices.detach().cpu().numpy(), rtol=0, atol=0)

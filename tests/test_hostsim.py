@@ -192,3 +192,56 @@ def test_bounce_adjoint_vs_autograd(hostsim):
     for mine, ref in ((g_tri, gt), (g_o, go), (g_d, gd)):
         ref = ref.numpy()
         np.testing.assert_allclose(mine, ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+
+
+def _cam50(g):
+    return np.concatenate([np.asarray(g[k], dtype=np.float64).reshape(-1) for k in ("R", "K", "Rinv", "Kinv")])
+
+
+@pytest.mark.parametrize("name", ["hand_r64_v5", "hand_r128_v23", "hand_r128_v41"])
+def test_silhouette_branch_vs_golden(hostsim, hand, name):
+    g = golden(name)
+    topo = golden("hand_topology")
+    res = int(g["res"])
+    o, d, _, _ = fixture_view(g)
+    s = HostScene(hostsim, hand.faces, hand.vertices)
+    E2F = np.ascontiguousarray(topo["E2F"]); Edges = topo["Edges"]
+    origin3 = o[0].numpy().copy()
+    flags = np.zeros(len(E2F), np.uint8)
+    hostsim.hs_silhouette_flags(s.v64.ctypes.data, E2F.ctypes.data, len(E2F), origin3.ctypes.data, flags.ctypes.data)
+    sil = np.ascontiguousarray(Edges[flags.astype(bool)])
+    assert np.array_equal(sil, g["sil_edges"])
+    cam = _cam50(g)
+    index = np.zeros((len(sil), 2), np.int64); f = np.zeros(len(sil), np.float32)
+    hostsim.hs_edge_sample_forward(s.h, s.v64.ctypes.data, sil.ctypes.data, len(sil), cam.ctypes.data, origin3.ctypes.data,
+                                   index.ctypes.data, f.ctypes.data)
+    valid_edge = np.abs(f) > 1e-5
+    idx = index[valid_edge]
+    keep = (idx[:, 0] < res - 1) & (idx[:, 1] < res - 1) & (idx[:, 0] >= 0) & (idx[:, 1] >= 0)
+    assert np.array_equal(idx[keep], g["vh_index"])
+    # vh_loss = sum |soft[y, x] - 0.5| and its gradient: d/d output = -sign(soft - 0.5)
+    hit = np.zeros(res * res, dtype=np.uint8); hit[g["b1_ind"]] = 1
+    soft = views.process_mask(hit.reshape(res, res))
+    diff = soft[idx[:, 1].clip(0, res - 1), idx[:, 0].clip(0, res - 1)] - 0.5
+    assert np.abs(diff[keep]).sum() == pytest.approx(float(g["vh_loss"]), rel=1e-12)
+    coef = np.zeros(len(sil))
+    coef[np.flatnonzero(valid_edge)[keep]] = -np.sign(diff[keep])
+    gv = np.zeros_like(s.v64)
+    hostsim.hs_edge_sample_backward(s.v64.ctypes.data, sil.ctypes.data, len(sil), cam.ctypes.data, f.ctypes.data, coef.ctypes.data, 1, gv.ctypes.data)
+    ref = g["grad_vh"]
+    np.testing.assert_allclose(gv, ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+
+
+def test_dihedral_vs_golden(hostsim):
+    g = golden("hand_smooth_sm")
+    V = np.ascontiguousarray(g["vertices"].astype(np.float64)); E2F = np.ascontiguousarray(g["E2F"])
+    cosv = np.zeros(len(E2F)); loss = np.zeros(1); gv = np.zeros_like(V)
+    hostsim.hs_dihedral(V.ctypes.data, E2F.ctypes.data, len(E2F), 2, cosv.ctypes.data, None, loss.ctypes.data, gv.ctypes.data)
+    np.testing.assert_allclose(cosv, g["dihedral_cos"], rtol=1e-10, atol=1e-12)
+    assert loss[0] == pytest.approx(float(g["sm_loss"]), rel=1e-12)
+    ref = g["grad_sm"]
+    np.testing.assert_allclose(gv, ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+    # explicit-adjoint mode with the same d loss / d cos
+    gv2 = np.zeros_like(V); gc = -1.0 / (1.0 + cosv)
+    hostsim.hs_dihedral(V.ctypes.data, E2F.ctypes.data, len(E2F), 1, None, gc.ctypes.data, None, gv2.ctypes.data)
+    np.testing.assert_allclose(gv2, gv, rtol=1e-12, atol=1e-14 * np.abs(gv).max())
