@@ -53,6 +53,49 @@ def per_view_mesh_bytes(V, F):
     return 24 * V + 12 * V + 12 * F + 48 * F + 64 * (F - 1) + 24 * V
 
 
+def roofline(prof, args, P, n_local_views, V, F, elapsed, world):
+    """Per-kernel live timing (hipEvents on the launch stream, drt_profile_*) -> roofline of the kernel
+    that takes the most time, plus every stage for context.  Algorithmic bytes follow DESIGN.md section 4:
+    float64 ray I/O of the reference's tensor signature + queue indices; mesh/BVH gathers are cache-resident
+    and counted once per launch (per_view_mesh_bytes)."""
+    n = P * n_local_views * args.steps                 # rays through the pipeline in the timed region
+    it = {k: v[2] for k, v in prof.items()}
+    c, h, s2, v = it["primary"], it["bounce"], it["occlusion"], it["backward"]
+    fused = args.mode == "fused"
+    alg = {
+        "cull": (49 * n + 4 * c) if fused else (48 * n + 59 * (n - c) + 4 * c),
+        "primary": (56 * c + 4 * h) if fused else (56 * c + 55 * (c - h) + 4 * h),
+        "bounce": (56 * h + 32 * s2) if fused else (56 * h + 59 * h + 4 * s2),
+        "occlusion": 28 * s2 if fused else 52 * s2,
+        "collect": 4 * n + 4 * v,
+        "backward": (4 + 48 + 8 + 24) * v + 144 * v,
+        "loss_bwd_fused": (4 + 48 + 8 + 24) * s2 + 144 * s2,
+        "build": per_view_mesh_bytes(V, F) * args.steps,
+    }
+    stages = {}
+    for k, (ms, launches, items) in prof.items():
+        if launches == 0:
+            continue
+        mesh_b = per_view_mesh_bytes(V, F) * launches if k in ("primary", "bounce", "occlusion") else 0
+        gbs = (alg[k] + mesh_b) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        stages[k] = {"ms_per_step": round(ms / args.steps, 4), "avg_launch_ms": round(ms / launches, 4), "launches": launches,
+                     "items_per_launch": items // launches, "alg_GBps": round(gbs, 1)}
+    dom = max((k for k in stages if k != "build"), key=lambda k: stages[k]["ms_per_step"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC FETCH_SIZE/WRITE_SIZE of the same command (tools/profile.sh)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.mode, {}).get(dom)
+        except Exception:
+            traffic = None
+    step_alg = ((73 if fused else B_STEP) * P + per_view_mesh_bytes(V, F)) * args.views
+    ach = stages[dom]["alg_GBps"]
+    return {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "avg_launch_ms": stages[dom]["avg_launch_ms"], "stages": stages,
+            "whole_step_alg_GBps_per_gpu": round(step_alg / (elapsed / args.steps) / 1e9 / world, 1),
+            "note": "traversal stages are latency-bound on a cache-resident BVH; k_cull is the HBM-streaming stage"}
+
+
 def cpu_baseline(mesh, center, extent, res_sample=128):
     """The oracle (a port of the reference's CPU path: brute-force float32 tracer + float64
     PyTorch autograd) on one res_sample^2 slice of view 0 of the same workload, fwd + bwd."""
@@ -90,6 +133,9 @@ def main():
     ap.add_argument("--batch-views", type=int, default=0,
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--random-targets", action="store_true",
+                    help="skip the ground-truth render of the setup (targets = random points); used for PMC passes so that every "
+                         "traced kernel dispatch belongs to a step")
     args = ap.parse_args()
 
     rank, local_rank, world = ddist.init()
@@ -119,8 +165,13 @@ def main():
     with torch.no_grad():
         for k in my_views:
             o, d = views.generate_ray(res, res, cams[k][3], cams[k][2], device=dev)
-            oo, od, mk = gt_scene.render_transparent(o, d)
-            sp = views.screen_targets(oo, od, mk, cams[k], center, extent)
+            if args.random_targets:
+                gen = torch.Generator(device=dev).manual_seed(k)
+                sp = torch.randn(o.shape, dtype=torch.float64, device=dev, generator=gen) * 40.0 + torch.tensor(center, device=dev)
+                sp = sp * (torch.rand(P, device=dev, generator=gen) < 0.05).unsqueeze(1)
+            else:
+                oo, od, mk = gt_scene.render_transparent(o, d)
+                sp = views.screen_targets(oo, od, mk, cams[k], center, extent)
             data.append((sp.contiguous(), (sp[:, 0] != 0).contiguous(), o, d))
     del gt_scene
     valid_frac = float(np.mean([v.float().mean().item() for _, v, _, _ in data]))
@@ -139,7 +190,6 @@ def main():
 
     opt = torch.optim.SGD([parameter], lr=0.1, momentum=0.95, nesterov=True)
     w_ray = 40 * 217.5 / res / res             # reference optim.py:127 with config.py defaults
-    fwd_events = []
 
     def step(record):
         opt.zero_grad(set_to_none=True)
@@ -150,13 +200,7 @@ def main():
             if args.mode == "fused":
                 loss = loss + scene.ray_loss_fused(o, d, sp, valid)
             else:
-                if record:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
                 out_ori, out_dir, mask = scene.render_transparent(o, d)
-                if record:
-                    e1.record()
-                    fwd_events.append((e0, e1))
                 loss = loss + Render.ray_loss(out_ori, out_dir, mask, sp, valid)
         (w_ray * loss).backward()
         g = parameter.grad
@@ -167,6 +211,8 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    scene.optix_mesh.profile_enable(True)       # hipEvent pairs around every pipeline kernel, on the launch stream
+    scene.optix_mesh.profile_read()
     ddist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -188,18 +234,9 @@ def main():
                    "mode": args.mode, "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
                    "final_loss": float(loss.item())},
     }
+    prof = scene.optix_mesh.profile_read()
     if rank == 0:
-        if args.mode == "dropin" and fwd_events:
-            ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events]))
-            rays_per_launch = P * min(bv, len(my_views))
-            alg = B_FWD * rays_per_launch + per_view_mesh_bytes(n_verts, n_faces)
-            ach = alg / (ms * 1e-3) / 1e9
-            step_alg = (B_STEP * P + per_view_mesh_bytes(n_verts, n_faces)) * args.views
-            out["roofline"] = {"bound": "hbm", "kernel": "k_render_fwd", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(ms, 4),
-                               "alg_bytes_per_launch": alg,
-                               "whole_step_achieved": round(step_alg / (elapsed / args.steps) / 1e9 / world, 2),
-                               "rays_per_launch": rays_per_launch, "rays_per_s_in_kernel_G": round(rays_per_launch / (ms * 1e-3) / 1e9, 4)}
+        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mesh, center, extent)
         print(json.dumps(out), flush=True)

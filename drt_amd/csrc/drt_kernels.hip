@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/drt_hip.h"
 #include "drt_common.h"
@@ -48,6 +49,9 @@ constexpr int64_t kChunkRays = 1 << 24; // rays per pipeline pass; bounds the qu
 
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
 
+// stage ids of drt_profile_read
+enum { kStageBuild = 0, kStageCull, kStagePrimary, kStageBounce, kStageOcclusion, kStageCollect, kStageBackward, kStageLossBwdFused, kProfStages };
+
 struct BuildParams {   // written by k_bounds, read by the later build kernels
     float lox, loy, loz;
     float ix, iy, iz;   // 1 / extent per axis (0 extent -> 0)
@@ -78,6 +82,13 @@ struct drt_scene {
     int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;   // fused path keeps face ids here
     unsigned* qcount = nullptr;    // [4]
     int64_t q_cap = 0, fused_cap = 0;
+    // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;          // pool, used pairwise
+    std::vector<int> prof_stage;              // stage id of pair k
+    size_t prof_used = 0;                     // events handed out since the last read
+    unsigned long long* prof_counts = nullptr;  // device [kProfStages]: queue sizes accumulated per stage
+    hipStream_t prof_stream = nullptr;
     int n_cu = 256;
     int grid_trace = 2048;         // resident blocks of the pure-traversal kernels
     int grid_bounce = 1024;        // resident blocks of k_bounce (more registers)
@@ -884,7 +895,10 @@ static int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
     return DRT_OK;
 }
 
-static int rebuild(drt_scene* s, hipStream_t st) {
+struct StageTimer;
+static int rebuild_impl(drt_scene* s, hipStream_t st);
+
+static int rebuild_impl(drt_scene* s, hipStream_t st) {
     const int n = (int)s->n_faces;
     s->built = true;
     if (n == 0) return DRT_OK;
@@ -907,6 +921,8 @@ static int rebuild(drt_scene* s, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
+
+static int rebuild(drt_scene* s, hipStream_t st);
 
 static TraceCtx trace_ctx(const drt_scene* s) { return TraceCtx{s->wide, s->tris, (int)s->n_faces, s->slow_stack}; }
 
@@ -970,6 +986,8 @@ void drt_destroy(drt_scene_t* s) {
     (void)hipFree(s->scratch);
     (void)hipFree(s->q0); (void)hipFree(s->q1); (void)hipFree(s->q2); (void)hipFree(s->exit32);
     (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2); (void)hipFree(s->qcount);
+    for (auto& e : s->prof_ev) (void)hipEventDestroy(e);
+    (void)hipFree(s->prof_counts);
     delete s;
 }
 
@@ -1062,6 +1080,42 @@ static PathCtx path_ctx(const drt_scene* s, const double* d_verts, double ior_in
     return PathCtx{trace_ctx(s), s->faces, d_verts, ior_int, ior_ext};
 }
 
+// RAII-ish stage timer: records an event pair around a kernel launch when profiling is on.
+struct StageTimer {
+    drt_scene* s; hipStream_t st; bool on;
+    StageTimer(drt_scene* s_, hipStream_t st_, int stage) : s(s_), st(st_), on(false) {
+        if (!s->prof_on || s->prof_used + 2 > s->prof_ev.size()) return;
+        on = true;
+        s->prof_stage[s->prof_used / 2] = stage;
+        s->prof_stream = st;
+        (void)hipEventRecord(s->prof_ev[s->prof_used], st);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord(s->prof_ev[s->prof_used + 1], st);
+        s->prof_used += 2;
+    }
+};
+
+__global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    tot[kStageCull] += n_rays;
+    tot[kStagePrimary] += qcount[0];
+    tot[kStageBounce] += qcount[1];
+    tot[kStageOcclusion] += qcount[2];
+    if (fused) tot[kStageLossBwdFused] += qcount[2];
+}
+__global__ void k_prof_counts_bwd(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    tot[kStageCollect] += n_rays;
+    tot[kStageBackward] += qcount[1];
+}
+
+static int rebuild(drt_scene* s, hipStream_t st) {
+    StageTimer t(s, st, kStageBuild);
+    return rebuild_impl(s, st);
+}
+
 // Queue workspace for one chunk of `n` rays (grown, never shrunk).  Growing frees the old buffers,
 // which synchronises the device once; steady-state calls allocate nothing.
 static int ensure_queues(drt_scene* s, int64_t n, bool fused) {
@@ -1100,13 +1154,18 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
         HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        k_cull<false><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b,
-                                                                                   d_out_dir + 3 * b, d_mask + 3 * b, d_face1 + b, d_face2 + b, q);
-        k_primary<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                                                               d_mask + 3 * b, d_face1 + b, d_face2 + b, q);
-        k_bounce<false><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                                                                d_mask + 3 * b, d_face1 + b, d_face2 + b, q, nullptr);
-        k_occlusion<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, q, nullptr);
+        { StageTimer t(s, st, kStageCull);
+          k_cull<false><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b,
+                                                                                     d_out_dir + 3 * b, d_mask + 3 * b, d_face1 + b, d_face2 + b, q); }
+        { StageTimer t(s, st, kStagePrimary);
+          k_primary<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                                                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, q); }
+        { StageTimer t(s, st, kStageBounce);
+          k_bounce<false><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                                                                  d_mask + 3 * b, d_face1 + b, d_face2 + b, q, nullptr); }
+        { StageTimer t(s, st, kStageOcclusion);
+          k_occlusion<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, q, nullptr); }
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts, 0);
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1128,10 +1187,13 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
         HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, q);
-        k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_face1 + b, d_face2 + b,
-                                                   d_grad_out_ori ? d_grad_out_ori + 3 * b : nullptr,
-                                                   d_grad_out_dir ? d_grad_out_dir + 3 * b : nullptr, d_grad_verts, q);
+        { StageTimer t(s, st, kStageCollect);
+          k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, q); }
+        { StageTimer t(s, st, kStageBackward);
+          k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_face1 + b, d_face2 + b,
+                                                     d_grad_out_ori ? d_grad_out_ori + 3 * b : nullptr,
+                                                     d_grad_out_dir ? d_grad_out_dir + 3 * b : nullptr, d_grad_verts, q); }
+        if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts);
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1163,16 +1225,56 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
         HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        k_cull<true><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr,
-                                                                                  nullptr, s->tmp_face1, s->tmp_face2, q);
-        k_primary<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2, q);
-        k_bounce<true><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr,
-                                                               s->tmp_face1, s->tmp_face2, q, s->exit32);
-        k_occlusion<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, nullptr, nullptr, nullptr, s->tmp_face2, q, s->exit32);
-        k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, q,
-                                                       d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid));
+        { StageTimer t(s, st, kStageCull);
+          k_cull<true><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr,
+                                                                                    nullptr, s->tmp_face1, s->tmp_face2, q); }
+        { StageTimer t(s, st, kStagePrimary);
+          k_primary<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2, q); }
+        { StageTimer t(s, st, kStageBounce);
+          k_bounce<true><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr,
+                                                                 s->tmp_face1, s->tmp_face2, q, s->exit32); }
+        { StageTimer t(s, st, kStageOcclusion);
+          k_occlusion<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, nullptr, nullptr, nullptr, s->tmp_face2, q, s->exit32); }
+        { StageTimer t(s, st, kStageLossBwdFused);
+          k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, q,
+                                                         d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts, 1);
     }
     HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_profile_enable(drt_scene_t* s, int on) {
+    CHECK_SCENE(s);
+    if (on && s->prof_ev.empty()) {
+        s->prof_ev.resize(8192);
+        s->prof_stage.resize(4096);
+        for (auto& e : s->prof_ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipMalloc(&s->prof_counts, sizeof(unsigned long long) * kProfStages));
+        HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(unsigned long long) * kProfStages));
+    }
+    s->prof_on = on != 0;
+    return DRT_OK;
+}
+
+int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out) {
+    CHECK_SCENE(s);
+    if (!ms_out || !launches_out || !items_out) return fail(DRT_E_INVALID, "null pointer argument");
+    for (int k = 0; k < kProfStages; ++k) { ms_out[k] = 0.0; launches_out[k] = 0; items_out[k] = 0; }
+    if (s->prof_ev.empty()) return DRT_OK;
+    HIP_TRY(hipStreamSynchronize(s->prof_stream));
+    for (size_t k = 0; k + 1 < s->prof_used; k += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->prof_ev[k], s->prof_ev[k + 1]));
+        const int stg = s->prof_stage[k / 2];
+        ms_out[stg] += ms;
+        launches_out[stg] += 1;
+    }
+    unsigned long long h[kProfStages];
+    HIP_TRY(hipMemcpy(h, s->prof_counts, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < kProfStages; ++k) items_out[k] = (int64_t)h[k];
+    HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(h)));
+    s->prof_used = 0;
     return DRT_OK;
 }
 

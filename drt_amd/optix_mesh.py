@@ -137,3 +137,20 @@ class optix_mesh:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().drt_bvh_sorted_faces(self._h, out.data_ptr(), _stream()))
         return out
+
+    STAGES = ("build", "cull", "primary", "bounce", "occlusion", "collect", "backward", "loss_bwd_fused")
+
+    def profile_enable(self, on=True):
+        """Bracket every pipeline kernel with hipEvents on its launch stream (bench.py's live timing)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """{stage: (total_ms, launches, items)} since the previous read; synchronises the stream."""
+        n = len(self.STAGES)
+        ms = (ctypes.c_double * n)()
+        launches = (ctypes.c_int64 * n)()
+        items = (ctypes.c_int64 * n)()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_profile_read(self._h, ms, launches, items))
+        return {k: (ms[i], launches[i], items[i]) for i, k in enumerate(self.STAGES)}

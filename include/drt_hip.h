@@ -43,7 +43,7 @@ void drt_destroy(drt_scene_t* s);
  * drt_update_vert  <- optix_mesh::update_vert(V float32 [V,3]),               optix_extend.cpp:23-27
  * Both copy their inputs (the reference keeps tensor references alive instead) and rebuild
  * the LBVH on `stream`: scene bounds -> 30-bit Morton codes -> radix sort -> Karras
- * hierarchy -> bottom-up box refit.
+ * hierarchy -> bottom-up box refit -> collapse to a 4-wide tree with <= 4-triangle leaves.
  * drt_update_vert_f64 fuses the reference's `vertices.detach().to(float32)`
  * (DiffRender.py:379) into the rebuild. */
 int drt_update_mesh(drt_scene_t* s, const int32_t* d_faces, int64_t n_faces,
@@ -140,6 +140,17 @@ int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t
 int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int64_t n_edges,
                              const double* d_camera, const float* d_f, const double* d_coef,
                              int detach_depth, double* d_grad_verts, void* stream);
+
+/* ---- measurement (bench.py's live per-kernel timing) --------------------------------------------
+ * When enabled every kernel of the build / forward / backward / fused pipelines is bracketed by a
+ * hipEvent pair on the stream it is launched on.  drt_profile_read synchronises that stream and
+ * returns, per stage, the summed kernel time in ms, the number of launches and the number of work
+ * items (rays in the stage's input queue) since the previous read.  Arrays have DRT_PROFILE_STAGES
+ * entries: 0 build, 1 cull, 2 primary, 3 bounce, 4 occlusion, 5 collect (backward compaction),
+ * 6 backward, 7 fused loss+backward. */
+#define DRT_PROFILE_STAGES 8
+int drt_profile_enable(drt_scene_t* s, int on);
+int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out);
 
 #ifdef __cplusplus
 }
