@@ -60,23 +60,26 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world):
     and counted once per launch (per_view_mesh_bytes)."""
     n = P * n_local_views * args.steps                 # rays through the pipeline in the timed region
     it = {k: v[2] for k, v in prof.items()}
-    c, h, s2, v = it["primary"], it["bounce"], it["occlusion"], it["backward"]
+    c, h, s2 = it["trace1"], it["trace2"], it["trace3"]          # candidates, refracted primary hits, exit rays
+    v = it["loss_bwd_fused"] if args.mode == "fused" else it["backward"]
     fused = args.mode == "fused"
+    # bytes per item: list entry = 4 (index) + 24 (float32 ray) + 4 (face); float64 ray = 48; dense outputs = 51 + 8 (face ids)
     alg = {
-        "cull": (49 * n + 4 * c) if fused else (48 * n + 59 * (n - c) + 4 * c),
-        "primary": (56 * c + 4 * h) if fused else (56 * c + 55 * (c - h) + 4 * h),
-        "bounce": (56 * h + 32 * s2) if fused else (56 * h + 59 * h + 4 * s2),
-        "occlusion": 28 * s2 if fused else 52 * s2,
+        "cull": (49 * n + 28 * c) if fused else (48 * n + 59 * (n - c) + 28 * c),
+        "trace1": 28 * c, "trace2": 28 * h, "trace3": 28 * s2,
+        "shade1": (8 + 48 + 4) * c + 28 * h + (0 if fused else 59 * (c - h)),
+        "shade2": (8 + 48 + 4) * h + 28 * s2 + (4 * h if fused else 59 * h),
+        "finish": 8 * s2 + 4 * v,
         "collect": 4 * n + 4 * v,
         "backward": (4 + 48 + 8 + 24) * v + 144 * v,
-        "loss_bwd_fused": (4 + 48 + 8 + 24) * s2 + 144 * s2,
+        "loss_bwd_fused": (8 + 48 + 8 + 24) * s2 + 144 * s2,
         "build": per_view_mesh_bytes(V, F) * args.steps,
     }
     stages = {}
     for k, (ms, launches, items) in prof.items():
         if launches == 0:
             continue
-        mesh_b = per_view_mesh_bytes(V, F) * launches if k in ("primary", "bounce", "occlusion") else 0
+        mesh_b = per_view_mesh_bytes(V, F) * launches if k in ("trace1", "trace2", "trace3") else 0
         gbs = (alg[k] + mesh_b) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         stages[k] = {"ms_per_step": round(ms / args.steps, 4), "avg_launch_ms": round(ms / launches, 4), "launches": launches,
                      "items_per_launch": items // launches, "alg_GBps": round(gbs, 1)}
@@ -235,8 +238,19 @@ def main():
                    "final_loss": float(loss.item())},
     }
     prof = scene.optix_mesh.profile_read()
+    # one extra, untimed step (on every rank: it contains the all-reduce) with the traversal statistics
+    # switched on -- they cost contended atomics, so they are kept out of the timed region
+    scene.optix_mesh.profile_enable(2)
+    step(False)
+    prof2 = scene.optix_mesh.profile_read()
+    tstats = scene.optix_mesh.trace_stats()
+    scene.optix_mesh.profile_enable(0)
     if rank == 0:
         out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world)
+        for k, (ws, ls, rf, mx) in tstats.items():
+            if ws and k in out["roofline"]["stages"]:
+                out["roofline"]["stages"][k].update({"node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),
+                                                     "lane_utilisation": round(ls / (64.0 * ws), 3), "longest_wave_visits": mx})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mesh, center, extent)
         print(json.dumps(out), flush=True)

@@ -31,8 +31,8 @@ SIGNATURES = {
     "drt_intersect_bruteforce": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
     "drt_bvh_check": (_c.c_int, [_P, _P, _c.POINTER(_I64), _c.POINTER(_c.c_int32)]),
     "drt_bvh_sorted_faces": (_c.c_int, [_P, _P, _P]),
-    "drt_render_forward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P]),
-    "drt_render_backward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P]),
+    "drt_render_forward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "drt_render_backward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "drt_ray_loss": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "drt_render_ray_loss_fused": (_c.c_int, [_P, _P, _P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P]),
     "drt_dihedral_forward": (_c.c_int, [_P, _P, _I64, _P, _P]),
@@ -43,6 +43,7 @@ SIGNATURES = {
     "drt_edge_sample_backward": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _c.c_int, _P, _P]),
     "drt_profile_enable": (_c.c_int, [_P, _c.c_int]),
     "drt_profile_read": (_c.c_int, [_P, _P, _P, _P]),
+    "drt_profile_trace_stats": (_c.c_int, [_P, _P]),
 }
 
 _lib = None

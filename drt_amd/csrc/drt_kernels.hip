@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -50,7 +51,7 @@ constexpr int64_t kChunkRays = 1 << 24; // rays per pipeline pass; bounds the qu
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
 
 // stage ids of drt_profile_read
-enum { kStageBuild = 0, kStageCull, kStagePrimary, kStageBounce, kStageOcclusion, kStageCollect, kStageBackward, kStageLossBwdFused, kProfStages };
+enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kProfStages };
 
 struct BuildParams {   // written by k_bounds, read by the later build kernels
     float lox, loy, loz;
@@ -77,13 +78,15 @@ struct drt_scene {
     int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev]
     unsigned long long* scratch = nullptr;  // small counters
     // wavefront-pipeline workspace, sized for one chunk of rays, allocated on first use
-    int32_t *q0 = nullptr, *q1 = nullptr, *q2 = nullptr;
-    float* exit32 = nullptr;       // [cap,6] float32 exit rays of the fused path
-    int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;   // fused path keeps face ids here
+    int32_t* q_idx[3] = {nullptr, nullptr, nullptr};     // ray lists R0..R2: index,
+    float* q_ray[3] = {nullptr, nullptr, nullptr};       //   float32 ray [cap,6],
+    int32_t* q_face[3] = {nullptr, nullptr, nullptr};    //   traversal result
+    int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;  // fused path keeps face ids here; backward fallback list
     unsigned* qcount = nullptr;    // [4]
     int64_t q_cap = 0, fused_cap = 0;
     // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream
     bool prof_on = false;
+    bool prof_stats = false;                  // level 2: k_trace also accumulates visit statistics (adds contended atomics)
     std::vector<hipEvent_t> prof_ev;          // pool, used pairwise
     std::vector<int> prof_stage;              // stage id of pair k
     size_t prof_used = 0;                     // events handed out since the last read
@@ -91,8 +94,10 @@ struct drt_scene {
     hipStream_t prof_stream = nullptr;
     int n_cu = 256;
     int grid_trace = 2048;         // resident blocks of the pure-traversal kernels
-    int grid_bounce = 1024;        // resident blocks of k_bounce (more registers)
-    int grid_path = 2048;          // resident 256-thread blocks of k_primary / k_occlusion
+    int grid_path = 2048;          // resident 256-thread blocks of k_trace
+    int64_t trace_stats[12] = {0};  // per k_trace stage: wave-steps, lane-steps, refills, max wave-steps (last profile read)
+    int refill_min = 16;           // k_trace refills a wave once this many lanes are idle
+    int64_t chunk_rays = kChunkRays;
 
     bool built = false;
 };
@@ -461,30 +466,36 @@ __global__ void __launch_bounds__(256) k_bruteforce(const TriRec* __restrict__ t
 // ---- the two-bounce refraction path as a compacted wavefront pipeline ---------------------
 //
 // Only ~5-25 % of camera rays hit the object and the three traversals of a path have very
-// different lengths, so one thread per ray start-to-end leaves most lanes of a wave idle
-// (measured: 25 % VALU lane utilisation, 67 % of wave time waiting), and a static ray->wave
-// map leaves most waves with nothing but misses.  Instead every stage appends the indices of
-// its surviving rays to a queue and the next stage runs over the queue with full waves:
-//   k_cull      all rays : slab test against the two top-level boxes; definite miss -> write
-//                          zeros (pure streaming); candidate -> push Q0
-//   k_primary   Q0       : closest hit #1 -> face1; miss: zeros; hit: push Q1
-//   k_bounce    Q1       : shade #1, closest hit #2, shade #2 -> provisional
-//                          out_ori/out_dir/mask/face2, push Q2; dead paths: zeros
-//   k_occlusion Q2       : any-hit of the exit ray; occluded -> zeros, face2 = -1
-// Queues hold int32 ray indices of the current chunk.  A push costs ONE returning atomic per
-// 256-thread block iteration (a single counter word sustains only ~90 returning atomics per
-// microsecond on MI355X, so per-wave pushes would cap the pipeline).
+// different lengths.  One thread per ray start-to-end leaves most lanes idle (measured on the
+// first version: 25 % VALU lane utilisation with the SIMDs issue-bound), so the path is cut
+// into stages that hand COMPACT ray lists to each other:
+//   k_cull     all rays : slab test against the wide root's child boxes; definite miss -> write
+//                         zeros (pure HBM streaming); candidate -> R0 (index + float32 ray)
+//   k_trace    R0       : closest hit -> R0.face                    (persistent, lanes refilled)
+//   k_shade1   R0       : miss -> zeros; hit -> float64 bounce #1; refracted -> R1
+//   k_trace    R1       : closest hit -> R1.face
+//   k_shade2   R1       : miss/TIR -> zeros; else float64 bounces #1+#2 -> provisional outputs, R2
+//   k_trace    R2 (any) : occlusion test of the exit ray -> R2.face
+//   k_finish   R2       : occluded -> zeros; survivors -> list of valid rays (for the backward)
+// k_trace never diverges on "what kind of ray is this": it only walks the BVH, and a lane whose
+// ray ends takes the next ray of its wave's segment at once, so waves stay full.  The float64
+// shading runs in the k_shade kernels over dense lists with no traversal in them.
+// A list push costs ONE returning atomic per 256-thread block iteration (a single counter word
+// sustains only ~90 returning atomics per microsecond on MI355X).
 constexpr int kPathBlock = 256;
 constexpr int kPathWaves = kPathBlock / 64;
 
-struct Queues {
-    int32_t* q0;
-    int32_t* q1;
-    int32_t* q2;
-    unsigned* count;   // [0] = |Q0|, [1] = |Q1|, [2] = |Q2|
+struct RayList {
+    int32_t* idx;     // ray index within the chunk
+    float* ray;       // [cap,6] float32 origin, direction -- exactly what the tracer sees
+    int32_t* face;    // [cap] traversal result
+};
+struct Pipe {
+    RayList r0, r1, r2;
+    unsigned* count;  // [0..2] list sizes of the current chunk, [3] valid rays of the whole call
 };
 
-// Block-wide ordered compaction: returns the queue slot of this thread's item, or -1.
+// Block-wide ordered compaction: returns the list slot of this thread's item, or -1.
 // Must be reached by every thread of the block (contains barriers).
 __device__ __forceinline__ int block_push(bool pred, unsigned* counter, unsigned* s_tmp /* [kPathWaves + 1] */) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -520,6 +531,11 @@ __device__ __forceinline__ void write_dead(int64_t i, double* out_ori, double* o
     face2[i] = -1;
 }
 
+__device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
+    float* e = ray + 6 * (int64_t)slot;
+    e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z;
+}
+
 // Conservative "can this ray touch the mesh at all": the four child boxes of the wide root.
 __device__ __forceinline__ bool hits_top_boxes(const Node4* __restrict__ nodes, f3 o, f3 d) {
     const F4* np = reinterpret_cast<const F4*>(nodes);
@@ -536,128 +552,175 @@ __device__ __forceinline__ bool hits_top_boxes(const Node4* __restrict__ nodes, 
 }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock) k_cull(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+__global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                       const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
                                                       double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q) {
+                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
     __shared__ unsigned s_tmp[kPathWaves + 1];
     for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
         const int64_t i = base + threadIdx.x;
         bool cand = false;
+        f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f};
         if (i < n) {
             // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
-            if (!FUSED || valid[i]) cand = c.n_tris > 0 && hits_top_boxes(c.nodes, to_f32(load_d3(origin, i)), to_f32(load_d3(dir, i)));
+            if (!FUSED || valid[i]) {
+                o = to_f32(load_d3(origin, i)); d = to_f32(load_d3(dir, i));
+                cand = c.n_tris > 0 && hits_top_boxes(c.nodes, o, d);
+            }
             if (!cand) {
                 face1[i] = -1;
                 if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
             }
         }
-        const int slot = block_push(cand, &q.count[0], s_tmp);
-        if (slot >= 0) q.q0[slot] = (int32_t)i;
+        const int slot = block_push(cand, &p.count[0], s_tmp);
+        if (slot >= 0) { p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d); }
     }
 }
 
-template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock) k_primary(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                         int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q) {
+// Persistent traversal over a ray list.  Each wave owns a contiguous segment of the list; a lane
+// whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
+template <bool ANY>
+__global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
+                                                       int32_t* __restrict__ out_face, int refill_min, unsigned long long* stats) {
     __shared__ int32_t lds[kStackFast][kPathBlock];
-    __shared__ unsigned s_tmp[kPathWaves + 1];
     Stack st = make_stack256(lds, c);
-    const unsigned n0 = q.count[0];
+    const unsigned n = *n_ptr;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * kPathWaves + (threadIdx.x >> 6), n_waves = gridDim.x * kPathWaves;
+    const unsigned per = (((n + n_waves - 1) / n_waves) + 63u) & ~63u;
+    unsigned cursor = min(n, wave * per);
+    const unsigned seg_end = min(n, cursor + per);
+    int32_t slot = -1;
+    TravState s;
+    unsigned long long wave_steps = 0, lane_steps = 0, refills = 0;   // wave-uniform diagnostics (scalar registers)
+    for (;;) {
+        const unsigned long long idle = __ballot(slot < 0);
+        if (idle != 0 && cursor < seg_end && (__popcll(idle) >= refill_min || idle == ~0ull)) {
+            if (slot < 0) {
+                const unsigned k = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                if (k < seg_end) {
+                    const float* e = rays + 6 * (int64_t)k;
+                    trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+                    slot = (int32_t)k;
+                }
+            }
+            cursor += (unsigned)__popcll(idle);
+            ++refills;
+        }
+        const unsigned long long busy = __ballot(slot >= 0);
+        if (busy == 0) break;
+        ++wave_steps;
+        lane_steps += (unsigned long long)__popcll(busy);
+        if (slot >= 0 && trav_step<ANY>(c.nodes, c.tris, s, st)) {
+            out_face[slot] = s.best_face;
+            slot = -1;
+        }
+    }
+    if (stats && lane == 0 && wave_steps) {
+        atomicAdd(stats + 0, wave_steps);
+        atomicAdd(stats + 1, lane_steps);
+        atomicAdd(stats + 2, refills);
+        atomicMax(stats + 3, wave_steps);
+    }
+}
+
+// R0 -> R1: primary hit -> float64 bounce #1 -> refracted ray
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                        double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    const unsigned n0 = p.count[0];
     for (unsigned base = blockIdx.x * kPathBlock; base < n0; base += gridDim.x * kPathBlock) {
         const unsigned k = base + threadIdx.x;
+        bool ok = false;
         int64_t i = 0;
-        int32_t f1 = -1;
+        f3 o2{0.f, 0.f, 0.f}, d2{0.f, 0.f, 1.f};
         if (k < n0) {
-            i = q.q0[k];
-            f1 = traverse<false>(c.nodes, c.tris, c.n_tris, to_f32(load_d3(origin, i)), to_f32(load_d3(dir, i)), st).face;
+            i = p.r0.idx[k];
+            const int32_t f1 = p.r0.face[k];
             face1[i] = f1;
-            if (!FUSED && f1 < 0) write_dead(i, out_ori, out_dir, mask, face2);
+            if (f1 >= 0) {
+                d3 v0, v1, v2;
+                int32_t vid[3];
+                Bounce b;
+                load_tri64(c, f1, v0, v1, v2, vid);
+                bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+                ok = !b.tir;
+                o2 = to_f32(b.new_o); d2 = to_f32(b.wt);
+            }
+            if (!ok && !FUSED) write_dead(i, out_ori, out_dir, mask, face2);
         }
-        const int slot = block_push(f1 >= 0, &q.count[1], s_tmp);
-        if (slot >= 0) q.q1[slot] = (int32_t)i;
+        const int slot = block_push(ok, &p.count[1], s_tmp);
+        if (slot >= 0) { p.r1.idx[slot] = (int32_t)i; store_ray32(p.r1.ray, slot, o2, d2); }
     }
 }
 
-// FUSED: nothing dense is written; survivors carry (ray, face2) in Q2 and the float32 exit ray in `exit32`.
+// R1 -> R2: second hit -> float64 bounces #1 and #2 -> provisional exit ray
 template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock) k_bounce(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+__global__ void __launch_bounds__(kPathBlock) k_shade2(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                        const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Queues q,
-                                                        float* __restrict__ exit32) {
-    __shared__ int32_t lds[kStackFast][kPathBlock];
+                                                        const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
     __shared__ unsigned s_tmp[kPathWaves + 1];
-    Stack st = make_stack256(lds, c.tc);
-    const unsigned n1 = q.count[1];
+    const unsigned n1 = p.count[1];
     for (unsigned base = blockIdx.x * kPathBlock; base < n1; base += gridDim.x * kPathBlock) {
         const unsigned k = base + threadIdx.x;
         bool ok = false;
         int64_t i = 0;
-        int32_t f2 = -1;
-        Bounce b;
+        f3 o3{0.f, 0.f, 0.f}, d3f{0.f, 0.f, 1.f};
         if (k < n1) {
-            i = q.q1[k];
-            const d3 o = load_d3(origin, i), d = load_d3(dir, i);
-            d3 v0, v1, v2;
-            int32_t vid[3];
-            load_tri64(c, face1[i], v0, v1, v2, vid);
-            bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b);
-            ok = !b.tir;
-            const d3 o2 = b.new_o, d2 = b.wt;
-            if (ok) {
-                f2 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(o2), to_f32(d2), st).face;
-                ok = f2 >= 0;
-            }
-            if (ok) {
+            i = p.r1.idx[k];
+            const int32_t f2 = p.r1.face[k];
+            if (f2 >= 0) {
+                d3 v0, v1, v2;
+                int32_t vid[3];
+                Bounce b;
+                load_tri64(c, face1[i], v0, v1, v2, vid);
+                bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+                const d3 o2 = b.new_o, d2 = b.wt;
                 load_tri64(c, f2, v0, v1, v2, vid);
                 bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
                 ok = !b.tir;
-            }
-            if (!FUSED) {
                 if (ok) {
-                    store_d3(out_ori, i, b.new_o);
-                    store_d3(out_dir, i, b.wt);
-                    mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
+                    o3 = to_f32(b.new_o); d3f = to_f32(b.wt);
                     face2[i] = f2;
-                } else {
-                    write_dead(i, out_ori, out_dir, mask, face2);
+                    if (!FUSED) {
+                        store_d3(out_ori, i, b.new_o);
+                        store_d3(out_dir, i, b.wt);
+                        mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
+                    }
                 }
             }
+            if (!ok) { if (FUSED) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
         }
-        const int slot = block_push(ok, &q.count[2], s_tmp);
-        if (slot >= 0) {
-            q.q2[slot] = (int32_t)i;
-            if (FUSED) {
-                face2[i] = f2;
-                const f3 eo = to_f32(b.new_o), ed = to_f32(b.wt);
-                float* e = exit32 + 6 * (int64_t)slot;
-                e[0] = eo.x; e[1] = eo.y; e[2] = eo.z; e[3] = ed.x; e[4] = ed.y; e[5] = ed.z;
-            }
+        const int slot = block_push(ok, &p.count[2], s_tmp);
+        if (slot >= 0) { p.r2.idx[slot] = (int32_t)i; store_ray32(p.r2.ray, slot, o3, d3f); }
+    }
+}
+
+// R2: occluded exit rays die; survivors are appended to the caller's list of valid rays (global index).
+__global__ void __launch_bounds__(kPathBlock) k_finish(double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        int32_t* __restrict__ face2, Pipe p, int64_t chunk_base, int32_t* __restrict__ valid_idx) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    const unsigned n2 = p.count[2];
+    for (unsigned base = blockIdx.x * kPathBlock; base < n2; base += gridDim.x * kPathBlock) {
+        const unsigned k = base + threadIdx.x;
+        bool keep = false;
+        int64_t i = 0;
+        if (k < n2) {
+            i = p.r2.idx[k];
+            keep = p.r2.face[k] < 0;
+            if (!keep) write_dead(i, out_ori, out_dir, mask, face2);
+        }
+        if (valid_idx) {
+            const int slot = block_push(keep, &p.count[3], s_tmp);
+            if (slot >= 0) valid_idx[slot] = (int32_t)(chunk_base + i);
         }
     }
 }
 
-template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock) k_occlusion(TraceCtx c, double* __restrict__ out_ori, double* __restrict__ out_dir,
-                                                           uint8_t* __restrict__ mask, int32_t* __restrict__ face2, Queues q,
-                                                           const float* __restrict__ exit32) {
-    __shared__ int32_t lds[kStackFast][kPathBlock];
-    Stack st = make_stack256(lds, c);
-    const unsigned n2 = q.count[2];
-    for (unsigned k = blockIdx.x * kPathBlock + threadIdx.x; k < n2; k += gridDim.x * kPathBlock) {
-        const int64_t i = q.q2[k];
-        f3 o, d;
-        if (FUSED) {
-            const float* e = exit32 + 6 * (int64_t)k;
-            o = f3{e[0], e[1], e[2]}; d = f3{e[3], e[4], e[5]};
-        } else {
-            o = to_f32(load_d3(out_ori, i)); d = to_f32(load_d3(out_dir, i));
-        }
-        if (traverse<true>(c.nodes, c.tris, c.n_tris, o, d, st).face >= 0) {
-            if (FUSED) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2);
-        }
-    }
+__global__ void k_store_count(const unsigned* __restrict__ count, int64_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (int64_t)*count;
 }
 
 struct AtomicAdd3 {
@@ -669,24 +732,27 @@ struct AtomicAdd3 {
     }
 };
 
-// Backward, stage 1: compact the rays whose path completed (face2 >= 0) into Q1.
-__global__ void __launch_bounds__(kPathBlock) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, Queues q) {
+// Backward without a saved list: compact the rays whose path completed (face2 >= 0).
+__global__ void __launch_bounds__(kPathBlock) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, int64_t chunk_base,
+                                                               int32_t* __restrict__ list, unsigned* counter) {
     __shared__ unsigned s_tmp[kPathWaves + 1];
     for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
         const int64_t i = base + threadIdx.x;
-        const int slot = block_push(i < n && face2[i] >= 0, &q.count[1], s_tmp);
-        if (slot >= 0) q.q1[slot] = (int32_t)i;
+        const int slot = block_push(i < n && face2[i] >= 0, counter, s_tmp);
+        if (slot >= 0) list[slot] = (int32_t)(chunk_base + i);
     }
 }
 
-// Backward, stage 2 (full waves): recompute both bounces from (face1, face2), reverse, scatter.
+// Backward (full waves over the list of valid rays): recompute both bounces from (face1, face2),
+// reverse them, scatter the six vertex gradients.
 __global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                     const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
                                                     const double* __restrict__ g_out_ori, const double* __restrict__ g_out_dir,
-                                                    double* grad_verts, Queues q) {
-    const unsigned n1 = q.count[1];
-    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n1; k += gridDim.x * blockDim.x) {
-        const int64_t i = q.q1[k];
+                                                    double* grad_verts, const int32_t* __restrict__ list, const unsigned* __restrict__ n_u32,
+                                                    const int64_t* __restrict__ n_i64) {
+    const int64_t n = n_i64 ? *n_i64 : (int64_t)*n_u32;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = list[k];
         const d3 z{0.0, 0.0, 0.0};
         const d3 g_ori = g_out_ori ? load_d3(g_out_ori, i) : z;
         const d3 g_dir = g_out_dir ? load_d3(g_out_dir, i) : z;
@@ -716,15 +782,15 @@ __global__ void __launch_bounds__(256) k_ray_loss(const double* __restrict__ out
 // Fused loss, last stage (full waves over Q2): recompute the path in float64, loss term, adjoint.
 __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                         const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
-                                                        const int32_t* __restrict__ face2, Queues q, double* loss, double* grad_verts,
+                                                        const int32_t* __restrict__ face2, Pipe p, double* loss, double* grad_verts,
                                                         unsigned long long* n_valid) {
-    const unsigned n2 = q.count[2];
+    const unsigned n2 = p.count[2];
     double acc = 0.0;
     unsigned cnt = 0;
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += gridDim.x * blockDim.x) {
-        const int64_t i = q.q2[k];
+        if (p.r2.face[k] >= 0) continue;   // occluded exit ray
+        const int64_t i = p.r2.idx[k];
         const int32_t f2 = face2[i];
-        if (f2 < 0) continue;   // occluded exit ray
         const d3 o = load_d3(origin, i), d = load_d3(dir, i);
         d3 v0, v1, v2;
         int32_t vid1[3], vid2[3];
@@ -959,15 +1025,16 @@ int drt_create(int device, drt_scene_t** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_primary<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_intersect<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
         s->grid_trace = s->n_cu * per_cu;
         if (s->grid_trace > kTraceGridMax) s->grid_trace = kTraceGridMax;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bounce<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        s->grid_bounce = s->n_cu * per_cu;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_primary<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         s->grid_path = s->n_cu * per_cu;
-        if (s->grid_bounce * 2 > kTraceGridMax) s->grid_bounce = kTraceGridMax / 2;
         if (s->grid_path * 2 > kTraceGridMax) s->grid_path = kTraceGridMax / 2;
+        // tuning knobs (measurement only; defaults are the tuned values)
+        if (const char* e = getenv("DRT_TRACE_BPC")) { const int v = atoi(e); if (v >= 1 && v * s->n_cu * 2 <= kTraceGridMax) s->grid_path = v * s->n_cu; }
+        if (const char* e = getenv("DRT_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->refill_min = v; }
+        if (const char* e = getenv("DRT_CHUNK_LOG2")) { const int v = atoi(e); if (v >= 16 && v <= 30) s->chunk_rays = (int64_t)1 << v; }
     }
     if (e != hipSuccess) {
         drt_destroy(s);
@@ -984,7 +1051,7 @@ void drt_destroy(drt_scene_t* s) {
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
     (void)hipFree(s->scratch);
-    (void)hipFree(s->q0); (void)hipFree(s->q1); (void)hipFree(s->q2); (void)hipFree(s->exit32);
+    for (int k = 0; k < 3; ++k) { (void)hipFree(s->q_idx[k]); (void)hipFree(s->q_ray[k]); (void)hipFree(s->q_face[k]); }
     (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2); (void)hipFree(s->qcount);
     for (auto& e : s->prof_ev) (void)hipEventDestroy(e);
     (void)hipFree(s->prof_counts);
@@ -1100,15 +1167,15 @@ struct StageTimer {
 __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     tot[kStageCull] += n_rays;
-    tot[kStagePrimary] += qcount[0];
-    tot[kStageBounce] += qcount[1];
-    tot[kStageOcclusion] += qcount[2];
-    if (fused) tot[kStageLossBwdFused] += qcount[2];
+    tot[kStageTrace1] += qcount[0]; tot[kStageShade1] += qcount[0];
+    tot[kStageTrace2] += qcount[1]; tot[kStageShade2] += qcount[1];
+    tot[kStageTrace3] += qcount[2];
+    if (fused) tot[kStageLossBwdFused] += qcount[2]; else tot[kStageFinish] += qcount[2];
 }
 __global__ void k_prof_counts_bwd(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     tot[kStageCollect] += n_rays;
-    tot[kStageBackward] += qcount[1];
+    tot[kStageBackward] += qcount[3];
 }
 
 static int rebuild(drt_scene* s, hipStream_t st) {
@@ -1120,17 +1187,21 @@ static int rebuild(drt_scene* s, hipStream_t st) {
 // which synchronises the device once; steady-state calls allocate nothing.
 static int ensure_queues(drt_scene* s, int64_t n, bool fused) {
     if (n > s->q_cap) {
-        (void)hipFree(s->q0); (void)hipFree(s->q1); (void)hipFree(s->q2);
-        s->q0 = s->q1 = s->q2 = nullptr; s->q_cap = 0;
-        HIP_TRY(hipMalloc(&s->q0, sizeof(int32_t) * n));
-        HIP_TRY(hipMalloc(&s->q1, sizeof(int32_t) * n));
-        HIP_TRY(hipMalloc(&s->q2, sizeof(int32_t) * n));
+        for (int k = 0; k < 3; ++k) {
+            (void)hipFree(s->q_idx[k]); (void)hipFree(s->q_ray[k]); (void)hipFree(s->q_face[k]);
+            s->q_idx[k] = nullptr; s->q_ray[k] = nullptr; s->q_face[k] = nullptr;
+        }
+        s->q_cap = 0;
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(hipMalloc(&s->q_idx[k], sizeof(int32_t) * n));
+            HIP_TRY(hipMalloc(&s->q_ray[k], sizeof(float) * 6 * n));
+            HIP_TRY(hipMalloc(&s->q_face[k], sizeof(int32_t) * n));
+        }
         s->q_cap = n;
     }
     if (fused && n > s->fused_cap) {
-        (void)hipFree(s->exit32); (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2);
-        s->exit32 = nullptr; s->tmp_face1 = s->tmp_face2 = nullptr; s->fused_cap = 0;
-        HIP_TRY(hipMalloc(&s->exit32, sizeof(float) * 6 * n));
+        (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2);
+        s->tmp_face1 = s->tmp_face2 = nullptr; s->fused_cap = 0;
         HIP_TRY(hipMalloc(&s->tmp_face1, sizeof(int32_t) * n));
         HIP_TRY(hipMalloc(&s->tmp_face2, sizeof(int32_t) * n));
         s->fused_cap = n;
@@ -1138,62 +1209,93 @@ static int ensure_queues(drt_scene* s, int64_t n, bool fused) {
     return DRT_OK;
 }
 
+static Pipe pipe_of(const drt_scene* s) {
+    return Pipe{RayList{s->q_idx[0], s->q_ray[0], s->q_face[0]}, RayList{s->q_idx[1], s->q_ray[1], s->q_face[1]},
+                RayList{s->q_idx[2], s->q_ray[2], s->q_face[2]}, s->qcount};
+}
+
+// cull -> trace -> shade1 -> trace -> shade2 -> trace(any) for one chunk; the caller appends the last stage.
+extern "C++" {
+template <bool FUSED>
+static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
+                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2) {
+    const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
+    { StageTimer t(s, st, kStageCull);
+      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p); }
+    { StageTimer t(s, st, kStageTrace1);
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, s->refill_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr); }
+    { StageTimer t(s, st, kStageShade1);
+      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
+    { StageTimer t(s, st, kStageTrace2);
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, s->refill_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr); }
+    { StageTimer t(s, st, kStageShade2);
+      k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
+    { StageTimer t(s, st, kStageTrace3);
+      k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, s->refill_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
+}
+}  // extern "C++"
+
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
-                       int32_t* d_face1, int32_t* d_face2, void* stream) {
+                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, void* stream) {
     CHECK_BUILT(s);
-    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
-    if (n_rays == 0) return DRT_OK;
-    if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+    if (n_rays == 0) {
+        if (d_n_valid) HIP_TRY(hipMemsetAsync(d_n_valid, 0, sizeof(int64_t), st));
+        return DRT_OK;
+    }
+    if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
+    if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
+    const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
     int rc = ensure_queues(s, chunk, false);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Queues q{s->q0, s->q1, s->q2, s->qcount};
+    const Pipe p = pipe_of(s);
+    HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-        HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        { StageTimer t(s, st, kStageCull);
-          k_cull<false><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b,
-                                                                                     d_out_dir + 3 * b, d_mask + 3 * b, d_face1 + b, d_face2 + b, q); }
-        { StageTimer t(s, st, kStagePrimary);
-          k_primary<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                                                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, q); }
-        { StageTimer t(s, st, kStageBounce);
-          k_bounce<false><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                                                                  d_mask + 3 * b, d_face1 + b, d_face2 + b, q, nullptr); }
-        { StageTimer t(s, st, kStageOcclusion);
-          k_occlusion<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, q, nullptr); }
+        if (b) HIP_TRY(hipMemsetAsync(s->qcount, 0, 3 * sizeof(unsigned), st));
+        launch_chunk<false>(s, st, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                            d_mask + 3 * b, d_face1 + b, d_face2 + b);
+        { StageTimer t(s, st, kStageFinish);
+          k_finish<<<8 * s->n_cu, kPathBlock, 0, st>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
         if (s->prof_on) k_prof_counts<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts, 0);
     }
+    if (d_n_valid) k_store_count<<<1, 64, 0, st>>>(s->qcount + 3, d_n_valid);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
 int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                         double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                        const int32_t* d_valid_idx, const int64_t* d_n_valid,
                         const double* d_grad_out_ori, const double* d_grad_out_dir, double* d_grad_verts, void* stream) {
     CHECK_BUILT(s);
-    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     if (n_rays == 0 || (!d_grad_out_ori && !d_grad_out_dir)) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_face1 || !d_face2 || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
-    int rc = ensure_queues(s, chunk, false);
-    if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Queues q{s->q0, s->q1, s->q2, s->qcount};
-    for (int64_t b = 0; b < n_rays; b += chunk) {
-        const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-        HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        { StageTimer t(s, st, kStageCollect);
-          k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, q); }
-        { StageTimer t(s, st, kStageBackward);
-          k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_face1 + b, d_face2 + b,
-                                                     d_grad_out_ori ? d_grad_out_ori + 3 * b : nullptr,
-                                                     d_grad_out_dir ? d_grad_out_dir + 3 * b : nullptr, d_grad_verts, q); }
-        if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts);
+    if (d_valid_idx) {   // the forward's list of completed paths: no pass over the dense arrays at all
+        StageTimer t(s, st, kStageBackward);
+        k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+                                                   d_valid_idx, nullptr, d_n_valid);
+    } else {
+        const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
+        int rc = ensure_queues(s, chunk, false);
+        if (rc) return rc;
+        for (int64_t b = 0; b < n_rays; b += chunk) {
+            const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
+            HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
+            { StageTimer t(s, st, kStageCollect);
+              k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, b, s->q_idx[0], s->qcount + 3); }
+            { StageTimer t(s, st, kStageBackward);
+              k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+                                                         s->q_idx[0], s->qcount + 3, nullptr); }
+            if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts);
+        }
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1213,30 +1315,21 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
                               const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays, double ior_int,
                               double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, void* stream) {
     CHECK_BUILT(s);
-    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+    const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
     int rc = ensure_queues(s, chunk, true);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Queues q{s->q0, s->q1, s->q2, s->qcount};
+    const Pipe p = pipe_of(s);
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
         HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        { StageTimer t(s, st, kStageCull);
-          k_cull<true><<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr,
-                                                                                    nullptr, s->tmp_face1, s->tmp_face2, q); }
-        { StageTimer t(s, st, kStagePrimary);
-          k_primary<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2, q); }
-        { StageTimer t(s, st, kStageBounce);
-          k_bounce<true><<<s->grid_bounce, kPathBlock, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, nullptr, nullptr, nullptr,
-                                                                 s->tmp_face1, s->tmp_face2, q, s->exit32); }
-        { StageTimer t(s, st, kStageOcclusion);
-          k_occlusion<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, nullptr, nullptr, nullptr, s->tmp_face2, q, s->exit32); }
+        launch_chunk<true>(s, st, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2);
         { StageTimer t(s, st, kStageLossBwdFused);
-          k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, q,
+          k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, p,
                                                          d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
         if (s->prof_on) k_prof_counts<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts, 1);
     }
@@ -1250,10 +1343,11 @@ int drt_profile_enable(drt_scene_t* s, int on) {
         s->prof_ev.resize(8192);
         s->prof_stage.resize(4096);
         for (auto& e : s->prof_ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipMalloc(&s->prof_counts, sizeof(unsigned long long) * kProfStages));
-        HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(unsigned long long) * kProfStages));
+        HIP_TRY(hipMalloc(&s->prof_counts, sizeof(unsigned long long) * (kProfStages + 12)));
+        HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(unsigned long long) * (kProfStages + 12)));
     }
     s->prof_on = on != 0;
+    s->prof_stats = on >= 2;
     return DRT_OK;
 }
 
@@ -1270,11 +1364,19 @@ int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int6
         ms_out[stg] += ms;
         launches_out[stg] += 1;
     }
-    unsigned long long h[kProfStages];
+    unsigned long long h[kProfStages + 12];
     HIP_TRY(hipMemcpy(h, s->prof_counts, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < kProfStages; ++k) items_out[k] = (int64_t)h[k];
+    for (int k = 0; k < 12; ++k) s->trace_stats[k] = (int64_t)h[kProfStages + k];
     HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(h)));
     s->prof_used = 0;
+    return DRT_OK;
+}
+
+int drt_profile_trace_stats(drt_scene_t* s, int64_t* out12) {
+    CHECK_SCENE(s);
+    if (!out12) return fail(DRT_E_INVALID, "null pointer argument");
+    for (int k = 0; k < 12; ++k) out12[k] = s->trace_stats[k];
     return DRT_OK;
 }
 

@@ -37,6 +37,12 @@ struct Stack {
         if (sp < depth_fast) fast[sp * stride] = v; else slow[sp - depth_fast] = v;
         ++sp;
     }
+    // Store unconditionally, advance only when `pred`: a dead store above the top of the stack is
+    // harmless and keeps the hot loop free of divergent branches.
+    DRT_HD void push_if(int32_t v, bool pred) {
+        if (sp < depth_fast) fast[sp * stride] = v; else if (pred) slow[sp - depth_fast] = v;
+        sp += pred ? 1 : 0;
+    }
     DRT_HD int32_t pop() {
         --sp;
         return sp < depth_fast ? fast[sp * stride] : slow[sp - depth_fast];
@@ -67,69 +73,98 @@ DRT_HD float slab4(float lox, float hix, float loy, float hiy, float loz, float 
     return tmin;
 }
 
-DRT_HD void sort2(float& ka, int32_t& va, float& kb, int32_t& vb) {
-    if (kb < ka) { const float k = ka; ka = kb; kb = k; const int32_t v = va; va = vb; vb = v; }
+// Compare-exchange on 32-bit keys whose two low bits carry the child slot (select instructions only).
+DRT_HD void cswap(uint32_t& a, uint32_t& b) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+DRT_HD int32_t pick4(uint32_t key, int32_t c0, int32_t c1, int32_t c2, int32_t c3) {
+    const uint32_t k = key & 3u;
+    return k == 0u ? c0 : (k == 1u ? c1 : (k == 2u ? c2 : c3));
+}
+DRT_HD uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+// Resumable traversal: the per-ray state lives in registers (+ the lane's stack), one call to
+// trav_step visits one node (inner or leaf).  The persistent kernels interleave steps of many rays
+// and hand a finished lane a new ray without leaving the loop.
+struct TravState {
+    f3 o, d, inv, oi;
+    int32_t cur;
+    float best_t;
+    int32_t best_face;
+};
+
+DRT_HD void trav_init(TravState& s, Stack& st, f3 o, f3 d) {
+    s.o = o; s.d = d;
+    s.inv = f3{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
+    s.oi = f3{-o.x * s.inv.x, -o.y * s.inv.y, -o.z * s.inv.z};
+    s.cur = 0;
+    s.best_t = INFINITY;
+    s.best_face = -1;
+    st.sp = 0;
+}
+
+// Returns true when the ray is finished (result in best_face / best_t; for ANY the first hit found).
+template <bool ANY>
+DRT_HD bool trav_step(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, TravState& s, Stack& st) {
+    if (s.cur >= 0) {
+        const F4* np = reinterpret_cast<const F4*>(nodes + s.cur);
+        const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], chf = np[6];
+        int32_t c0, c1, c2, c3;
+        memcpy(&c0, &chf.x, 4); memcpy(&c1, &chf.y, 4); memcpy(&c2, &chf.z, 4); memcpy(&c3, &chf.w, 4);
+        bool h0, h1, h2, h3;
+        const float t0 = slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, s.inv, s.oi, s.best_t, h0);
+        const float t1 = slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, s.inv, s.oi, s.best_t, h1);
+        const float t2 = slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, s.inv, s.oi, s.best_t, h2);
+        const float t3 = slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, s.inv, s.oi, s.best_t, h3);
+        h0 &= c0 != kEmptyChild; h1 &= c1 != kEmptyChild; h2 &= c2 != kEmptyChild; h3 &= c3 != kEmptyChild;
+        // Entry distances are >= 0, so their bit patterns order like unsigned integers; the two low
+        // mantissa bits are replaced by the child slot (ordering only -- culling used the exact value);
+        // misses get the largest key.  Five compare-exchanges sort the four keys, all selects.
+        const uint32_t kMiss = 0xFFFFFFFCu;
+        uint32_t k0 = (h0 ? (f32_bits(t0) & ~3u) : kMiss) | 0u;
+        uint32_t k1 = (h1 ? (f32_bits(t1) & ~3u) : kMiss) | 1u;
+        uint32_t k2 = (h2 ? (f32_bits(t2) & ~3u) : kMiss) | 2u;
+        uint32_t k3 = (h3 ? (f32_bits(t3) & ~3u) : kMiss) | 3u;
+        cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+        if (k0 < kMiss) {
+            // visit the nearest, push the others far-first (dead stores for misses: they sort last)
+            st.push_if(pick4(k3, c0, c1, c2, c3), k3 < kMiss);
+            st.push_if(pick4(k2, c0, c1, c2, c3), k2 < kMiss);
+            st.push_if(pick4(k1, c0, c1, c2, c3), k1 < kMiss);
+            s.cur = pick4(k0, c0, c1, c2, c3);
+            return false;
+        }
+    } else {
+        const int32_t ref = ~s.cur;
+        const int first = ref >> 2, count = (ref & 3) + 1;
+        for (int j = 0; j < count; ++j) {
+            const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
+            const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+            float t;
+            if (tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
+                int32_t face;
+                memcpy(&face, &p0.w, 4);
+                if (ANY) { s.best_t = t; s.best_face = face; return true; }
+                if (t < s.best_t || (t == s.best_t && face < s.best_face)) { s.best_t = t; s.best_face = face; }
+            }
+        }
+    }
+    if (st.empty()) return true;
+    s.cur = st.pop();
+    return false;
 }
 
 template <bool ANY>
 DRT_HD Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, int n_tris,
                     f3 o, f3 d, Stack& st, uint32_t* visits = nullptr) {
-    Hit best{INFINITY, -1};
     if (n_tris <= 0) return Hit{-1.0f, -1};
-    const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
-    const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
-    st.sp = 0;
-    int32_t cur = 0;
-    uint32_t nvis = 0;
-    for (;;) {
-        if (cur >= 0) {
-            const F4* np = reinterpret_cast<const F4*>(nodes + cur);
-            const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], chf = np[6];
-            ++nvis;
-            int32_t c0, c1, c2, c3;
-            memcpy(&c0, &chf.x, 4); memcpy(&c1, &chf.y, 4); memcpy(&c2, &chf.z, 4); memcpy(&c3, &chf.w, 4);
-            bool h0, h1, h2, h3;
-            float k0 = slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, inv, oi, best.t, h0);
-            float k1 = slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, inv, oi, best.t, h1);
-            float k2 = slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, inv, oi, best.t, h2);
-            float k3 = slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, inv, oi, best.t, h3);
-            h0 &= c0 != kEmptyChild; h1 &= c1 != kEmptyChild; h2 &= c2 != kEmptyChild; h3 &= c3 != kEmptyChild;
-            const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-            if (nh > 0) {
-                // misses sort to the end (key = +inf); 5-comparator network; visit nearest, push the rest far-first
-                k0 = h0 ? k0 : INFINITY; k1 = h1 ? k1 : INFINITY; k2 = h2 ? k2 : INFINITY; k3 = h3 ? k3 : INFINITY;
-                sort2(k0, c0, k1, c1); sort2(k2, c2, k3, c3); sort2(k0, c0, k2, c2); sort2(k1, c1, k3, c3); sort2(k1, c1, k2, c2);
-                if (nh > 3) st.push(c3);
-                if (nh > 2) st.push(c2);
-                if (nh > 1) st.push(c1);
-                cur = c0;
-                continue;
-            }
-        } else {
-            const int32_t ref = ~cur;
-            const int first = ref >> 2, count = (ref & 3) + 1;
-            ++nvis;
-            for (int j = 0; j < count; ++j) {
-                const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
-                const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-                float t;
-                if (tri_hit(o, d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
-                    int32_t face;
-                    memcpy(&face, &p0.w, 4);
-                    if (ANY) {
-                        if (visits) *visits = nvis;
-                        return Hit{t, face};
-                    }
-                    if (t < best.t || (t == best.t && face < best.face)) { best.t = t; best.face = face; }
-                }
-            }
-        }
-        if (st.empty()) break;
-        cur = st.pop();
-    }
+    TravState s;
+    trav_init(s, st, o, d);
+    uint32_t nvis = 1;
+    while (!trav_step<ANY>(nodes, tris, s, st)) ++nvis;
     if (visits) *visits = nvis;
-    if (best.face < 0) best.t = -1.0f;
-    return best;
+    return Hit{s.best_face < 0 ? -1.0f : s.best_t, s.best_face};
 }
 
 }  // namespace drt

@@ -73,13 +73,17 @@ class _RenderTransparent(torch.autograd.Function):
         mask = torch.empty((n, 3), dtype=torch.uint8, device=o.device)
         face1 = torch.empty(n, dtype=torch.int32, device=o.device)
         face2 = torch.empty(n, dtype=torch.int32, device=o.device)
+        need_bwd = ctx.needs_input_grad[0]
+        valid_idx = torch.empty(n, dtype=torch.int32, device=o.device) if need_bwd else None
+        n_valid = torch.empty(1, dtype=torch.int64, device=o.device) if need_bwd else None
         with torch.cuda.device(o.device):
             _lib.check(_lib.lib().drt_render_forward(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
-                out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(), _stream()))
+                out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
+                _lib.ptr(valid_idx), _lib.ptr(n_valid), _stream()))
         ctx.scene = scene
         ctx.ior = (float(ior_int), float(ior_ext))
-        ctx.save_for_backward(v, o, d, face1, face2)
+        ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)
         mask_b = mask.view(torch.bool)
         ctx.mark_non_differentiable(mask_b)
         scene.last_face1, scene.last_face2 = face1, face2
@@ -87,14 +91,15 @@ class _RenderTransparent(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_ori, g_dir, g_mask):
-        v, o, d, face1, face2 = ctx.saved_tensors
+        v, o, d, face1, face2, valid_idx, n_valid = ctx.saved_tensors
         grad_v = torch.zeros_like(v)
         g_ori = None if g_ori is None else _f64c(g_ori, "grad_out_ori")
         g_dir = None if g_dir is None else _f64c(g_dir, "grad_out_dir")
         with torch.cuda.device(o.device):
             _lib.check(_lib.lib().drt_render_backward(
                 ctx.scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1],
-                face1.data_ptr(), face2.data_ptr(), _lib.ptr(g_ori), _lib.ptr(g_dir), grad_v.data_ptr(), _stream()))
+                face1.data_ptr(), face2.data_ptr(), _lib.ptr(valid_idx), _lib.ptr(n_valid),
+                _lib.ptr(g_ori), _lib.ptr(g_dir), grad_v.data_ptr(), _stream()))
         return grad_v, None, None, None, None, None
 
 

@@ -138,12 +138,13 @@ class optix_mesh:
             _lib.check(_lib.lib().drt_bvh_sorted_faces(self._h, out.data_ptr(), _stream()))
         return out
 
-    STAGES = ("build", "cull", "primary", "bounce", "occlusion", "collect", "backward", "loss_bwd_fused")
+    STAGES = ("build", "cull", "trace1", "shade1", "trace2", "shade2", "trace3", "finish", "collect", "backward", "loss_bwd_fused")
 
-    def profile_enable(self, on=True):
-        """Bracket every pipeline kernel with hipEvents on its launch stream (bench.py's live timing)."""
+    def profile_enable(self, on=1):
+        """1: bracket every pipeline kernel with hipEvents on its launch stream (bench.py's live timing);
+        2: also collect traversal statistics (perturbs timing); 0: off."""
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().drt_profile_enable(self._h, int(bool(on))))
+            _lib.check(_lib.lib().drt_profile_enable(self._h, int(on)))
 
     def profile_read(self):
         """{stage: (total_ms, launches, items)} since the previous read; synchronises the stream."""
@@ -154,3 +155,9 @@ class optix_mesh:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().drt_profile_read(self._h, ms, launches, items))
         return {k: (ms[i], launches[i], items[i]) for i, k in enumerate(self.STAGES)}
+
+    def trace_stats(self):
+        """Per k_trace stage: (wave_steps, lane_steps, refills, max_wave_steps) of the last profile_read interval."""
+        out = (ctypes.c_int64 * 12)()
+        _lib.check(_lib.lib().drt_profile_trace_stats(self._h, out))
+        return {f"trace{k + 1}": tuple(out[4 * k:4 * k + 4]) for k in range(3)}

@@ -77,16 +77,20 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
  * Out: out_ori, out_dir float64 [N,3] (zeros where the path is invalid), mask uint8 [N,3]
  *      (the reference's bool [N,3]), face1/face2 int32 [N]: faces hit at bounce 1 / 2,
  *      face2 >= 0 exactly for the rays with mask = 1 (saved for backward), face1 = -1 on
- *      a primary miss. */
+ *      a primary miss.  Optional (both or neither): d_valid_idx int32 [N] receives the indices of
+ *      the rays with mask = 1 (unordered), *d_n_valid (int64, device) their number -- handing
+ *      them to drt_render_backward spares it a pass over the dense arrays. */
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                        double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
-                       int32_t* d_face1, int32_t* d_face2, void* stream);
+                       int32_t* d_face1, int32_t* d_face2,
+                       int32_t* d_valid_idx, int64_t* d_n_valid, void* stream);
 /* Adjoint of drt_render_forward w.r.t. the vertices: d_grad_verts float64 [V,3] += ...
  * (atomic accumulation; zero it first).  Either incoming gradient may be NULL (= zeros). */
 int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                         const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                         const int32_t* d_face1, const int32_t* d_face2,
+                        const int32_t* d_valid_idx, const int64_t* d_n_valid,
                         const double* d_grad_out_ori, const double* d_grad_out_dir,
                         double* d_grad_verts, void* stream);
 
@@ -142,15 +146,21 @@ int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int6
                              int detach_depth, double* d_grad_verts, void* stream);
 
 /* ---- measurement (bench.py's live per-kernel timing) --------------------------------------------
- * When enabled every kernel of the build / forward / backward / fused pipelines is bracketed by a
+ * When enabled (on = 1; on = 2 additionally collects the traversal statistics below, which perturbs
+ * timing) every kernel of the build / forward / backward / fused pipelines is bracketed by a
  * hipEvent pair on the stream it is launched on.  drt_profile_read synchronises that stream and
  * returns, per stage, the summed kernel time in ms, the number of launches and the number of work
  * items (rays in the stage's input queue) since the previous read.  Arrays have DRT_PROFILE_STAGES
- * entries: 0 build, 1 cull, 2 primary, 3 bounce, 4 occlusion, 5 collect (backward compaction),
- * 6 backward, 7 fused loss+backward. */
-#define DRT_PROFILE_STAGES 8
+ * entries: 0 build, 1 cull, 2 trace1, 3 shade1, 4 trace2, 5 shade2, 6 trace3 (occlusion),
+ * 7 finish, 8 collect (backward compaction when no list was saved), 9 backward,
+ * 10 fused loss+backward. */
+#define DRT_PROFILE_STAGES 11
 int drt_profile_enable(drt_scene_t* s, int on);
 int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out);
+/* Traversal diagnostics of the last drt_profile_read interval, 4 values for each of the three
+ * k_trace stages: node visits summed over wavefronts ("wave-steps"), over lanes ("lane-steps";
+ * lane-steps / (64 * wave-steps) = SIMD lane utilisation), lane refills, longest wavefront. */
+int drt_profile_trace_stats(drt_scene_t* s, int64_t* out12);
 
 #ifdef __cplusplus
 }
