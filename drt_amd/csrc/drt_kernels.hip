@@ -736,6 +736,50 @@ struct AtomicAdd3 {
     }
 };
 
+// Vertex-gradient accumulation through an LDS hash table.  The float64 scatter is bound by the
+// chip's atomic rate (measured 22.6 G global_atomic_add_f64 per second, tools/ubench/atomic_scope.hip,
+// independent of scope or per-XCD privatisation), and neighbouring rays hit neighbouring triangles
+// that share vertices: a block first sums its contributions per vertex in LDS (ds_add_f64 after a
+// compare-and-swap probe on the key) and then issues three global atomics per DISTINCT vertex.
+constexpr int kHashBits = 11, kHashSize = 1 << kHashBits;      // 2048 slots: 8 KB keys + 48 KB sums
+constexpr int kBwdBatch = 1024;                                 // rays per table fill (6 vertex refs each)
+
+struct HashAdd3 {
+    int32_t* keys;      // LDS [kHashSize]
+    double* sums;       // LDS [kHashSize * 3]
+    double* g;          // global fallback / final target
+    __device__ __forceinline__ void operator()(int32_t v, d3 a) const {
+        unsigned h = ((unsigned)v * 2654435761u) >> (32 - kHashBits);
+#pragma unroll 1
+        for (int probe = 0; probe < 24; ++probe) {
+            int32_t k = keys[h];
+            if (k == -1) k = atomicCAS(&keys[h], -1, v);
+            if (k == -1 || k == v) {
+                __hip_atomic_fetch_add(&sums[3 * h + 0], a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sums[3 * h + 1], a.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sums[3 * h + 2], a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+            }
+            h = (h + 1) & (kHashSize - 1);
+        }
+        AtomicAdd3{g}(v, a);     // table crowded: straight to memory
+    }
+};
+
+__device__ __forceinline__ void hash_clear(int32_t* keys, double* sums) {
+    for (int i = threadIdx.x; i < kHashSize; i += blockDim.x) keys[i] = -1;
+    for (int i = threadIdx.x; i < 3 * kHashSize; i += blockDim.x) sums[i] = 0.0;
+    __syncthreads();
+}
+__device__ __forceinline__ void hash_flush(int32_t* keys, double* sums, double* g) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHashSize; i += blockDim.x) {
+        const int32_t v = keys[i];
+        if (v >= 0) AtomicAdd3{g}(v, d3{sums[3 * i], sums[3 * i + 1], sums[3 * i + 2]});
+    }
+    __syncthreads();
+}
+
 // Backward without a saved list: compact the rays whose path completed (face2 >= 0).
 __global__ void __launch_bounds__(kPathBlock) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, int64_t chunk_base,
                                                                int32_t* __restrict__ list, unsigned* counter) {
@@ -754,13 +798,21 @@ __global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __r
                                                     const double* __restrict__ g_out_ori, const double* __restrict__ g_out_dir,
                                                     double* grad_verts, const int32_t* __restrict__ list, const unsigned* __restrict__ n_u32,
                                                     const int64_t* __restrict__ n_i64) {
+    __shared__ int32_t hkeys[kHashSize];
+    __shared__ double hsums[3 * kHashSize];
     const int64_t n = n_i64 ? *n_i64 : (int64_t)*n_u32;
-    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = list[k];
-        const d3 z{0.0, 0.0, 0.0};
-        const d3 g_ori = g_out_ori ? load_d3(g_out_ori, i) : z;
-        const d3 g_dir = g_out_dir ? load_d3(g_out_dir, i) : z;
-        path_recompute_backward(c, load_d3(origin, i), load_d3(dir, i), face1[i], face2[i], g_ori, g_dir, AtomicAdd3{grad_verts});
+    const HashAdd3 add{hkeys, hsums, grad_verts};
+    for (int64_t base = blockIdx.x * (int64_t)kBwdBatch; base < n; base += (int64_t)gridDim.x * kBwdBatch) {
+        hash_clear(hkeys, hsums);
+        const int64_t end = base + kBwdBatch < n ? base + kBwdBatch : n;
+        for (int64_t k = base + threadIdx.x; k < end; k += blockDim.x) {
+            const int64_t i = list[k];
+            const d3 z{0.0, 0.0, 0.0};
+            const d3 g_ori = g_out_ori ? load_d3(g_out_ori, i) : z;
+            const d3 g_dir = g_out_dir ? load_d3(g_out_dir, i) : z;
+            path_recompute_backward(c, load_d3(origin, i), load_d3(dir, i), face1[i], face2[i], g_ori, g_dir, add);
+        }
+        hash_flush(hkeys, hsums, grad_verts);
     }
 }
 
@@ -788,32 +840,39 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
                                                         const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
                                                         const int32_t* __restrict__ face2, Pipe p, double* loss, double* grad_verts,
                                                         unsigned long long* n_valid) {
+    __shared__ int32_t hkeys[kHashSize];
+    __shared__ double hsums[3 * kHashSize];
     const unsigned n2 = p.count[2];
+    const HashAdd3 add{hkeys, hsums, grad_verts};
     double acc = 0.0;
     unsigned cnt = 0;
-    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += gridDim.x * blockDim.x) {
-        if (p.r2.face[k] >= 0) continue;   // occluded exit ray
-        const int64_t i = p.r2.idx[k];
-        const int32_t f2 = face2[i];
-        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
-        d3 v0, v1, v2;
-        int32_t vid1[3], vid2[3];
-        Bounce b1, b2;
-        load_tri64(c, face1[i], v0, v1, v2, vid1);
-        bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b1);
-        load_tri64(c, f2, v0, v1, v2, vid2);
-        bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
-        d3 g_dir;
-        acc += ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
-        ++cnt;
-        const d3 z{0.0, 0.0, 0.0};
-        d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
-        bounce_backward(b2, z, g_dir, ga, gb, gc, g_o, g_d);
-        const AtomicAdd3 add{grad_verts};
-        add(vid2[0], ga); add(vid2[1], gb); add(vid2[2], gc);
-        ga = z; gb = z; gc = z;
-        bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
-        add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
+    for (unsigned base = blockIdx.x * kBwdBatch; base < n2; base += gridDim.x * kBwdBatch) {
+        hash_clear(hkeys, hsums);
+        const unsigned end = base + kBwdBatch < n2 ? base + kBwdBatch : n2;
+        for (unsigned k = base + threadIdx.x; k < end; k += blockDim.x) {
+            if (p.r2.face[k] >= 0) continue;   // occluded exit ray
+            const int64_t i = p.r2.idx[k];
+            const int32_t f2 = face2[i];
+            const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+            d3 v0, v1, v2;
+            int32_t vid1[3], vid2[3];
+            Bounce b1, b2;
+            load_tri64(c, face1[i], v0, v1, v2, vid1);
+            bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b1);
+            load_tri64(c, f2, v0, v1, v2, vid2);
+            bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
+            d3 g_dir;
+            acc += ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
+            ++cnt;
+            const d3 z{0.0, 0.0, 0.0};
+            d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
+            bounce_backward(b2, z, g_dir, ga, gb, gc, g_o, g_d);
+            add(vid2[0], ga); add(vid2[1], gb); add(vid2[2], gc);
+            ga = z; gb = z; gc = z;
+            bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
+            add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
+        }
+        hash_flush(hkeys, hsums, grad_verts);
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
