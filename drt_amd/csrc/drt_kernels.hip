@@ -46,7 +46,7 @@ constexpr int kTraceBlock = 128;       // threads per block in traversal kernels
 constexpr int kStackFast = 19;         // LDS stack entries per lane (19.5 KB per 256-thread block -> 8 blocks = 32 waves per CU)
 constexpr int kStackSlowDev = 45;      // global overflow entries per thread (LBVH height <= 30 + log2 F <= 64)
 constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
-constexpr int64_t kChunkRays = 1 << 24; // rays per pipeline pass; bounds the queue workspace (40 B per ray)
+constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds the list workspace (96 B per ray of the largest pass)
 
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
 
@@ -97,6 +97,7 @@ struct drt_scene {
     int grid_path = 2048;          // resident 256-thread blocks of k_trace
     int64_t trace_stats[12] = {0};  // per k_trace stage: wave-steps, lane-steps, refills, max wave-steps (last profile read)
     int refill_min = 16;           // k_trace refills a wave once this many lanes are idle
+    int inner_min = 16;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
     int64_t chunk_rays = kChunkRays;
 
     bool built = false;
@@ -540,19 +541,35 @@ __device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
     e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z;
 }
 
-// Conservative "can this ray touch the mesh at all": the four child boxes of the wide root.
-__device__ __forceinline__ bool hits_top_boxes(const Node4* __restrict__ nodes, f3 o, f3 d) {
-    const F4* np = reinterpret_cast<const F4*>(nodes);
+// Conservative "can this ray touch the mesh at all": two levels of the wide tree (the root's
+// children, then the children of every inner child the ray enters).  k_cull is HBM-bound, so these
+// <= 20 slab tests are free, and every ray they reject is one the traversal stages never see.
+__device__ __forceinline__ unsigned hit_mask4(const Node4* __restrict__ node, f3 inv, f3 oi) {
+    const F4* np = reinterpret_cast<const F4*>(node);
     const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
-    const int32_t* ch = nodes[0].child;
-    const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
-    const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
+    const int32_t* ch = node->child;
     bool h0, h1, h2, h3;
     slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, inv, oi, INFINITY, h0);
     slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, inv, oi, INFINITY, h1);
     slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, inv, oi, INFINITY, h2);
     slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, inv, oi, INFINITY, h3);
-    return (h0 & (ch[0] != kEmptyChild)) | (h1 & (ch[1] != kEmptyChild)) | (h2 & (ch[2] != kEmptyChild)) | (h3 & (ch[3] != kEmptyChild));
+    return (unsigned)(h0 & (ch[0] != kEmptyChild)) | ((unsigned)(h1 & (ch[1] != kEmptyChild)) << 1) |
+           ((unsigned)(h2 & (ch[2] != kEmptyChild)) << 2) | ((unsigned)(h3 & (ch[3] != kEmptyChild)) << 3);
+}
+
+__device__ __forceinline__ bool hits_top_boxes(const Node4* __restrict__ nodes, f3 o, f3 d) {
+    const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
+    const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
+    const unsigned m = hit_mask4(nodes, inv, oi);
+    if (m == 0) return false;
+    bool any = false;
+    for (int k = 0; k < 4; ++k) {
+        if (!((m >> k) & 1u)) continue;
+        const int32_t c = nodes[0].child[k];
+        if (c < 0) { any = true; continue; }            // a leaf directly under the root
+        any |= hit_mask4(nodes + c, inv, oi) != 0;
+    }
+    return any;
 }
 
 template <bool FUSED>
@@ -585,7 +602,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double
 // whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
 template <bool ANY>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
-                                                       int32_t* __restrict__ out_face, int refill_min, unsigned long long* stats) {
+                                                       int32_t* __restrict__ out_face, int refill_min, int inner_min, unsigned long long* stats) {
     __shared__ int32_t lds[kStackFast][kPathBlock];
     Stack st = make_stack256(lds, c);
     const unsigned n = *n_ptr;
@@ -613,11 +630,30 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         }
         const unsigned long long busy = __ballot(slot >= 0);
         if (busy == 0) break;
-        ++wave_steps;
-        lane_steps += (unsigned long long)__popcll(busy);
-        if (slot >= 0 && trav_step<ANY>(c.nodes, c.tris, s, st)) {
-            out_face[slot] = s.best_face;
-            slot = -1;
+        // inner phase ("while-while"): lanes at inner nodes keep descending; lanes that reached a leaf
+        // wait, so that the (longer) triangle code runs once for many lanes instead of on every step
+        for (;;) {
+            const bool at_inner = slot >= 0 && s.cur >= 0;
+            const unsigned long long mi = __ballot(at_inner);
+            if (mi == 0) break;
+            if (__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(mi);
+            if (at_inner && trav_inner(c.nodes, s, st)) {
+                out_face[slot] = s.best_face;
+                slot = -1;
+            }
+        }
+        // leaf phase
+        const bool at_leaf = slot >= 0 && s.cur < 0;
+        const unsigned long long ml = __ballot(at_leaf);
+        if (ml != 0) {
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(ml);
+            if (at_leaf && trav_leaf<ANY>(c.tris, s, st)) {
+                out_face[slot] = s.best_face;
+                slot = -1;
+            }
         }
     }
     if (stats && lane == 0 && wave_steps) {
@@ -1096,6 +1132,7 @@ int drt_create(int device, drt_scene_t** out) {
         if (s->grid_path * 2 > kTraceGridMax) s->grid_path = kTraceGridMax / 2;
         // tuning knobs (measurement only; defaults are the tuned values)
         if (const char* e = getenv("DRT_TRACE_BPC")) { const int v = atoi(e); if (v >= 1 && v * s->n_cu * 2 <= kTraceGridMax) s->grid_path = v * s->n_cu; }
+        if (const char* e = getenv("DRT_INNER_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->inner_min = v; }
         if (const char* e = getenv("DRT_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->refill_min = v; }
         if (const char* e = getenv("DRT_CHUNK_LOG2")) { const int v = atoi(e); if (v >= 16 && v <= 30) s->chunk_rays = (int64_t)1 << v; }
     }
@@ -1286,15 +1323,15 @@ static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const 
     { StageTimer t(s, st, kStageCull);
       k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace1);
-      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, s->refill_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr); }
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr); }
     { StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace2);
-      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, s->refill_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr); }
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr); }
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);
-      k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, s->refill_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
+      k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
 }
 }  // extern "C++"
 
@@ -1310,7 +1347,8 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     }
     if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
-    const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
+    const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
+    const int64_t chunk = (((n_rays + n_pass - 1) / n_pass) + 255) & ~(int64_t)255;   // equal passes: fewer, longer launches amortise wave tails
     int rc = ensure_queues(s, chunk, false);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
@@ -1346,7 +1384,8 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
         k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
                                                    d_valid_idx, nullptr, d_n_valid);
     } else {
-        const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
+        const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
+    const int64_t chunk = (((n_rays + n_pass - 1) / n_pass) + 255) & ~(int64_t)255;   // equal passes: fewer, longer launches amortise wave tails
         int rc = ensure_queues(s, chunk, false);
         if (rc) return rc;
         for (int64_t b = 0; b < n_rays; b += chunk) {
@@ -1382,7 +1421,8 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
+    const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
+    const int64_t chunk = (((n_rays + n_pass - 1) / n_pass) + 255) & ~(int64_t)255;   // equal passes: fewer, longer launches amortise wave tails
     int rc = ensure_queues(s, chunk, true);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);

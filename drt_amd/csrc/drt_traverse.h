@@ -104,55 +104,69 @@ DRT_HD void trav_init(TravState& s, Stack& st, f3 o, f3 d) {
     st.sp = 0;
 }
 
-// Returns true when the ray is finished (result in best_face / best_t; for ANY the first hit found).
-template <bool ANY>
-DRT_HD bool trav_step(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, TravState& s, Stack& st) {
-    if (s.cur >= 0) {
-        const F4* np = reinterpret_cast<const F4*>(nodes + s.cur);
-        const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], chf = np[6];
-        int32_t c0, c1, c2, c3;
-        memcpy(&c0, &chf.x, 4); memcpy(&c1, &chf.y, 4); memcpy(&c2, &chf.z, 4); memcpy(&c3, &chf.w, 4);
-        bool h0, h1, h2, h3;
-        const float t0 = slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, s.inv, s.oi, s.best_t, h0);
-        const float t1 = slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, s.inv, s.oi, s.best_t, h1);
-        const float t2 = slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, s.inv, s.oi, s.best_t, h2);
-        const float t3 = slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, s.inv, s.oi, s.best_t, h3);
-        h0 &= c0 != kEmptyChild; h1 &= c1 != kEmptyChild; h2 &= c2 != kEmptyChild; h3 &= c3 != kEmptyChild;
-        // Entry distances are >= 0, so their bit patterns order like unsigned integers; the two low
-        // mantissa bits are replaced by the child slot (ordering only -- culling used the exact value);
-        // misses get the largest key.  Five compare-exchanges sort the four keys, all selects.
-        const uint32_t kMiss = 0xFFFFFFFCu;
-        uint32_t k0 = (h0 ? (f32_bits(t0) & ~3u) : kMiss) | 0u;
-        uint32_t k1 = (h1 ? (f32_bits(t1) & ~3u) : kMiss) | 1u;
-        uint32_t k2 = (h2 ? (f32_bits(t2) & ~3u) : kMiss) | 2u;
-        uint32_t k3 = (h3 ? (f32_bits(t3) & ~3u) : kMiss) | 3u;
-        cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-        if (k0 < kMiss) {
-            // visit the nearest, push the others far-first (dead stores for misses: they sort last)
-            st.push_if(pick4(k3, c0, c1, c2, c3), k3 < kMiss);
-            st.push_if(pick4(k2, c0, c1, c2, c3), k2 < kMiss);
-            st.push_if(pick4(k1, c0, c1, c2, c3), k1 < kMiss);
-            s.cur = pick4(k0, c0, c1, c2, c3);
-            return false;
-        }
-    } else {
-        const int32_t ref = ~s.cur;
-        const int first = ref >> 2, count = (ref & 3) + 1;
-        for (int j = 0; j < count; ++j) {
-            const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
-            const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-            float t;
-            if (tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
-                int32_t face;
-                memcpy(&face, &p0.w, 4);
-                if (ANY) { s.best_t = t; s.best_face = face; return true; }
-                if (t < s.best_t || (t == s.best_t && face < s.best_face)) { s.best_t = t; s.best_face = face; }
-            }
-        }
-    }
+// Pop the next node; returns true when the stack is empty (ray finished).
+DRT_HD bool trav_pop(TravState& s, Stack& st) {
     if (st.empty()) return true;
     s.cur = st.pop();
     return false;
+}
+
+// Visit the inner node s.cur (>= 0).  Returns true when the ray is finished.
+DRT_HD bool trav_inner(const Node4* __restrict__ nodes, TravState& s, Stack& st) {
+    const F4* np = reinterpret_cast<const F4*>(nodes + s.cur);
+    const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], chf = np[6];
+    int32_t c0, c1, c2, c3;
+    memcpy(&c0, &chf.x, 4); memcpy(&c1, &chf.y, 4); memcpy(&c2, &chf.z, 4); memcpy(&c3, &chf.w, 4);
+    bool h0, h1, h2, h3;
+    const float t0 = slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, s.inv, s.oi, s.best_t, h0);
+    const float t1 = slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, s.inv, s.oi, s.best_t, h1);
+    const float t2 = slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, s.inv, s.oi, s.best_t, h2);
+    const float t3 = slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, s.inv, s.oi, s.best_t, h3);
+    h0 &= c0 != kEmptyChild; h1 &= c1 != kEmptyChild; h2 &= c2 != kEmptyChild; h3 &= c3 != kEmptyChild;
+    // Entry distances are >= 0, so their bit patterns order like unsigned integers; the two low
+    // mantissa bits are replaced by the child slot (ordering only -- culling used the exact value);
+    // misses get the largest key.  Five compare-exchanges sort the four keys, all selects.
+    const uint32_t kMiss = 0xFFFFFFFCu;
+    uint32_t k0 = (h0 ? (f32_bits(t0) & ~3u) : kMiss) | 0u;
+    uint32_t k1 = (h1 ? (f32_bits(t1) & ~3u) : kMiss) | 1u;
+    uint32_t k2 = (h2 ? (f32_bits(t2) & ~3u) : kMiss) | 2u;
+    uint32_t k3 = (h3 ? (f32_bits(t3) & ~3u) : kMiss) | 3u;
+    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+    if (k0 < kMiss) {
+        // visit the nearest, push the others far-first (dead stores for misses: they sort last)
+        st.push_if(pick4(k3, c0, c1, c2, c3), k3 < kMiss);
+        st.push_if(pick4(k2, c0, c1, c2, c3), k2 < kMiss);
+        st.push_if(pick4(k1, c0, c1, c2, c3), k1 < kMiss);
+        s.cur = pick4(k0, c0, c1, c2, c3);
+        return false;
+    }
+    return trav_pop(s, st);
+}
+
+// Test the triangles of the leaf s.cur (< 0).  Returns true when the ray is finished.
+template <bool ANY>
+DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, Stack& st) {
+    const int32_t ref = ~s.cur;
+    const int first = ref >> 2, count = (ref & 3) + 1;
+    for (int j = 0; j < count; ++j) {
+        const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
+        const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+        float t;
+        if (tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
+            int32_t face;
+            memcpy(&face, &p0.w, 4);
+            if (ANY) { s.best_t = t; s.best_face = face; return true; }
+            if (t < s.best_t || (t == s.best_t && face < s.best_face)) { s.best_t = t; s.best_face = face; }
+        }
+    }
+    return trav_pop(s, st);
+}
+
+// One node visit, inner or leaf.  Returns true when the ray is finished (result in best_face /
+// best_t; for ANY the first hit found).
+template <bool ANY>
+DRT_HD bool trav_step(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, TravState& s, Stack& st) {
+    return s.cur >= 0 ? trav_inner(nodes, s, st) : trav_leaf<ANY>(tris, s, st);
 }
 
 template <bool ANY>
