@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--mesh", default="horse")
     ap.add_argument("--batch-views", type=int, default=0,
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-targets", action="store_true",
                     help="skip the ground-truth render of the setup (targets = random points); used for PMC passes so that every "
@@ -212,15 +214,33 @@ def main():
         opt.step()
         return loss
 
+    graph = None
+    if args.graph:
+        # The step has no host-side data dependence (every list size lives on the device), so it can be
+        # captured once and replayed: one graph launch per step instead of ~60 kernel launches.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(3, args.warmup)):
+                step(False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step(False)
+        run = lambda: (graph.replay(), static_loss)[1]
+    else:
+        run = lambda: step(True)
     for _ in range(args.warmup):
-        step(False)
-    scene.optix_mesh.profile_enable(True)       # hipEvent pairs around every pipeline kernel, on the launch stream
-    scene.optix_mesh.profile_read()
+        run()
+    if not args.graph:
+        scene.optix_mesh.profile_enable(True)   # hipEvent pairs around every pipeline kernel, on the launch stream
+        scene.optix_mesh.profile_read()
     ddist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(True)
+        loss = run()
     ddist.barrier()
     torch.cuda.synchronize()
     elapsed = ddist.allreduce_max_float(time.perf_counter() - t0, dev)
@@ -234,9 +254,16 @@ def main():
         "vs_baseline": None, "dtype": "f32 traversal + f64 shading/gradients", "data": "synthetic",
         "config": {"workload": f"{mesh_src} x4 midpoint subdivision = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD",
-                   "mode": args.mode, "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
+                   "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
                    "final_loss": float(loss.item())},
     }
+    if args.graph:
+        # events cannot be recorded inside a replayed graph: repeat the same K steps eagerly, right after the
+        # timed region, with the per-kernel event pairs on (same kernels, same inputs, same launch stream)
+        scene.optix_mesh.profile_enable(1)
+        scene.optix_mesh.profile_read()
+        for _ in range(args.steps):
+            step(True)
     prof = scene.optix_mesh.profile_read()
     # one extra, untimed step (on every rank: it contains the all-reduce) with the traversal statistics
     # switched on -- they cost contended atomics, so they are kept out of the timed region

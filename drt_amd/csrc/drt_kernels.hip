@@ -857,18 +857,41 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_ray_loss(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
-                                                  const uint8_t* __restrict__ mask, const double* __restrict__ screen_pixel,
-                                                  const uint8_t* __restrict__ valid, int64_t n, double* loss,
-                                                  double* __restrict__ g_out_dir) {
+// ray_loss forward: loss, dense d loss / d out_dir, and (optionally) the list of contributing rays so
+// that the backward can rescale only those rows instead of streaming the whole [N,3] tensor again.
+__global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
+                                                          const uint8_t* __restrict__ mask, const double* __restrict__ screen_pixel,
+                                                          const uint8_t* __restrict__ valid, int64_t n, double* loss,
+                                                          double* __restrict__ g_out_dir, int32_t* __restrict__ list, unsigned* list_count) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
     double acc = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        d3 g{0.0, 0.0, 0.0};
-        if (valid[i] && mask[3 * i]) acc += ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g);
-        if (g_out_dir) store_d3(g_out_dir, i, g);
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        const int64_t i = base + threadIdx.x;
+        bool on = false;
+        if (i < n) {
+            d3 g{0.0, 0.0, 0.0};
+            on = valid[i] && mask[3 * i];
+            if (on) acc += ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g);
+            if (g_out_dir) store_d3(g_out_dir, i, g);
+        }
+        if (list) {
+            const int slot = block_push(on, list_count, s_tmp);
+            if (slot >= 0) list[slot] = (int32_t)i;
+        }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+}
+
+// x[list[k], 0..2] *= *scale
+__global__ void __launch_bounds__(256) k_scale_rows3(double* __restrict__ x, const int32_t* __restrict__ list, const unsigned* __restrict__ n_ptr,
+                                                     const double* __restrict__ scale) {
+    const unsigned n = *n_ptr;
+    const double sc = *scale;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int64_t i = list[k];
+        x[3 * i] *= sc; x[3 * i + 1] *= sc; x[3 * i + 2] *= sc;
+    }
 }
 
 // Fused loss, last stage (full waves over Q2): recompute the path in float64, loss term, adjoint.
@@ -1404,11 +1427,21 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
 }
 
 int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t* d_mask, const double* d_screen_pixel,
-                 const uint8_t* d_valid, int64_t n_rays, double* d_loss, double* d_grad_out_dir, void* stream) {
-    if (n_rays < 0) return fail(DRT_E_INVALID, "negative ray count");
+                 const uint8_t* d_valid, int64_t n_rays, double* d_loss, double* d_grad_out_dir,
+                 int32_t* d_list, uint32_t* d_n_list, void* stream) {
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     if (n_rays == 0) return DRT_OK;
     if (!d_out_ori || !d_out_dir || !d_mask || !d_screen_pixel || !d_valid || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
-    k_ray_loss<<<grid_for(n_rays, 256, 4096), 256, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays, d_loss, d_grad_out_dir);
+    if ((d_list == nullptr) != (d_n_list == nullptr)) return fail(DRT_E_INVALID, "d_list and d_n_list go together");
+    k_ray_loss<<<grid_for(n_rays, kPathBlock, 4096), kPathBlock, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays,
+                                                                                          d_loss, d_grad_out_dir, d_list, d_n_list);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list, const double* d_scale, void* stream) {
+    if (!d_x || !d_list || !d_n_list || !d_scale) return fail(DRT_E_INVALID, "null pointer argument");
+    k_scale_rows3<<<1024, 256, 0, (hipStream_t)stream>>>(d_x, d_list, d_n_list, d_scale);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

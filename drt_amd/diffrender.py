@@ -115,18 +115,27 @@ class _RayLoss(torch.autograd.Function):
         va = valid.contiguous().view(torch.uint8)
         n = oo.shape[0]
         loss = torch.zeros((), dtype=torch.float64, device=oo.device)
-        g = torch.empty_like(od) if ctx.needs_input_grad[1] else None
+        need = ctx.needs_input_grad[1]
+        g = torch.empty_like(od) if need else None
+        rows = torch.empty(n, dtype=torch.int32, device=oo.device) if need else None
+        n_rows = torch.zeros(1, dtype=torch.int32, device=oo.device) if need else None
         with torch.cuda.device(oo.device):
             _lib.check(_lib.lib().drt_ray_loss(oo.data_ptr(), od.data_ptr(), m.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
-                                               loss.data_ptr(), _lib.ptr(g), _stream()))
-        ctx.save_for_backward(g)
+                                               loss.data_ptr(), _lib.ptr(g), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
+        ctx.save_for_backward(g, rows, n_rows)
         return loss
 
     @staticmethod
     def backward(ctx, g_loss):
-        (g,) = ctx.saved_tensors
+        g, rows, n_rows = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None
+        # scale only the contributing rows (a few % of the rays) instead of streaming the dense tensor again;
         # out_ori is detached in the reference's loss (optim.py:100): no gradient for it
-        return None, (None if g is None else g * g_loss), None, None, None
+        sc = g_loss.detach().to(torch.float64).reshape(1).contiguous()
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().drt_scale_rows3(g.data_ptr(), rows.data_ptr(), n_rows.data_ptr(), sc.data_ptr(), _stream()))
+        return None, g, None, None, None
 
 
 class _RenderRayLossFused(torch.autograd.Function):

@@ -97,10 +97,18 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
 /* ---- Loss_calculator.ray_loss, optim.py:91-108 ------------------------------------------
  * loss = sum over rays with valid & mask of |out_dir - normalize(screen_pixel - out_ori)|^2.
  * Forward accumulates into *d_loss (float64 scalar, zero it first) and, when
- * d_grad_out_dir is not NULL, writes d loss / d out_dir float64 [N,3] (zeros elsewhere). */
+ * d_grad_out_dir is not NULL, writes d loss / d out_dir float64 [N,3] (zeros elsewhere).  Optional
+ * (both or neither): d_list int32 [N] receives the indices of the contributing rays and *d_n_list
+ * (uint32, device, zero it first) their number. */
 int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t* d_mask,
                  const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays,
-                 double* d_loss, double* d_grad_out_dir, void* stream);
+                 double* d_loss, double* d_grad_out_dir,
+                 int32_t* d_list, uint32_t* d_n_list, void* stream);
+/* Backward helper of the loss: x[list[k], 0..2] *= *d_scale for the *d_n_list rows listed (the rows
+ * drt_ray_loss reported as contributing) -- rescales d loss / d out_dir by the incoming scalar
+ * gradient without another pass over the dense [N,3] tensor. */
+int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list,
+                    const double* d_scale, void* stream);
 
 /* One pass: render_transparent + ray_loss + d ray_loss / d vertices, nothing dense written.
  * *d_loss += loss, d_grad_verts [V,3] += gradient (both float64, zero them first);

@@ -51,5 +51,5 @@ def test_null_arguments_are_rejected():
     assert lib.drt_create(0, None) != 0
     assert lib.drt_update_vert(None, None, 0, None) != 0
     assert lib.drt_intersect(None, None, 0, None, None, None) != 0
-    assert lib.drt_ray_loss(None, None, None, None, None, 5, None, None, None) != 0
+    assert lib.drt_ray_loss(None, None, None, None, None, 5, None, None, None, None, None) != 0
     lib.drt_destroy(None)   # no-op

@@ -1,6 +1,5 @@
-for im in 1 8 16 32 48; do
-echo -n "inner_min=$im: "; DRT_INNER_MIN=$im python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+for v in 9 18 36 72; do for g in 0 1; do echo -n "views=$v graph=$g: "; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --views $v --graph $g 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); st=d['roofline']['stages']
-print(d['ms_per_step'], {k:(st[k]['ms_per_step'], st[k].get('lane_utilisation'), st[k].get('node_visits_per_ray')) for k in ('trace1','trace2','trace3') if k in st})"
-done
+try:
+    d=json.loads(sys.stdin.read()); st=d['roofline']['stages']; print(d['value'], d['ms_per_step'], d['config']['final_loss'], 'kernels', round(sum(st[k]['ms_per_step'] for k in st),3))
+except Exception as e: print('FAILED', e)"; done; done
