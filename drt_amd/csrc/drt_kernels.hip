@@ -572,14 +572,29 @@ __device__ __forceinline__ bool hits_top_boxes(const Node4* __restrict__ nodes, 
     return any;
 }
 
+// `tile_w` > 0: the rays are rows of an image `tile_w` pixels wide (any number of images of a
+// multiple-of-4 height, concatenated).  A block then takes a 64x4 pixel patch per iteration and
+// appends its candidates in 16x4-tile order, so that the 64 rays a traversal wave picks up come from
+// a compact screen region (same BVH nodes, same depth) instead of a 64x1 strip.
 template <bool FUSED>
 __global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                       const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
                                                       double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
+                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w) {
     __shared__ unsigned s_tmp[kPathWaves + 1];
+    __shared__ uint8_t s_flag[kPathBlock];
+    __shared__ int s_slot[kPathBlock];
+    const int tid = threadIdx.x;
+    // patch = 64 pixels wide x 4 rows (every wave reads one full 1536-byte row segment); tiles of 16x4 pixels
+    const int vt = ((tid & 63) >> 4) * 64 + (tid >> 6) * 16 + (tid & 15);   // position of this thread's pixel in tile order
+    const int64_t patches_per_row = tile_w > 0 ? tile_w / 64 : 1;
     for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
-        const int64_t i = base + threadIdx.x;
+        int64_t i = base + tid;
+        if (tile_w > 0) {
+            const int64_t patch = base / kPathBlock;
+            const int64_t y = 4 * (patch / patches_per_row) + (tid >> 6), x = 64 * (patch % patches_per_row) + (tid & 63);
+            i = y * tile_w + x;
+        }
         bool cand = false;
         f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f};
         if (i < n) {
@@ -593,7 +608,17 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double
                 if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
             }
         }
-        const int slot = block_push(cand, &p.count[0], s_tmp);
+        int slot;
+        if (tile_w > 0) {
+            s_flag[vt] = cand ? 1 : 0;
+            __syncthreads();
+            s_slot[tid] = block_push(s_flag[tid] != 0, &p.count[0], s_tmp);   // ranks in tile order
+            __syncthreads();
+            slot = s_slot[vt];
+            __syncthreads();
+        } else {
+            slot = block_push(cand, &p.count[0], s_tmp);
+        }
         if (slot >= 0) { p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d); }
     }
 }
@@ -608,24 +633,29 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
     const unsigned n = *n_ptr;
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * kPathWaves + (threadIdx.x >> 6), n_waves = gridDim.x * kPathWaves;
-    const unsigned per = (((n + n_waves - 1) / n_waves) + 63u) & ~63u;
-    unsigned cursor = min(n, wave * per);
-    const unsigned seg_end = min(n, cursor + per);
+    // Work assignment without atomics: the list is cut into groups of 64 consecutive rays (one 8x8 screen
+    // tile when k_cull ordered it so) and wave w owns groups w, w + n_waves, w + 2 n_waves, ...: coherent
+    // within a group, statistically balanced across waves.  `taken` counts the rays this wave has started.
+    const unsigned n_groups = (n + 63u) >> 6;
+    const unsigned my_groups = wave < n_groups ? (n_groups - wave + n_waves - 1) / n_waves : 0u;
+    const unsigned my_rays = my_groups << 6;      // upper bound; indices >= n are skipped
+    unsigned taken = 0;
     int32_t slot = -1;
     TravState s;
     unsigned long long wave_steps = 0, lane_steps = 0, refills = 0;   // wave-uniform diagnostics (scalar registers)
     for (;;) {
         const unsigned long long idle = __ballot(slot < 0);
-        if (idle != 0 && cursor < seg_end && (__popcll(idle) >= refill_min || idle == ~0ull)) {
+        if (idle != 0 && taken < my_rays && (__popcll(idle) >= refill_min || idle == ~0ull)) {
             if (slot < 0) {
-                const unsigned k = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-                if (k < seg_end) {
+                const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                const unsigned k = (((j >> 6) * n_waves + wave) << 6) | (j & 63u);
+                if (j < my_rays && k < n) {
                     const float* e = rays + 6 * (int64_t)k;
                     trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
                     slot = (int32_t)k;
                 }
             }
-            cursor += (unsigned)__popcll(idle);
+            taken += (unsigned)__popcll(idle);
             ++refills;
         }
         const unsigned long long busy = __ballot(slot >= 0);
@@ -1341,10 +1371,11 @@ static Pipe pipe_of(const drt_scene* s) {
 extern "C++" {
 template <bool FUSED>
 static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
-                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2) {
+                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w) {
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
+    if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
     { StageTimer t(s, st, kStageCull);
-      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p); }
+      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
     { StageTimer t(s, st, kStageTrace1);
       k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr); }
     { StageTimer t(s, st, kStageShade1);
@@ -1358,9 +1389,18 @@ static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const 
 }
 }  // extern "C++"
 
+static int64_t pass_size(const drt_scene* s, int64_t n_rays, int tile_w) {
+    const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
+    int64_t unit = 256;
+    if (tile_w >= 64 && tile_w % 64 == 0) unit = 4 * (int64_t)tile_w;       // whole rows of 64x4 patches per pass
+    int64_t chunk = (n_rays + n_pass - 1) / n_pass;
+    chunk = (chunk + unit - 1) / unit * unit;                                 // equal passes: fewer, longer launches amortise wave tails
+    return chunk;
+}
+
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
-                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, void* stream) {
+                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -1370,8 +1410,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     }
     if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
-    const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
-    const int64_t chunk = (((n_rays + n_pass - 1) / n_pass) + 255) & ~(int64_t)255;   // equal passes: fewer, longer launches amortise wave tails
+    const int64_t chunk = pass_size(s, n_rays, tile_w);
     int rc = ensure_queues(s, chunk, false);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
@@ -1381,7 +1420,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
         if (b) HIP_TRY(hipMemsetAsync(s->qcount, 0, 3 * sizeof(unsigned), st));
         launch_chunk<false>(s, st, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                            d_mask + 3 * b, d_face1 + b, d_face2 + b);
+                            d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w);
         { StageTimer t(s, st, kStageFinish);
           k_finish<<<8 * s->n_cu, kPathBlock, 0, st>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
         if (s->prof_on) k_prof_counts<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts, 0);
@@ -1448,14 +1487,13 @@ int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list
 
 int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir,
                               const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays, double ior_int,
-                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, void* stream) {
+                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, int tile_w, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
-    const int64_t chunk = (((n_rays + n_pass - 1) / n_pass) + 255) & ~(int64_t)255;   // equal passes: fewer, longer launches amortise wave tails
+    const int64_t chunk = pass_size(s, n_rays, tile_w);
     int rc = ensure_queues(s, chunk, true);
     if (rc) return rc;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
@@ -1463,7 +1501,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     for (int64_t b = 0; b < n_rays; b += chunk) {
         const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
         HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        launch_chunk<true>(s, st, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2);
+        launch_chunk<true>(s, st, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2, tile_w);
         { StageTimer t(s, st, kStageLossBwdFused);
           k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, p,
                                                          d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }

@@ -79,12 +79,15 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
  *      face2 >= 0 exactly for the rays with mask = 1 (saved for backward), face1 = -1 on
  *      a primary miss.  Optional (both or neither): d_valid_idx int32 [N] receives the indices of
  *      the rays with mask = 1 (unordered), *d_n_valid (int64, device) their number -- handing
- *      them to drt_render_backward spares it a pass over the dense arrays. */
+ *      them to drt_render_backward spares it a pass over the dense arrays.
+ *      tile_w: 0, or the width in pixels of the image(s) whose rows the rays are (multiple of 32, whole
+ *      images of a multiple-of-8 height concatenated): a pure ordering hint that lets the pipeline
+ *      group rays by 8x8 screen tiles; results do not depend on it. */
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                        double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
                        int32_t* d_face1, int32_t* d_face2,
-                       int32_t* d_valid_idx, int64_t* d_n_valid, void* stream);
+                       int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, void* stream);
 /* Adjoint of drt_render_forward w.r.t. the vertices: d_grad_verts float64 [V,3] += ...
  * (atomic accumulation; zero it first).  Either incoming gradient may be NULL (= zeros). */
 int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin,
@@ -117,7 +120,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
                               const double* d_dir, const double* d_screen_pixel,
                               const uint8_t* d_valid, int64_t n_rays, double ior_int,
                               double ior_ext, double* d_loss, double* d_grad_verts,
-                              int64_t* d_n_valid, void* stream);
+                              int64_t* d_n_valid, int tile_w, void* stream);
 
 /* ---- smoothness branch: Scene.dihedral_angle (DiffRender.py:440-443, edge_face_norm :149-163)
  * and Loss_calculator.sm_loss (optim.py:82-89) ---------------------------------------------------

@@ -232,9 +232,16 @@ def test_properties_at_full_size(Render, horse50k):
     # exit rays leave the object: re-tracing them hits nothing (that is the occlusion test)
     _, again = scene.optix_intersect(Render.Ray(out_ori.detach()[m], out_dir.detach()[m]))
     assert not again.any()
-    # determinism of the forward, run-to-run
+    # determinism of the forward, run-to-run, and independence from the 8x8-tile ordering hint
     o2, d2, m2 = scene.render_transparent(o, d)
     assert torch.equal(o2, out_ori) and torch.equal(d2, out_dir) and torch.equal(m2, mask)
+    saved = (Render.resx, Render.resy)
+    for rx, ry in ((1024, 1024), (7, 7)):          # tiled (whole 1024-wide images) vs linear order
+        Render.resx, Render.resy = rx, ry
+        o3, d3, m3 = scene.render_transparent(o, d)
+        assert torch.equal(o3, out_ori) and torch.equal(d3, out_dir) and torch.equal(m3, mask)
+        assert torch.equal(scene.last_face1, f1) and torch.equal(scene.last_face2, f2)
+    Render.resx, Render.resy = saved
     # linearity of the adjoint in the incoming gradient, and fused == two-pass
     w = torch.randn(o.shape, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     g1, = torch.autograd.grad((out_dir * w).sum(), V, retain_graph=True)
