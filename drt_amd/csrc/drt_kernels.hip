@@ -75,15 +75,30 @@ struct drt_scene {
     int32_t *parent_inner = nullptr, *parent_leaf = nullptr;
     uint32_t* flags = nullptr;
     BuildParams* params = nullptr;
-    int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev]
+    int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev] (B1 queries and edge probes)
     unsigned long long* scratch = nullptr;  // small counters
     // wavefront-pipeline workspace, sized for one chunk of rays, allocated on first use
-    int32_t* q_idx[3] = {nullptr, nullptr, nullptr};     // ray lists R0..R2: index,
-    float* q_ray[3] = {nullptr, nullptr, nullptr};       //   float32 ray [cap,6],
-    int32_t* q_face[3] = {nullptr, nullptr, nullptr};    //   traversal result
-    int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;  // fused path keeps face ids here; backward fallback list
-    unsigned* qcount = nullptr;    // [4]
-    int64_t q_cap = 0, fused_cap = 0;
+    // Pipeline workspaces: one per internal stream.  A call is cut into sub-batches that run on
+    // different HIP streams, so that the HBM-bound k_cull of one sub-batch overlaps the latency-bound
+    // k_trace of another and the tail of one kernel is filled by the next sub-batch's work.
+    struct Sub {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        int32_t* q_idx[3] = {nullptr, nullptr, nullptr};     // ray lists R0..R2: index,
+        float* q_ray[3] = {nullptr, nullptr, nullptr};       //   float32 ray [cap,6],
+        int32_t* q_face[3] = {nullptr, nullptr, nullptr};    //   traversal result
+        int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;  // fused path keeps face ids here; backward fallback list
+        unsigned* qcount = nullptr;                          // [3] list sizes of the sub-batch in flight
+        int32_t* slow_stack = nullptr;                       // traversal-stack overflow area of this stream's kernels
+        int64_t q_cap = 0, fused_cap = 0;
+    };
+    static constexpr int kMaxSub = 4;
+    Sub sub[kMaxSub];
+    int n_sub = 2;                 // internal streams in use
+    int sub_per_stream = 1;        // sub-batches dealt to each stream (when the call is large enough)
+    int64_t min_sub_rays = 1 << 24;   // do not cut a call into sub-batches smaller than this
+    hipEvent_t fork_ev = nullptr;
+    unsigned* vcount = nullptr;    // [1] valid rays of the whole call
     // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream
     bool prof_on = false;
     bool prof_stats = false;                  // level 2: k_trace also accumulates visit statistics (adds contended atomics)
@@ -497,7 +512,8 @@ struct RayList {
 };
 struct Pipe {
     RayList r0, r1, r2;
-    unsigned* count;  // [0..2] list sizes of the current chunk, [3] valid rays of the whole call
+    unsigned* count;   // [0..2] list sizes of the sub-batch in flight
+    unsigned* valid;   // number of valid rays of the whole call (shared by all sub-batches)
 };
 
 // Block-wide ordered compaction: returns the list slot of this thread's item, or -1.
@@ -783,7 +799,7 @@ __global__ void __launch_bounds__(kPathBlock) k_finish(double* __restrict__ out_
             if (!keep) write_dead(i, out_ori, out_dir, mask, face2);
         }
         if (valid_idx) {
-            const int slot = block_push(keep, &p.count[3], s_tmp);
+            const int slot = block_push(keep, p.valid, s_tmp);
             if (slot >= 0) valid_idx[slot] = (int32_t)(chunk_base + i);
         }
     }
@@ -1172,7 +1188,18 @@ int drt_create(int device, drt_scene_t** out) {
     hipError_t e = hipMalloc(&s->params, sizeof(BuildParams));
     if (e == hipSuccess) e = hipMalloc(&s->slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
     if (e == hipSuccess) e = hipMalloc(&s->scratch, sizeof(unsigned long long) * 8);
-    if (e == hipSuccess) e = hipMalloc(&s->qcount, sizeof(unsigned) * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
+    if (const char* ev = getenv("DRT_STREAMS")) { const int v = atoi(ev); if (v >= 1 && v <= drt_scene::kMaxSub) s->n_sub = v; }
+    if (const char* ev = getenv("DRT_SUB_PER_STREAM")) { const int v = atoi(ev); if (v >= 1 && v <= 16) s->sub_per_stream = v; }
+    if (const char* ev = getenv("DRT_MIN_SUB_LOG2")) { const int v = atoi(ev); if (v >= 12 && v <= 30) s->min_sub_rays = (int64_t)1 << v; }
+    for (int k = 0; k < s->n_sub && e == hipSuccess; ++k) {
+        drt_scene::Sub& w = s->sub[k];
+        e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * 4);
+        if (e == hipSuccess) e = hipMalloc(&w.slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
+    }
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
@@ -1204,8 +1231,15 @@ void drt_destroy(drt_scene_t* s) {
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
     (void)hipFree(s->scratch);
-    for (int k = 0; k < 3; ++k) { (void)hipFree(s->q_idx[k]); (void)hipFree(s->q_ray[k]); (void)hipFree(s->q_face[k]); }
-    (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2); (void)hipFree(s->qcount);
+    for (int j = 0; j < drt_scene::kMaxSub; ++j) {
+        drt_scene::Sub& w = s->sub[j];
+        for (int k = 0; k < 3; ++k) { (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]); }
+        (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2); (void)hipFree(w.qcount); (void)hipFree(w.slow_stack);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
+    (void)hipFree(s->vcount);
+    if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
     for (auto& e : s->prof_ev) (void)hipEventDestroy(e);
     (void)hipFree(s->prof_counts);
     delete s;
@@ -1307,7 +1341,7 @@ struct StageTimer {
         if (!s->prof_on || s->prof_used + 2 > s->prof_ev.size()) return;
         on = true;
         s->prof_stage[s->prof_used / 2] = stage;
-        s->prof_stream = st;
+        if (!s->prof_stream) s->prof_stream = st;
         (void)hipEventRecord(s->prof_ev[s->prof_used], st);
     }
     ~StageTimer() {
@@ -1319,16 +1353,17 @@ struct StageTimer {
 
 __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    tot[kStageCull] += n_rays;
-    tot[kStageTrace1] += qcount[0]; tot[kStageShade1] += qcount[0];
-    tot[kStageTrace2] += qcount[1]; tot[kStageShade2] += qcount[1];
-    tot[kStageTrace3] += qcount[2];
-    if (fused) tot[kStageLossBwdFused] += qcount[2]; else tot[kStageFinish] += qcount[2];
+    // sub-batches on different streams may report concurrently: atomics
+    atomicAdd(&tot[kStageCull], n_rays);
+    atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
+    atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
+    atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[2]);
+    atomicAdd(&tot[fused ? kStageLossBwdFused : kStageFinish], (unsigned long long)qcount[2]);
 }
-__global__ void k_prof_counts_bwd(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot) {
+__global__ void k_prof_counts_bwd(const unsigned* __restrict__ vcount, unsigned long long n_rays, unsigned long long* __restrict__ tot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     tot[kStageCollect] += n_rays;
-    tot[kStageBackward] += qcount[3];
+    tot[kStageBackward] += vcount[0];
 }
 
 static int rebuild(drt_scene* s, hipStream_t st) {
@@ -1338,36 +1373,57 @@ static int rebuild(drt_scene* s, hipStream_t st) {
 
 // Queue workspace for one chunk of `n` rays (grown, never shrunk).  Growing frees the old buffers,
 // which synchronises the device once; steady-state calls allocate nothing.
-static int ensure_queues(drt_scene* s, int64_t n, bool fused) {
-    if (n > s->q_cap) {
+static int ensure_queues(drt_scene::Sub& w, int64_t n, bool fused) {
+    if (n > w.q_cap) {
         for (int k = 0; k < 3; ++k) {
-            (void)hipFree(s->q_idx[k]); (void)hipFree(s->q_ray[k]); (void)hipFree(s->q_face[k]);
-            s->q_idx[k] = nullptr; s->q_ray[k] = nullptr; s->q_face[k] = nullptr;
+            (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]);
+            w.q_idx[k] = nullptr; w.q_ray[k] = nullptr; w.q_face[k] = nullptr;
         }
-        s->q_cap = 0;
+        w.q_cap = 0;
         for (int k = 0; k < 3; ++k) {
-            HIP_TRY(hipMalloc(&s->q_idx[k], sizeof(int32_t) * n));
-            HIP_TRY(hipMalloc(&s->q_ray[k], sizeof(float) * 6 * n));
-            HIP_TRY(hipMalloc(&s->q_face[k], sizeof(int32_t) * n));
+            HIP_TRY(hipMalloc(&w.q_idx[k], sizeof(int32_t) * n));
+            HIP_TRY(hipMalloc(&w.q_ray[k], sizeof(float) * 6 * n));
+            HIP_TRY(hipMalloc(&w.q_face[k], sizeof(int32_t) * n));
         }
-        s->q_cap = n;
+        w.q_cap = n;
     }
-    if (fused && n > s->fused_cap) {
-        (void)hipFree(s->tmp_face1); (void)hipFree(s->tmp_face2);
-        s->tmp_face1 = s->tmp_face2 = nullptr; s->fused_cap = 0;
-        HIP_TRY(hipMalloc(&s->tmp_face1, sizeof(int32_t) * n));
-        HIP_TRY(hipMalloc(&s->tmp_face2, sizeof(int32_t) * n));
-        s->fused_cap = n;
+    if (fused && n > w.fused_cap) {
+        (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2);
+        w.tmp_face1 = w.tmp_face2 = nullptr; w.fused_cap = 0;
+        HIP_TRY(hipMalloc(&w.tmp_face1, sizeof(int32_t) * n));
+        HIP_TRY(hipMalloc(&w.tmp_face2, sizeof(int32_t) * n));
+        w.fused_cap = n;
     }
     return DRT_OK;
 }
 
-static Pipe pipe_of(const drt_scene* s) {
-    return Pipe{RayList{s->q_idx[0], s->q_ray[0], s->q_face[0]}, RayList{s->q_idx[1], s->q_ray[1], s->q_face[1]},
-                RayList{s->q_idx[2], s->q_ray[2], s->q_face[2]}, s->qcount};
+static Pipe pipe_of(const drt_scene* s, const drt_scene::Sub& w) {
+    return Pipe{RayList{w.q_idx[0], w.q_ray[0], w.q_face[0]}, RayList{w.q_idx[1], w.q_ray[1], w.q_face[1]},
+                RayList{w.q_idx[2], w.q_ray[2], w.q_face[2]}, w.qcount, s->vcount};
 }
 
-// cull -> trace -> shade1 -> trace -> shade2 -> trace(any) for one chunk; the caller appends the last stage.
+// How a call of n_rays is cut: `size` rays per sub-batch (a multiple of `unit`), `count` sub-batches, dealt
+// round-robin to `streams` internal streams.  Sub-batches are at most chunk_rays (workspace bound) and, when
+// there is enough work, at least min_sub_rays, so that small calls are not shredded into launch overhead.
+struct Plan { int64_t size; int count; int streams; };
+static Plan plan_call(const drt_scene* s, int64_t n_rays, int tile_w) {
+    int64_t unit = 256;
+    if (tile_w >= 64 && tile_w % 64 == 0) unit = 4 * (int64_t)tile_w;       // whole rows of 64x4 patches per sub-batch
+    int64_t count = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
+    const int64_t by_min = n_rays / s->min_sub_rays;
+    const int64_t most = (int64_t)s->n_sub * s->sub_per_stream;
+    const int64_t want = by_min < most ? by_min : most;
+    if (want > count) count = want;
+    if (count < 1) count = 1;
+    int64_t size = (n_rays + count - 1) / count;
+    size = (size + unit - 1) / unit * unit;
+    count = (n_rays + size - 1) / size;
+    Plan pl;
+    pl.size = size; pl.count = (int)count; pl.streams = count < s->n_sub ? (int)count : s->n_sub;
+    return pl;
+}
+
+// cull -> trace -> shade1 -> trace -> shade2 -> trace(any) for one sub-batch; the caller appends the last stage.
 extern "C++" {
 template <bool FUSED>
 static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
@@ -1389,13 +1445,25 @@ static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const 
 }
 }  // extern "C++"
 
-static int64_t pass_size(const drt_scene* s, int64_t n_rays, int tile_w) {
-    const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
-    int64_t unit = 256;
-    if (tile_w >= 64 && tile_w % 64 == 0) unit = 4 * (int64_t)tile_w;       // whole rows of 64x4 patches per pass
-    int64_t chunk = (n_rays + n_pass - 1) / n_pass;
-    chunk = (chunk + unit - 1) / unit * unit;                                 // equal passes: fewer, longer launches amortise wave tails
-    return chunk;
+// Fork: the internal streams wait for everything already enqueued on the caller's stream.
+static int fork_streams(drt_scene* s, hipStream_t st, int streams) {
+    HIP_TRY(hipEventRecord(s->fork_ev, st));
+    for (int k = 0; k < streams; ++k) HIP_TRY(hipStreamWaitEvent(s->sub[k].stream, s->fork_ev, 0));
+    return DRT_OK;
+}
+// Join: the caller's stream waits for every internal stream.
+static int join_streams(drt_scene* s, hipStream_t st, int streams) {
+    for (int k = 0; k < streams; ++k) {
+        HIP_TRY(hipEventRecord(s->sub[k].done, s->sub[k].stream));
+        HIP_TRY(hipStreamWaitEvent(st, s->sub[k].done, 0));
+    }
+    return DRT_OK;
+}
+
+static PathCtx sub_ctx(const drt_scene* s, const drt_scene::Sub& w, const double* d_verts, double ior_int, double ior_ext) {
+    PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    pc.tc.slow_stack = w.slow_stack;     // concurrent kernels must not share overflow stacks
+    return pc;
 }
 
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
@@ -1410,22 +1478,28 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     }
     if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
-    const int64_t chunk = pass_size(s, n_rays, tile_w);
-    int rc = ensure_queues(s, chunk, false);
+    const Plan pl = plan_call(s, n_rays, tile_w);
+    for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, false); if (rc) return rc; }
+    HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
+    int rc = fork_streams(s, st, pl.streams);
     if (rc) return rc;
-    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Pipe p = pipe_of(s);
-    HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-    for (int64_t b = 0; b < n_rays; b += chunk) {
-        const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-        if (b) HIP_TRY(hipMemsetAsync(s->qcount, 0, 3 * sizeof(unsigned), st));
-        launch_chunk<false>(s, st, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
+    for (int j = 0; j < pl.count; ++j) {
+        drt_scene::Sub& w = s->sub[j % pl.streams];
+        const int64_t b = j * pl.size;
+        const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
+        const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
+        const Pipe p = pipe_of(s, w);
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, 3 * sizeof(unsigned), w.stream));
+        launch_chunk<false>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
                             d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w);
-        { StageTimer t(s, st, kStageFinish);
-          k_finish<<<8 * s->n_cu, kPathBlock, 0, st>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
-        if (s->prof_on) k_prof_counts<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts, 0);
+        { StageTimer t(s, w.stream, kStageFinish);
+          k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 0);
     }
-    if (d_n_valid) k_store_count<<<1, 64, 0, st>>>(s->qcount + 3, d_n_valid);
+    rc = join_streams(s, st, pl.streams);
+    if (rc) return rc;
+    if (d_n_valid) k_store_count<<<1, 64, 0, st>>>(s->vcount, d_n_valid);
+    if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -1445,22 +1519,23 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
         StageTimer t(s, st, kStageBackward);
         k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
                                                    d_valid_idx, nullptr, d_n_valid);
-    } else {
-        const int64_t n_pass = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
-    const int64_t chunk = (((n_rays + n_pass - 1) / n_pass) + 255) & ~(int64_t)255;   // equal passes: fewer, longer launches amortise wave tails
-        int rc = ensure_queues(s, chunk, false);
+    } else {             // no list saved: compact face2 >= 0 first (on the caller's stream, workspace of sub-stream 0)
+        drt_scene::Sub& w = s->sub[0];
+        const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
+        int rc = ensure_queues(w, chunk, false);
         if (rc) return rc;
         for (int64_t b = 0; b < n_rays; b += chunk) {
             const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-            HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
+            HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
             { StageTimer t(s, st, kStageCollect);
-              k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, b, s->q_idx[0], s->qcount + 3); }
+              k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, b, w.q_idx[0], s->vcount); }
             { StageTimer t(s, st, kStageBackward);
               k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
-                                                         s->q_idx[0], s->qcount + 3, nullptr); }
-            if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts);
+                                                         w.q_idx[0], s->vcount, nullptr); }
+            if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->vcount, (unsigned long long)n, s->prof_counts);
         }
     }
+    if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -1493,20 +1568,26 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t chunk = pass_size(s, n_rays, tile_w);
-    int rc = ensure_queues(s, chunk, true);
+    const Plan pl = plan_call(s, n_rays, tile_w);
+    for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true); if (rc) return rc; }
+    int rc = fork_streams(s, st, pl.streams);
     if (rc) return rc;
-    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
-    const Pipe p = pipe_of(s);
-    for (int64_t b = 0; b < n_rays; b += chunk) {
-        const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
-        HIP_TRY(hipMemsetAsync(s->qcount, 0, 4 * sizeof(unsigned), st));
-        launch_chunk<true>(s, st, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, s->tmp_face1, s->tmp_face2, tile_w);
-        { StageTimer t(s, st, kStageLossBwdFused);
-          k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, s->tmp_face1, s->tmp_face2, p,
-                                                         d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
-        if (s->prof_on) k_prof_counts<<<1, 64, 0, st>>>(s->qcount, (unsigned long long)n, s->prof_counts, 1);
+    for (int j = 0; j < pl.count; ++j) {
+        drt_scene::Sub& w = s->sub[j % pl.streams];
+        const int64_t b = j * pl.size;
+        const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
+        const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
+        const Pipe p = pipe_of(s, w);
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, 3 * sizeof(unsigned), w.stream));
+        launch_chunk<true>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w);
+        { StageTimer t(s, w.stream, kStageLossBwdFused);
+          k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
+                                                               d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1);
     }
+    rc = join_streams(s, st, pl.streams);
+    if (rc) return rc;
+    if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
