@@ -96,7 +96,9 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world):
     return {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
             "traffic": traffic, "avg_launch_ms": stages[dom]["avg_launch_ms"], "stages": stages,
             "whole_step_alg_GBps_per_gpu": round(step_alg / (elapsed / args.steps) / 1e9 / world, 1),
-            "note": "traversal stages are latency-bound on a cache-resident BVH; k_cull is the HBM-streaming stage"}
+            "note": "per-kernel times are hipEvent pairs on the launch streams over the timed region; sub-batches run on two internal "
+                    "streams, so stage durations overlap (their sum exceeds the step). Traversal stages are issue/latency-bound on a "
+                    "cache-resident BVH (see node_visits_per_ray, lane_utilisation); k_cull is the HBM-streaming stage."}
 
 
 def cpu_baseline(mesh, center, extent, res_sample=128):
@@ -138,6 +140,9 @@ def main():
     ap.add_argument("--graph", type=int, default=0,
                     help="1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras after the timed region (fused-mode comparison, traversal statistics); "
+                         "used under rocprofv3 so that the trace ends with the timed steps")
     ap.add_argument("--random-targets", action="store_true",
                     help="skip the ground-truth render of the setup (targets = random points); used for PMC passes so that every "
                          "traced kernel dispatch belongs to a step")
@@ -257,6 +262,33 @@ def main():
                    "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
                    "final_loss": float(loss.item())},
     }
+    prof_timed = None if args.graph else scene.optix_mesh.profile_read()
+    fused_extra = None
+    if args.mode == "dropin" and not args.graph and not args.no_extras:
+        # same K steps through the one-pass API (Scene.ray_loss_fused: no dense out_ori/out_dir/mask, rays of
+        # pixels without a target dropped before tracing) -- reported next to the headline, never as `value`
+        def fused_step():
+            opt.zero_grad(set_to_none=True)
+            scene.update_verticex(init_vertices + parameter)
+            fl = torch.zeros((), dtype=torch.float64, device=dev)
+            for sp, valid, o, d in data:
+                fl = fl + scene.ray_loss_fused(o, d, sp, valid)
+            (w_ray * fl).backward()
+            ddist.allreduce_sum_(parameter.grad)
+            parameter.grad = limit_hook(parameter.grad)
+            opt.step()
+        scene.optix_mesh.profile_enable(0)
+        fused_step()
+        ddist.barrier(); torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for _ in range(args.steps):
+            fused_step()
+        ddist.barrier(); torch.cuda.synchronize()
+        tf = ddist.allreduce_max_float(time.perf_counter() - tf, dev)
+        fused_extra = {"M_rays_per_s": round(total_rays / tf / 1e6, 3), "ms_per_step": round(1e3 * tf / args.steps, 3),
+                       "alg_bytes_per_ray": 73, "api": "Scene.ray_loss_fused (render_transparent + ray_loss + backward in one pass)"}
+        scene.optix_mesh.profile_enable(1)
+        scene.optix_mesh.profile_read()
     if args.graph:
         # events cannot be recorded inside a replayed graph: repeat the same K steps eagerly, right after the
         # timed region, with the per-kernel event pairs on (same kernels, same inputs, same launch stream)
@@ -264,13 +296,16 @@ def main():
         scene.optix_mesh.profile_read()
         for _ in range(args.steps):
             step(True)
-    prof = scene.optix_mesh.profile_read()
+        prof_timed = scene.optix_mesh.profile_read()
+    prof = prof_timed
     # one extra, untimed step (on every rank: it contains the all-reduce) with the traversal statistics
     # switched on -- they cost contended atomics, so they are kept out of the timed region
-    scene.optix_mesh.profile_enable(2)
-    step(False)
-    prof2 = scene.optix_mesh.profile_read()
-    tstats = scene.optix_mesh.trace_stats()
+    tstats, prof2 = {}, None
+    if not args.no_extras:
+        scene.optix_mesh.profile_enable(2)
+        step(False)
+        prof2 = scene.optix_mesh.profile_read()
+        tstats = scene.optix_mesh.trace_stats()
     scene.optix_mesh.profile_enable(0)
     if rank == 0:
         out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world)
@@ -278,6 +313,8 @@ def main():
             if ws and k in out["roofline"]["stages"]:
                 out["roofline"]["stages"][k].update({"node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),
                                                      "lane_utilisation": round(ls / (64.0 * ws), 3), "longest_wave_visits": mx})
+        if fused_extra:
+            out["fused_mode"] = fused_extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mesh, center, extent)
         print(json.dumps(out), flush=True)

@@ -10,7 +10,7 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 W=/tmp/prof_$TAG; rm -rf "$W"; mkdir -p "$W"
 cd "$R"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$W/kt" -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$O/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$W/kt" -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$O/bench_under_rocprof.log" 2>&1
 find "$W/kt" -name '*kernel_stats.csv' -exec cp {} "$O/kernel_stats.csv" \;
 python - "$W/kt" "$O" <<'PY'
 import csv, glob, sys, collections
@@ -49,7 +49,7 @@ with open(out + '/kernel_summary.txt', 'w') as o:
 PY
 run_pmc () {  # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
   local f=$(find "$W/$name" -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then python tools/pmc_summary.py "$f" k_ > "$O/$name.txt"; else echo "no counter file" > "$O/$name.txt"; fi
 }
@@ -70,7 +70,7 @@ out = sys.argv[1]
 def parse(path, counter):
     res, cur = {}, None
     for line in open(path):
-        m = re.match(r"(?:void )?(k_\w+)(?:<\w+>)?\s+launches=(\d+)", line)
+        m = re.match(r"(?:void )?(k_\w+(?:<\w+>)?)\s+launches=(\d+)", line)
         if m:
             cur = (m.group(1), int(m.group(2)))
             continue
