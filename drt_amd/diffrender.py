@@ -52,7 +52,7 @@ class Ray:
 
 
 def _tile_hint(n_rays):
-    """Image width for the pipeline's 8x8-tile ray grouping when the ray list is whole images of the module's
+    """Image width for the pipeline's 16x4-pixel tile ray grouping when the ray list is whole images of the module's
     resx x resy (as produced by generate_ray, reference captured_data.py:23-40); 0 = no assumption."""
     if resx >= 64 and resx % 64 == 0 and resy % 4 == 0 and n_rays % (resx * resy) == 0:
         return int(resx)

@@ -80,9 +80,9 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
  *      a primary miss.  Optional (both or neither): d_valid_idx int32 [N] receives the indices of
  *      the rays with mask = 1 (unordered), *d_n_valid (int64, device) their number -- handing
  *      them to drt_render_backward spares it a pass over the dense arrays.
- *      tile_w: 0, or the width in pixels of the image(s) whose rows the rays are (multiple of 32, whole
- *      images of a multiple-of-8 height concatenated): a pure ordering hint that lets the pipeline
- *      group rays by 8x8 screen tiles; results do not depend on it. */
+ *      tile_w: 0, or the width in pixels of the image(s) whose rows the rays are (multiple of 64, whole
+ *      images of a multiple-of-4 height concatenated): a pure ordering hint that lets the pipeline
+ *      group rays by 16x4-pixel screen tiles; results do not depend on it. */
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                        double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
