@@ -154,6 +154,10 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    if local_rank >= torch.cuda.device_count():
+        # more ranks than GPUs: only for functional checks of the multi-rank path on one GPU (DRT_DIST_BACKEND=gloo)
+        assert os.environ.get("DRT_DIST_BACKEND") == "gloo", "one rank per GPU"
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdrt_hip.so")
+LIB_PATH = os.environ.get("DRT_HIP_LIB") or os.path.join(_HERE, "libdrt_hip.so")   # override: measurement variants only
 
 _c = ctypes
 _P = _c.c_void_p
