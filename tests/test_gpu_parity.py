@@ -373,3 +373,46 @@ def test_two_optimisation_steps_vs_golden(Render, hand, fused):
         np.testing.assert_allclose(parameter.detach().cpu().numpy(), g[f"param{it}"], rtol=1e-7, atol=1e-11)
     assert scene.mesh.vertices.shape == Vs.shape     # lazy device->host copy of the optimised vertices
     np.testing.assert_allclose(scene.mesh.vertices, vertices.detach().cpu().numpy(), rtol=0, atol=0)
+
+
+def test_optimize_loop_on_synthetic_capture(Render, hand):
+    """drt_amd.optim.optimize (the reference's pass/iteration loop) on a synthetic capture: the smoothed hull is
+    optimised towards a displaced ground truth; the ray loss must fall and every tensor stay finite."""
+    from drt_amd import optim as O
+    g = golden("hand_smooth_sm")
+    Vs = g["vertices"].astype(np.float64)
+    mesh = mesh_io.TriMesh(Vs, hand.faces)
+    res = 128
+    Render.intIOR = IOR
+    Render.resx = Render.resy = res
+    center, extent = views.mesh_frame(Vs)
+    gt = views.displaced_ground_truth(mesh, sigma=0.15, seed=3)
+    scene_gt = Render.Scene(gt, 0)
+    data = O.SyntheticData(scene_gt, center, extent, res, res, num_view=8, n_total=8)
+    tgt, valid, soft, origin, ray_dir, cam = data.get_view(3)
+    assert tgt.shape == (res * res, 3) and valid.dtype == torch.bool and soft.shape == (res * res,)
+    assert 0.01 < valid.float().mean().item() < 0.5 and float(soft.min()) >= 0 and float(soft.max()) <= 1
+    assert torch.all((tgt[:, 0] != 0) == valid)
+    scene = Render.Scene(mesh, 0)
+    hp = dict(O.HyperParams, Pass=1, Iters=30, start_lr=0.05, vh_w=2e-3, sm_w=0.08, ray_w=40)
+
+    def mean_ray_loss():
+        with torch.no_grad():
+            tot = 0.0
+            for k in range(8):
+                t, v, _, o, d, _ = data.get_view(k)
+                oo, od, mk = scene.render_transparent(o, d)
+                tot += Render.ray_loss(oo, od, mk, t, v).item()
+        return tot / 8
+
+    scene.update_verticex(scene.vertices.detach())
+    before = mean_ray_loss()
+    scene, hist = O.optimize(scene, data, hp, output=False)
+    after = mean_ray_loss()
+    assert np.isfinite(before) and np.isfinite(after) and torch.isfinite(scene.vertices).all()
+    assert after < 0.8 * before, (before, after)
+    out = "/tmp/drt_amd_recons.ply"
+    scene.mesh.export(out)
+    back = mesh_io.read_ply(out)
+    assert back.is_watertight and len(back.faces) == len(hand.faces)
+    np.testing.assert_allclose(back.vertices, scene.vertices.detach().cpu().numpy().astype(np.float32), rtol=0, atol=0)
