@@ -36,7 +36,7 @@ B_FWD = 48 + 51              # render_transparent kernel: read origin+dir, write
 B_STEP = 148                 # whole fwd + loss + bwd per ray
 
 
-def load_workload(name):
+def load_workload(name, subdiv=None):
     path = os.path.join(ROOT, "data", f"{name}_vh.ply")
     if os.path.exists(path):
         base = mesh_io.read_ply(path)
@@ -44,8 +44,12 @@ def load_workload(name):
     else:                                   # licence-free stand-in with a similar triangle count
         base = mesh_io.icosphere(4, radius=60.0, noise=0.01)
         src = "icosphere(4)"
-    mesh = mesh_io.subdivide_midpoint(base) if name in ("horse", "mouse") else base
-    return mesh, src
+    if subdiv is None:
+        subdiv = 1 if name in ("horse", "mouse") else 0
+    mesh = base
+    for _ in range(subdiv):
+        mesh = mesh_io.subdivide_midpoint(mesh)
+    return mesh, f"{src} x{4 ** subdiv} ({subdiv} midpoint subdivision{'s' if subdiv != 1 else ''})"
 
 
 def per_view_mesh_bytes(V, F):
@@ -135,6 +139,7 @@ def main():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--views", type=int, default=72)
     ap.add_argument("--mesh", default="horse")
+    ap.add_argument("--subdiv", type=int, default=None, help="midpoint subdivisions of the input hull (default: 1 for horse/mouse)")
     ap.add_argument("--batch-views", type=int, default=0,
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
     ap.add_argument("--graph", type=int, default=0,
@@ -161,7 +166,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    mesh, mesh_src = load_workload(args.mesh)
+    mesh, mesh_src = load_workload(args.mesh, args.subdiv)
     n_faces, n_verts = len(mesh.faces), len(mesh.vertices)
     center, extent = views.mesh_frame(mesh.vertices)
     res = args.res
@@ -261,7 +266,7 @@ def main():
         "value": round(value, 3), "unit": "M camera-rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32 traversal + f64 shading/gradients", "data": "synthetic",
-        "config": {"workload": f"{mesh_src} x4 midpoint subdivision = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
+        "config": {"workload": f"{mesh_src} = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD",
                    "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
                    "final_loss": float(loss.item())},

@@ -70,49 +70,58 @@ class SyntheticData:
                 yield int(i) % self.n_total
 
 
+def loss_weights(hp, resy, mean_len):
+    """(w_ray, w_vh, w_sm): the fixed scalings of reference optim.py:127-129."""
+    return hp["ray_w"] * 217.5 / resy / resy, hp["vh_w"] * 217.5 / resy, hp["sm_w"] * mean_len / 10
+
+
 class Loss_calculator:
+    """Same role and method names as the reference class (optim.py:59-130); every term is evaluated by
+    the HIP kernels behind ``drt_amd.diffrender``.  ``fused=True`` uses the one-pass kernels
+    (``Scene.ray_loss_fused`` / ``Scene.sm_loss_fused``) -- same values, no dense intermediates."""
+
+    N_SILHOUETTE_VIEWS = 8          # the reference loops over np.arange(0, 72, 9)
+
     def __init__(self, scene, data, HyperParams, fused=False):
-        self.scene = scene
-        self.data = data
-        self.HyperParams = HyperParams
-        self.fused = fused
+        self.scene, self.data, self.HyperParams, self.fused = scene, data, HyperParams, fused
         self.ray_view = data.ray_view_generator()
         self.silh_view = data.silh_view_generator()
 
-    def vh_loss(self, n_views=8):
-        scene, data = self.scene, self.data
-        vh_loss = 0
-        for _ in range(n_views):                       # reference: for v in np.arange(0, 72, 9)
-            index = next(self.silh_view)
-            screen_pixel, valid, mask, origin, ray_dir, camera_M = data.get_view(index)
-            silhouette_edge = scene.silhouette_edge(origin[0])
-            index, output = scene.primary_visibility(silhouette_edge, camera_M, origin[0], detach_depth=True)
-            vh_loss = vh_loss + (mask.view((data.resy, data.resx))[index[:, 1], index[:, 0]] - output).abs().sum()
-        return vh_loss
+    def _silhouette_term(self, view_id):
+        """sum |soft_mask[y, x] - 0.5| over the visible silhouette samples of one view (optim.py:74-78)."""
+        _, _, soft_mask, origin, _, camera_M = self.data.get_view(view_id)
+        eye = origin[0]
+        edges = self.scene.silhouette_edge(eye)
+        pix, out = self.scene.primary_visibility(edges, camera_M, eye, detach_depth=True)
+        image = soft_mask.view((self.data.resy, self.data.resx))
+        return (image[pix[:, 1], pix[:, 0]] - out).abs().sum()
+
+    def vh_loss(self):
+        terms = [self._silhouette_term(next(self.silh_view)) for _ in range(self.N_SILHOUETTE_VIEWS)]
+        return torch.stack(terms).sum()
 
     def sm_loss(self):
         if self.fused:
             return self.scene.sm_loss_fused()
-        return (-torch.log(1 + self.scene.dihedral_angle())).sum()
+        cos_dihedral = self.scene.dihedral_angle()
+        return (-torch.log(1 + cos_dihedral)).sum()
 
     def ray_loss(self):
-        V_index = next(self.ray_view)
-        target, valid, mask, origin, ray_dir, camera_M = self.data.get_view(V_index)
+        target, valid, _, origin, ray_dir, _ = self.data.get_view(next(self.ray_view))
         if self.fused:
             return self.scene.ray_loss_fused(origin, ray_dir, target, valid)
-        out_ori, out_dir, render_mask = self.scene.render_transparent(origin, ray_dir)
-        return Render.ray_loss(out_ori, out_dir, render_mask, target, valid)
+        exit_o, exit_d, exit_mask = self.scene.render_transparent(origin, ray_dir)
+        return Render.ray_loss(exit_o, exit_d, exit_mask, target, valid)
 
     def all_loss(self):
-        hp, data, scene = self.HyperParams, self.data, self.scene
-        zero = torch.zeros((), dtype=Float, device=scene.vertices.device)
-        ray_loss = self.ray_loss() if hp["ray_w"] != 0 else zero
-        vh_loss = self.vh_loss() if hp["vh_w"] != 0 else zero
-        sm_loss = self.sm_loss() if hp["sm_w"] != 0 else zero
-        LOSS = hp["ray_w"] * 217.5 / data.resy / data.resy * ray_loss \
-            + hp["vh_w"] * 217.5 / data.resy * vh_loss \
-            + hp["sm_w"] * scene.mean_len / 10 * sm_loss
-        return LOSS, (ray_loss, vh_loss, sm_loss)
+        hp = self.HyperParams
+        none = torch.zeros((), dtype=Float, device=self.scene.vertices.device)
+        parts = (self.ray_loss() if hp["ray_w"] != 0 else none,
+                 self.vh_loss() if hp["vh_w"] != 0 else none,
+                 self.sm_loss() if hp["sm_w"] != 0 else none)
+        w = loss_weights(hp, self.data.resy, self.scene.mean_len)
+        total = w[0] * parts[0] + w[1] * parts[1] + w[2] * parts[2]
+        return total, parts
 
 
 def loss_string(parts):

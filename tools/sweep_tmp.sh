@@ -1,6 +1,7 @@
-for cfg in "2 1 24" "2 2 23" "2 3 22" "3 2 22" "2 4 21"; do set -- $cfg; echo -n "streams=$1 per=$2 minlog=$3: "; DRT_STREAMS=$1 DRT_SUB_PER_STREAM=$2 DRT_MIN_SUB_LOG2=$3 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+for cfg in "hand 0" "horse 0" "horse 1" "horse 2"; do set -- $cfg; DRT_STREAMS=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --mesh $1 --subdiv $2 --views 24 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
-for v in 36 18 9; do echo -n "default views=$v: "; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --views $v 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
+d=json.loads(sys.stdin.read()); st=d['roofline']['stages']
+print(d['config']['workload'][:60], d['ms_per_step'])
+for k in ('trace1','trace2','trace3'):
+    s=st[k]; rays=s['items_per_launch']*s['launches']/3; v=s.get('node_visits_per_ray',0)
+    print('   ',k,'ms',s['ms_per_step'],'rays/step',int(rays),'visits/ray',v,'ps per lane-visit', round(1e9*s['ms_per_step']*1e-3/max(1,rays*v)*1e3,2), 'util', s.get('lane_utilisation'))"; done
