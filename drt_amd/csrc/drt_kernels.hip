@@ -381,7 +381,7 @@ __global__ void k_wide_check(const Node4* __restrict__ wide, const int32_t* __re
     for (int k = 0; k < 4; ++k) {
         const int32_t c = nd.child[k];
         if (c == kEmptyChild || c >= 0) continue;
-        const int first = (~c) >> 2, count = ((~c) & 3) + 1;
+        const int first = (~c) >> kLeafBits, count = ((~c) & (kLeafMax - 1)) + 1;
         for (int j = first; j < first + count; ++j) {
             if (j < 0 || j >= n) { ++bad; continue; }
             atomicAdd(&seen[j], 1u);

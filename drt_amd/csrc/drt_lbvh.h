@@ -135,16 +135,19 @@ DRT_HD void lbvh_children(const uint32_t* keys, int n, int i, int32_t& left, int
 // Fewer, fatter steps: traversal on MI355X is bound by the latency of the dependent node
 // fetches, not by ALU or bytes.  One node = 128 bytes = one L2 line, SoA so that each 16-byte
 // load brings one bound of all four children.
-constexpr int kLeafMax = 4;
+#ifndef DRT_LEAF_BITS
+#define DRT_LEAF_BITS 2
+#endif
+constexpr int kLeafBits = DRT_LEAF_BITS, kLeafMax = 1 << kLeafBits;
 
 struct alignas(16) Node4 {
     float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];
-    int32_t child[4];   // >= 0: Node4 index; < 0: leaf, ~child = (first_slot << 2) | (count - 1); kEmptyChild: none
+    int32_t child[4];   // >= 0: Node4 index; < 0: leaf, ~child = (first_slot << kLeafBits) | (count - 1); kEmptyChild: none
     int32_t pad[4];
 };
 constexpr int32_t kEmptyChild = INT32_MIN;   // an inverted box still passes a slab test (inf - inf), so empties are flagged
 
-DRT_HD int32_t leaf_ref(int first, int count) { return ~((first << 2) | (count - 1)); }
+DRT_HD int32_t leaf_ref(int first, int count) { return ~((first << kLeafBits) | (count - 1)); }
 
 DRT_HD bool wide_leaf_of(int32_t c, const int32_t* range_lo, const int32_t* range_hi, int& first, int& count) {
     if (c < 0) { first = ~c; count = 1; return true; }

@@ -147,7 +147,7 @@ DRT_HD bool trav_inner(const Node4* __restrict__ nodes, TravState& s, Stack& st)
 template <bool ANY>
 DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, Stack& st) {
     const int32_t ref = ~s.cur;
-    const int first = ref >> 2, count = (ref & 3) + 1;
+    const int first = ref >> kLeafBits, count = (ref & (kLeafMax - 1)) + 1;
     for (int j = 0; j < count; ++j) {
         const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
         const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];

@@ -160,7 +160,7 @@ int64_t hs_check(void* h) {
             const int32_t c = nd.child[k];
             if (c == kEmptyChild) continue;
             if (c >= 0) { todo.push_back(c); continue; }
-            const int first = (~c) >> 2, count = ((~c) & 3) + 1;
+            const int first = (~c) >> kLeafBits, count = ((~c) & (kLeafMax - 1)) + 1;
             for (int j = first; j < first + count; ++j) {
                 if (j < 0 || j >= n) { ++bad; continue; }
                 ++seen[j];
