@@ -43,7 +43,10 @@ static int fail(int code, const char* fmt, ...) {
 // scene object
 // ------------------------------------------------------------------------------------------
 constexpr int kTraceBlock = 128;       // threads per block in traversal kernels (2 waves)
-constexpr int kStackFast = 19;         // LDS stack entries per lane (19.5 KB per 256-thread block -> 8 blocks = 32 waves per CU)
+#ifndef DRT_STACK_FAST
+#define DRT_STACK_FAST 19
+#endif
+constexpr int kStackFast = DRT_STACK_FAST;         // LDS stack entries per lane (19.5 KB per 256-thread block -> 8 blocks = 32 waves per CU)
 constexpr int kStackSlowDev = 45;      // global overflow entries per thread (LBVH height <= 30 + log2 F <= 64)
 constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
 constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds the list workspace (96 B per ray of the largest pass)
@@ -88,7 +91,8 @@ struct drt_scene {
         float* q_ray[3] = {nullptr, nullptr, nullptr};       //   float32 ray [cap,6],
         int32_t* q_face[3] = {nullptr, nullptr, nullptr};    //   traversal result
         int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;  // fused path keeps face ids here; backward fallback list
-        unsigned* qcount = nullptr;                          // [3] list sizes of the sub-batch in flight
+        unsigned* qcount = nullptr;                          // [8] list sizes + redo counts of the sub-batch in flight
+        int32_t* redo = nullptr;                             // [cap] rays for k_trace_redo
         int32_t* slow_stack = nullptr;                       // traversal-stack overflow area of this stream's kernels
         int64_t q_cap = 0, fused_cap = 0;
     };
@@ -512,8 +516,9 @@ struct RayList {
 };
 struct Pipe {
     RayList r0, r1, r2;
-    unsigned* count;   // [0..2] list sizes of the sub-batch in flight
+    unsigned* count;   // [0..2] list sizes of the sub-batch in flight, [4..6] rays handed to k_trace_redo per stage
     unsigned* valid;   // number of valid rays of the whole call (shared by all sub-batches)
+    int32_t* redo;     // list entries whose traversal overflowed the LDS stack
 };
 
 // Block-wide ordered compaction: returns the list slot of this thread's item, or -1.
@@ -643,9 +648,11 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double
 // whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
 template <bool ANY>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
-                                                       int32_t* __restrict__ out_face, int refill_min, int inner_min, unsigned long long* stats) {
-    __shared__ int32_t lds[kStackFast][kPathBlock];
-    Stack st = make_stack256(lds, c);
+                                                       int32_t* __restrict__ out_face, int32_t* __restrict__ redo_list, unsigned* redo_count,
+                                                       int refill_min, int inner_min, unsigned long long* stats) {
+    __shared__ int32_t lds[kStackFast + 1][kPathBlock];     // + the dump slot of FastStack: 20 x 1 KB x 8 blocks = the CU's 160 KB
+    FastStack st;
+    st.fast = &lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast; st.sp = 0; st.overflow = false;
     const unsigned n = *n_ptr;
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * kPathWaves + (threadIdx.x >> 6), n_waves = gridDim.x * kPathWaves;
@@ -668,6 +675,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                 if (j < my_rays && k < n) {
                     const float* e = rays + 6 * (int64_t)k;
                     trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+                    st.overflow = false;
                     slot = (int32_t)k;
                 }
             }
@@ -685,9 +693,15 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             if (__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
             ++wave_steps;
             lane_steps += (unsigned long long)__popcll(mi);
-            if (at_inner && trav_inner(c.nodes, s, st)) {
-                out_face[slot] = s.best_face;
-                slot = -1;
+            if (at_inner) {
+                const bool done = trav_inner(c.nodes, s, st);
+                if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to k_trace_redo
+                    redo_list[atomicAdd(redo_count, 1u)] = slot;
+                    slot = -1;
+                } else if (done) {
+                    out_face[slot] = s.best_face;
+                    slot = -1;
+                }
             }
         }
         // leaf phase
@@ -707,6 +721,22 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         atomicAdd(stats + 1, lane_steps);
         atomicAdd(stats + 2, refills);
         atomicMax(stats + 3, wave_steps);
+    }
+}
+
+// Second pass for the rays whose traversal overflowed the LDS-only stack of k_trace: one thread per
+// ray, spilling stack.  Normally the list is empty and the kernel returns at once.
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_trace_redo(TraceCtx c, const float* __restrict__ rays, const int32_t* __restrict__ redo_list,
+                                                             const unsigned* __restrict__ redo_count, int32_t* __restrict__ out_face) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    const unsigned n = *redo_count;
+    if (n == 0) return;
+    Stack st = make_stack(lds, c);
+    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
+        const int32_t slot = redo_list[k];
+        const float* e = rays + 6 * (int64_t)slot;
+        out_face[slot] = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st).face;
     }
 }
 
@@ -1197,7 +1227,7 @@ int drt_create(int device, drt_scene_t** out) {
         drt_scene::Sub& w = s->sub[k];
         e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * 4);
+        if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * 8);
         if (e == hipSuccess) e = hipMalloc(&w.slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
     }
     if (e == hipSuccess) {
@@ -1234,7 +1264,7 @@ void drt_destroy(drt_scene_t* s) {
     for (int j = 0; j < drt_scene::kMaxSub; ++j) {
         drt_scene::Sub& w = s->sub[j];
         for (int k = 0; k < 3; ++k) { (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]); }
-        (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2); (void)hipFree(w.qcount); (void)hipFree(w.slow_stack);
+        (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2); (void)hipFree(w.qcount); (void)hipFree(w.slow_stack); (void)hipFree(w.redo);
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
@@ -1385,6 +1415,8 @@ static int ensure_queues(drt_scene::Sub& w, int64_t n, bool fused) {
             HIP_TRY(hipMalloc(&w.q_ray[k], sizeof(float) * 6 * n));
             HIP_TRY(hipMalloc(&w.q_face[k], sizeof(int32_t) * n));
         }
+        (void)hipFree(w.redo); w.redo = nullptr;
+        HIP_TRY(hipMalloc(&w.redo, sizeof(int32_t) * n));
         w.q_cap = n;
     }
     if (fused && n > w.fused_cap) {
@@ -1399,7 +1431,7 @@ static int ensure_queues(drt_scene::Sub& w, int64_t n, bool fused) {
 
 static Pipe pipe_of(const drt_scene* s, const drt_scene::Sub& w) {
     return Pipe{RayList{w.q_idx[0], w.q_ray[0], w.q_face[0]}, RayList{w.q_idx[1], w.q_ray[1], w.q_face[1]},
-                RayList{w.q_idx[2], w.q_ray[2], w.q_face[2]}, w.qcount, s->vcount};
+                RayList{w.q_idx[2], w.q_ray[2], w.q_face[2]}, w.qcount, s->vcount, w.redo};
 }
 
 // How a call of n_rays is cut: `size` rays per sub-batch (a multiple of `unit`), `count` sub-batches, dealt
@@ -1433,15 +1465,18 @@ static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const 
     { StageTimer t(s, st, kStageCull);
       k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
     { StageTimer t(s, st, kStageTrace1);
-      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr); }
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
+      k_trace_redo<false><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, p.r0.face); }
     { StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace2);
-      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr); }
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
+      k_trace_redo<false><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, p.r1.face); }
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);
-      k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
+      k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
+      k_trace_redo<true><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, p.r2.face); }
 }
 }  // extern "C++"
 
@@ -1489,7 +1524,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
-        HIP_TRY(hipMemsetAsync(w.qcount, 0, 3 * sizeof(unsigned), w.stream));
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
         launch_chunk<false>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
                             d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w);
         { StageTimer t(s, w.stream, kStageFinish);
@@ -1578,7 +1613,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
         const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
-        HIP_TRY(hipMemsetAsync(w.qcount, 0, 3 * sizeof(unsigned), w.stream));
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
         launch_chunk<true>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w);
         { StageTimer t(s, w.stream, kStageLossBwdFused);
           k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,

@@ -51,6 +51,29 @@ struct Stack {
 };
 constexpr int kStackSlow = 72;
 
+// Stack of the persistent GPU traversal: fast memory only, no overflow area and therefore no
+// divergent slow path (and no flat loads) in the hot loop.  A push beyond `depth` sets `overflow`;
+// the kernel then abandons that ray and a second pass re-traces it with the spilling Stack above.
+struct FastStack {
+    int32_t* fast;      // &fast_mem[lane], entry k at fast[k * stride]; depth + 1 entries allocated
+    int stride;
+    int depth;          // usable entries [0, depth); entry `depth` is a dump slot for stores beyond the top
+    int sp;
+    bool overflow;
+    DRT_HD void push_if(int32_t v, bool pred) {
+        const int k = sp < depth ? sp : depth;          // a store at a full stack must not clobber a live entry
+        fast[k * stride] = v;
+        overflow |= pred & (sp >= depth);
+        sp += pred ? 1 : 0;
+    }
+    DRT_HD int32_t pop() {
+        --sp;
+        const int k = sp < depth ? sp : depth;
+        return fast[k * stride];
+    }
+    DRT_HD bool empty() const { return sp == 0; }
+};
+
 // Reciprocal direction for the slab test only.  A zero (or denormal-small) component would
 // give inf and then inf - inf = NaN in the fma slab form, so it is replaced by +-2^-80: over
 // any t a ray can reach that moves it by far less than the box padding, so culling stays
@@ -79,8 +102,8 @@ DRT_HD void cswap(uint32_t& a, uint32_t& b) {
     a = lo; b = hi;
 }
 DRT_HD int32_t pick4(uint32_t key, int32_t c0, int32_t c1, int32_t c2, int32_t c3) {
-    const uint32_t k = key & 3u;
-    return k == 0u ? c0 : (k == 1u ? c1 : (k == 2u ? c2 : c3));
+    const int32_t lo = (key & 1u) ? c1 : c0, hi = (key & 1u) ? c3 : c2;   // two-level select, no branches
+    return (key & 2u) ? hi : lo;
 }
 DRT_HD uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
@@ -94,7 +117,8 @@ struct TravState {
     int32_t best_face;
 };
 
-DRT_HD void trav_init(TravState& s, Stack& st, f3 o, f3 d) {
+template <class STACK>
+DRT_HD void trav_init(TravState& s, STACK& st, f3 o, f3 d) {
     s.o = o; s.d = d;
     s.inv = f3{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
     s.oi = f3{-o.x * s.inv.x, -o.y * s.inv.y, -o.z * s.inv.z};
@@ -105,14 +129,16 @@ DRT_HD void trav_init(TravState& s, Stack& st, f3 o, f3 d) {
 }
 
 // Pop the next node; returns true when the stack is empty (ray finished).
-DRT_HD bool trav_pop(TravState& s, Stack& st) {
+template <class STACK>
+DRT_HD bool trav_pop(TravState& s, STACK& st) {
     if (st.empty()) return true;
     s.cur = st.pop();
     return false;
 }
 
 // Visit the inner node s.cur (>= 0).  Returns true when the ray is finished.
-DRT_HD bool trav_inner(const Node4* __restrict__ nodes, TravState& s, Stack& st) {
+template <class STACK>
+DRT_HD bool trav_inner(const Node4* __restrict__ nodes, TravState& s, STACK& st) {
     const F4* np = reinterpret_cast<const F4*>(nodes + s.cur);
     const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], chf = np[6];
     int32_t c0, c1, c2, c3;
@@ -144,8 +170,8 @@ DRT_HD bool trav_inner(const Node4* __restrict__ nodes, TravState& s, Stack& st)
 }
 
 // Test the triangles of the leaf s.cur (< 0).  Returns true when the ray is finished.
-template <bool ANY>
-DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, Stack& st) {
+template <bool ANY, class STACK>
+DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, STACK& st) {
     const int32_t ref = ~s.cur;
     const int first = ref >> kLeafBits, count = (ref & (kLeafMax - 1)) + 1;
     for (int j = 0; j < count; ++j) {
@@ -164,8 +190,8 @@ DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, Stack& st) 
 
 // One node visit, inner or leaf.  Returns true when the ray is finished (result in best_face /
 // best_t; for ANY the first hit found).
-template <bool ANY>
-DRT_HD bool trav_step(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, TravState& s, Stack& st) {
+template <bool ANY, class STACK>
+DRT_HD bool trav_step(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, TravState& s, STACK& st) {
     return s.cur >= 0 ? trav_inner(nodes, s, st) : trav_leaf<ANY>(tris, s, st);
 }
 

@@ -1,6 +1,8 @@
 """Parity of the gfx950 kernels (through the C ABI) with the CPU oracle and the golden
 vectors of the reference.  Face ids / masks / T bit-exact; float64 rays within 1e-9;
 gradients within 1e-5 absolute (north_star bar), in practice ~1e-12 relative."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -416,3 +418,21 @@ def test_optimize_loop_on_synthetic_capture(Render, hand):
     back = mesh_io.read_ply(out)
     assert back.is_watertight and len(back.faces) == len(hand.faces)
     np.testing.assert_allclose(back.vertices, scene.vertices.detach().cpu().numpy().astype(np.float32), rtol=0, atol=0)
+
+
+def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
+    """Build the library with a 3-entry LDS traversal stack so that (a) the spilling stack of the B1 / probe
+    kernels and (b) the overflow -> k_trace_redo hand-off of the pipeline are exercised on every other ray,
+    then repeat the golden and brute-force comparisons in a subprocess that loads that build."""
+    import subprocess
+    import sys
+    from drt_amd import build
+    so = str(tmp_path / "libdrt_hip_stack3.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc] + build.FLAGS + ["-DDRT_STACK_FAST=3", "-o", so, build.SRC])
+    env = dict(os.environ, DRT_HIP_LIB=so)
+    sel = "test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or test_silhouette_branch_vs_golden"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
