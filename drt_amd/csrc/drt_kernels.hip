@@ -70,7 +70,7 @@ struct drt_scene {
     int32_t* faces = nullptr;      // [F,3] copy
     float* verts = nullptr;        // [V,3] float32 copy (tracer precision)
     Node* nodes = nullptr;         // [max(F-1,1)] binary radix tree (build intermediate)
-    Node4* wide = nullptr;         // [max(F-1,1)] 4-wide tree read by the traversal, indexed by binary root
+    Node4Q* wide = nullptr;        // [max(F-1,1)] 4-wide tree (quantised, 64 B/node) read by the traversal, indexed by binary root
     int32_t *range_lo = nullptr, *range_hi = nullptr;   // sorted-slot range of each binary node
     TriRec* tris = nullptr;        // [F] Morton order
     uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
@@ -351,7 +351,7 @@ __global__ void k_refit(const uint32_t* __restrict__ sorted_idx, const int32_t* 
 // boundary = all boxes visible).
 __global__ void k_collapse4(const Node* __restrict__ nodes, const int32_t* __restrict__ parent_inner,
                             const int32_t* __restrict__ range_lo, const int32_t* __restrict__ range_hi, int n,
-                            Node4* __restrict__ wide) {
+                            Node4Q* __restrict__ wide) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int inner = n > 1 ? n - 1 : 1;
     if (i >= inner) return;
@@ -363,11 +363,11 @@ __global__ void k_collapse4(const Node* __restrict__ nodes, const int32_t* __res
     }
     Node4 out;
     collapse4(nodes, range_lo, range_hi, n, i, out);
-    wide[i] = out;
+    wide[i] = node4_quantize(out);
 }
 
 // Diagnostic for the wide tree: every leaf marks its triangle slots and checks its box.
-__global__ void k_wide_check(const Node4* __restrict__ wide, const int32_t* __restrict__ parent_inner,
+__global__ void k_wide_check(const Node4Q* __restrict__ wide, const int32_t* __restrict__ parent_inner,
                              const int32_t* __restrict__ range_lo, const int32_t* __restrict__ range_hi,
                              const TriRec* __restrict__ tris, int n, const BuildParams* __restrict__ bp,
                              uint32_t* seen, unsigned long long* violations) {
@@ -380,7 +380,7 @@ __global__ void k_wide_check(const Node4* __restrict__ wide, const int32_t* __re
         for (int32_t link = parent_inner[i]; link >= 0; link = parent_inner[link >> 1]) ++depth;
         if (depth & 1) return;
     }
-    const Node4 nd = wide[i];
+    const Node4Q nd = wide[i];
     unsigned long long bad = 0;
     for (int k = 0; k < 4; ++k) {
         const int32_t c = nd.child[k];
@@ -391,7 +391,7 @@ __global__ void k_wide_check(const Node4* __restrict__ wide, const int32_t* __re
             atomicAdd(&seen[j], 1u);
             const TriRec t = tris[j];
             const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, cc{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
-            if (!box_contains(node4_box(nd, k), box_of_tri(a, b, cc, 0.5f * bp->pad))) ++bad;
+            if (!box_contains(node4q_box(nd, k), box_of_tri(a, b, cc, 0.5f * bp->pad))) ++bad;
         }
     }
     if (bad) atomicAdd(violations, bad);
@@ -565,20 +565,17 @@ __device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
 // Conservative "can this ray touch the mesh at all": two levels of the wide tree (the root's
 // children, then the children of every inner child the ray enters).  k_cull is HBM-bound, so these
 // <= 20 slab tests are free, and every ray they reject is one the traversal stages never see.
-__device__ __forceinline__ unsigned hit_mask4(const Node4* __restrict__ node, f3 inv, f3 oi) {
+__device__ __forceinline__ unsigned hit_mask4(const Node4Q* __restrict__ node, f3 inv, f3 oi) {
     const F4* np = reinterpret_cast<const F4*>(node);
-    const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
     const int32_t* ch = node->child;
-    bool h0, h1, h2, h3;
-    slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, inv, oi, INFINITY, h0);
-    slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, inv, oi, INFINITY, h1);
-    slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, inv, oi, INFINITY, h2);
-    slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, inv, oi, INFINITY, h3);
-    return (unsigned)(h0 & (ch[0] != kEmptyChild)) | ((unsigned)(h1 & (ch[1] != kEmptyChild)) << 1) |
-           ((unsigned)(h2 & (ch[2] != kEmptyChild)) << 2) | ((unsigned)(h3 & (ch[3] != kEmptyChild)) << 3);
+    float t[4];
+    bool h[4];
+    slab_node4q(np[0], np[1], np[2], inv, oi, INFINITY, t, h);
+    return (unsigned)(h[0] & (ch[0] != kEmptyChild)) | ((unsigned)(h[1] & (ch[1] != kEmptyChild)) << 1) |
+           ((unsigned)(h[2] & (ch[2] != kEmptyChild)) << 2) | ((unsigned)(h[3] & (ch[3] != kEmptyChild)) << 3);
 }
 
-__device__ __forceinline__ bool hits_top_boxes(const Node4* __restrict__ nodes, f3 o, f3 d) {
+__device__ __forceinline__ bool hits_top_boxes(const Node4Q* __restrict__ nodes, f3 o, f3 d) {
     const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
     const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
     const unsigned m = hit_mask4(nodes, inv, oi);
@@ -1142,7 +1139,7 @@ static int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
     HIP_TRY(hipMalloc(&s->faces, sizeof(int32_t) * 3 * F));
     HIP_TRY(hipMalloc(&s->verts, sizeof(float) * 3 * V));
     HIP_TRY(hipMalloc(&s->nodes, sizeof(Node) * F));
-    HIP_TRY(hipMalloc(&s->wide, sizeof(Node4) * F));
+    HIP_TRY(hipMalloc(&s->wide, sizeof(Node4Q) * F));
     HIP_TRY(hipMalloc(&s->range_lo, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->range_hi, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->tris, sizeof(TriRec) * F));

@@ -170,6 +170,61 @@ DRT_HD void node4_set(Node4& o, int k, Box b, int32_t child) {
 }
 DRT_HD Box node4_box(const Node4& o, int k) { return Box{o.lox[k], o.loy[k], o.loz[k], o.hix[k], o.hiy[k], o.hiz[k]}; }
 
+// Stored form of a wide node: 64 bytes = four 16-byte loads instead of seven.  The traversal is bound
+// by the number of per-lane vector-memory requests (each lane walks its own node, so every 16-byte
+// load of a wave touches 64 different lines), not by ALU: child bounds are therefore quantised to
+// 8 bits on the grid (origin, scale) of the node's own box, rounded OUTWARDS, and decoded with spare
+// ALU (lo = origin + q * scale).  Boxes only steer the traversal; results are defined by drt_tri.h.
+struct alignas(16) Node4Q {
+    float ox, oy, oz, sx;                     // chunk 0: grid origin, x scale
+    float sy, sz;                             // chunk 1: y, z scale,
+    uint32_t qlox, qloy;                      //          byte k of each q word = child k
+    uint32_t qloz, qhix, qhiy, qhiz;          // chunk 2
+    int32_t child[4];                         // chunk 3: as Node4
+};
+
+DRT_HD float q_byte(uint32_t word, int k) { return (float)((word >> (8 * k)) & 255u); }
+DRT_HD Box node4q_box(const Node4Q& n, int k) {
+    return Box{fmaf(q_byte(n.qlox, k), n.sx, n.ox), fmaf(q_byte(n.qloy, k), n.sy, n.oy), fmaf(q_byte(n.qloz, k), n.sz, n.oz),
+               fmaf(q_byte(n.qhix, k), n.sx, n.ox), fmaf(q_byte(n.qhiy, k), n.sy, n.oy), fmaf(q_byte(n.qhiz, k), n.sz, n.oz)};
+}
+
+// One axis: grid (origin strictly below every child's lo, 253 steps up to the largest hi) and the
+// outward-rounded bytes of the four children.
+DRT_HD void quantize_axis(const float lo[4], const float hi[4], const bool valid[4], float& o, float& s, uint32_t& qlo, uint32_t& qhi) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < 4; ++k)
+        if (valid[k]) { mn = fminf(mn, lo[k]); mx = fmaxf(mx, hi[k]); }
+    if (!(mn <= mx)) { mn = 0.0f; mx = 0.0f; }
+    o = mn - (fabsf(mn) * 9.5367431640625e-7f + 1e-30f);
+    s = ((mx - o) / 253.0f) * 1.00000095367431640625f;
+    if (!(s > 0.0f)) s = 1e-30f;
+    qlo = 0; qhi = 0;
+    for (int k = 0; k < 4; ++k) {
+        int a = 0, b = 255;
+        if (valid[k]) {
+            a = (int)floorf((lo[k] - o) / s);
+            a = a < 0 ? 0 : (a > 255 ? 255 : a);
+            while (a > 0 && fmaf((float)a, s, o) > lo[k]) --a;
+            b = (int)ceilf((hi[k] - o) / s);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            while (b < 255 && fmaf((float)b, s, o) < hi[k]) ++b;
+        }
+        qlo |= (uint32_t)a << (8 * k);
+        qhi |= (uint32_t)b << (8 * k);
+    }
+}
+
+DRT_HD Node4Q node4_quantize(const Node4& f) {
+    Node4Q q;
+    bool valid[4];
+    for (int k = 0; k < 4; ++k) { valid[k] = f.child[k] != kEmptyChild; q.child[k] = f.child[k]; }
+    quantize_axis(f.lox, f.hix, valid, q.ox, q.sx, q.qlox, q.qhix);
+    quantize_axis(f.loy, f.hiy, valid, q.oy, q.sy, q.qloy, q.qhiy);
+    quantize_axis(f.loz, f.hiz, valid, q.oz, q.sz, q.qloz, q.qhiz);
+    return q;
+}
+
 // Wide node rooted at binary node i (which must be at even depth with more than kLeafMax
 // triangles below it, or be the root).  Wide nodes keep the index of their binary root.
 DRT_HD void collapse4(const Node* bin, const int32_t* range_lo, const int32_t* range_hi, int n_tris, int i, Node4& out) {

@@ -12,7 +12,7 @@
 namespace drt {
 
 struct TraceCtx {
-    const Node4* nodes;
+    const Node4Q* nodes;
     const TriRec* tris;
     int n_tris;
     int32_t* slow_stack;

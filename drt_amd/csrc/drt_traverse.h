@@ -136,27 +136,49 @@ DRT_HD bool trav_pop(TravState& s, STACK& st) {
     return false;
 }
 
+// Slab tests of the four children of a quantised node given its three bound chunks: entry distances
+// t[k] (>= 0) and hit flags against [0, best_t].  The decode lo = origin + q * scale is folded into the
+// slab: t = q * (scale * inv) + (origin * inv - o * inv).
+DRT_HD void slab_node4q(F4 c0, F4 c1, F4 c2, f3 inv, f3 oi, float best_t, float (&t)[4], bool (&h)[4]) {
+    const float ax = c0.w * inv.x, ay = c1.x * inv.y, az = c1.y * inv.z;
+    const float bx = fmaf(c0.x, inv.x, oi.x), by = fmaf(c0.y, inv.y, oi.y), bz = fmaf(c0.z, inv.z, oi.z);
+    const uint32_t qlox = f32_bits(c1.z), qloy = f32_bits(c1.w), qloz = f32_bits(c2.x);
+    const uint32_t qhix = f32_bits(c2.y), qhiy = f32_bits(c2.z), qhiz = f32_bits(c2.w);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+        float t0 = fmaf(q_byte(qlox, k), ax, bx), t1 = fmaf(q_byte(qhix, k), ax, bx);
+        float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
+        t0 = fmaf(q_byte(qloy, k), ay, by); t1 = fmaf(q_byte(qhiy, k), ay, by);
+        tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+        t0 = fmaf(q_byte(qloz, k), az, bz); t1 = fmaf(q_byte(qhiz, k), az, bz);
+        tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+        tmin = fmaxf(tmin, 0.0f);
+        t[k] = tmin;
+        h[k] = tmin <= fminf(tmax, best_t);
+    }
+}
+
 // Visit the inner node s.cur (>= 0).  Returns true when the ray is finished.
 template <class STACK>
-DRT_HD bool trav_inner(const Node4* __restrict__ nodes, TravState& s, STACK& st) {
+DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st) {
     const F4* np = reinterpret_cast<const F4*>(nodes + s.cur);
-    const F4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5], chf = np[6];
+    const F4 q0 = np[0], q1 = np[1], q2 = np[2], chf = np[3];
     int32_t c0, c1, c2, c3;
     memcpy(&c0, &chf.x, 4); memcpy(&c1, &chf.y, 4); memcpy(&c2, &chf.z, 4); memcpy(&c3, &chf.w, 4);
-    bool h0, h1, h2, h3;
-    const float t0 = slab4(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, s.inv, s.oi, s.best_t, h0);
-    const float t1 = slab4(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, s.inv, s.oi, s.best_t, h1);
-    const float t2 = slab4(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, s.inv, s.oi, s.best_t, h2);
-    const float t3 = slab4(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, s.inv, s.oi, s.best_t, h3);
-    h0 &= c0 != kEmptyChild; h1 &= c1 != kEmptyChild; h2 &= c2 != kEmptyChild; h3 &= c3 != kEmptyChild;
+    float t[4];
+    bool h[4];
+    slab_node4q(q0, q1, q2, s.inv, s.oi, s.best_t, t, h);
+    const bool h0 = h[0] & (c0 != kEmptyChild), h1 = h[1] & (c1 != kEmptyChild), h2 = h[2] & (c2 != kEmptyChild), h3 = h[3] & (c3 != kEmptyChild);
     // Entry distances are >= 0, so their bit patterns order like unsigned integers; the two low
     // mantissa bits are replaced by the child slot (ordering only -- culling used the exact value);
     // misses get the largest key.  Five compare-exchanges sort the four keys, all selects.
     const uint32_t kMiss = 0xFFFFFFFCu;
-    uint32_t k0 = (h0 ? (f32_bits(t0) & ~3u) : kMiss) | 0u;
-    uint32_t k1 = (h1 ? (f32_bits(t1) & ~3u) : kMiss) | 1u;
-    uint32_t k2 = (h2 ? (f32_bits(t2) & ~3u) : kMiss) | 2u;
-    uint32_t k3 = (h3 ? (f32_bits(t3) & ~3u) : kMiss) | 3u;
+    uint32_t k0 = (h0 ? (f32_bits(t[0]) & ~3u) : kMiss) | 0u;
+    uint32_t k1 = (h1 ? (f32_bits(t[1]) & ~3u) : kMiss) | 1u;
+    uint32_t k2 = (h2 ? (f32_bits(t[2]) & ~3u) : kMiss) | 2u;
+    uint32_t k3 = (h3 ? (f32_bits(t[3]) & ~3u) : kMiss) | 3u;
     cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
     if (k0 < kMiss) {
         // visit the nearest, push the others far-first (dead stores for misses: they sort last)
@@ -191,12 +213,12 @@ DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, STACK& st) 
 // One node visit, inner or leaf.  Returns true when the ray is finished (result in best_face /
 // best_t; for ANY the first hit found).
 template <bool ANY, class STACK>
-DRT_HD bool trav_step(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, TravState& s, STACK& st) {
+DRT_HD bool trav_step(const Node4Q* __restrict__ nodes, const TriRec* __restrict__ tris, TravState& s, STACK& st) {
     return s.cur >= 0 ? trav_inner(nodes, s, st) : trav_leaf<ANY>(tris, s, st);
 }
 
 template <bool ANY>
-DRT_HD Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris, int n_tris,
+DRT_HD Hit traverse(const Node4Q* __restrict__ nodes, const TriRec* __restrict__ tris, int n_tris,
                     f3 o, f3 d, Stack& st, uint32_t* visits = nullptr) {
     if (n_tris <= 0) return Hit{-1.0f, -1};
     TravState s;

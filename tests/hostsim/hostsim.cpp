@@ -20,7 +20,7 @@ struct HsScene {
     std::vector<int32_t> faces;
     std::vector<float> verts;
     std::vector<Node> nodes;       // binary radix tree (build intermediate)
-    std::vector<Node4> wide;       // what the traversal reads
+    std::vector<Node4Q> wide;      // what the traversal reads (quantised)
     std::vector<int32_t> range_lo, range_hi;
     std::vector<TriRec> tris;
     std::vector<int32_t> parent_inner, parent_leaf;
@@ -57,7 +57,7 @@ static void build(HsScene& s) {
     s.parent_leaf.assign(n, -1);
     s.range_lo.assign(inner, 0);
     s.range_hi.assign(inner, n - 1);
-    s.wide.assign(inner, Node4{});
+    s.wide.assign(inner, Node4Q{});
     s.tris.resize(n);
     if (n == 0) return;
     if (n == 1) {
@@ -98,7 +98,7 @@ static void build(HsScene& s) {
         int depth = 0;
         for (int32_t link = s.parent_inner[i]; link >= 0; link = s.parent_inner[link >> 1]) ++depth;
         const bool wide_root = i == 0 || ((depth & 1) == 0 && s.range_hi[i] - s.range_lo[i] + 1 > kLeafMax);
-        if (wide_root) collapse4(s.nodes.data(), s.range_lo.data(), s.range_hi.data(), n, i, s.wide[i]);
+        if (wide_root) { Node4 full; collapse4(s.nodes.data(), s.range_lo.data(), s.range_hi.data(), n, i, full); s.wide[i] = node4_quantize(full); }
     }
 }
 
@@ -154,7 +154,7 @@ int64_t hs_check(void* h) {
     std::vector<int32_t> todo;
     if (n > 0) todo.push_back(0);
     while (!todo.empty()) {
-        const Node4& nd = s->wide[todo.back()];
+        const Node4Q& nd = s->wide[todo.back()];
         todo.pop_back();
         for (int k = 0; k < 4; ++k) {
             const int32_t c = nd.child[k];
@@ -166,7 +166,7 @@ int64_t hs_check(void* h) {
                 ++seen[j];
                 const TriRec& t = s->tris[j];
                 const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, c2{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
-                if (!box_contains(node4_box(nd, k), box_of_tri(a, b, c2, 0.5f * s->pad))) ++bad;
+                if (!box_contains(node4q_box(nd, k), box_of_tri(a, b, c2, 0.5f * s->pad))) ++bad;
             }
         }
     }
