@@ -1121,6 +1121,79 @@ __global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restric
     add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
 }
 
+// ---- fused silhouette loss: Loss_calculator.vh_loss (reference optim.py:73-78) with no host round trip:
+// the drop-in methods return dynamically sized tensors (two device->host syncs per view); here the
+// silhouette edges of up to kVhViews views are compacted on the device into ONE list and one kernel does
+// projection, probe rays, the loss term |soft_mask[y, x] - 0.5| and its vertex gradient.  Views are
+// batched because a view has only a few thousand silhouette edges and its probe rays graze the surface:
+// a per-view launch is bound by the latency of its longest traversal, not by throughput.
+constexpr int kVhViews = 16;
+struct VhViews {
+    const double* cam[kVhViews];
+    const double* origin[kVhViews];
+    const double* soft[kVhViews];
+};
+
+__global__ void __launch_bounds__(kPathBlock) k_vh_cull(const double* __restrict__ verts, const int64_t* __restrict__ e2f, int64_t n_edges,
+                                                         int n_views, VhViews vw, uint32_t* __restrict__ list, unsigned* count) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    const int64_t n = n_edges * n_views;
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        const int64_t k = base + threadIdx.x;
+        bool sil = false;
+        if (k < n) {
+            const int64_t e = k % n_edges;
+            const double* o3 = vw.origin[k / n_edges];
+            d3 a0, b0, v1, v2;
+            FaceNormal a, b;
+            load_face64(verts, e2f + 6 * e, a0, v1, v2); face_normal(a0, v1, v2, a);
+            load_face64(verts, e2f + 6 * e + 3, b0, v1, v2); face_normal(b0, v1, v2, b);
+            sil = silhouette_flag(a, a0, b, b0, d3{o3[0], o3[1], o3[2]});
+        }
+        const int slot = block_push(sil, count, s_tmp);
+        if (slot >= 0) list[slot] = (uint32_t)k;
+    }
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const double* __restrict__ verts, const int64_t* __restrict__ edges,
+                                                           uint32_t n_edges, const uint32_t* __restrict__ list, const unsigned* __restrict__ count,
+                                                           VhViews vw, int resx, int resy, int detach_depth, double* loss, double* grad_verts) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    const unsigned n = *count;
+    double acc = 0.0;
+    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
+        const uint32_t item = list[k], view = item / n_edges;
+        const int64_t e = item - view * n_edges;
+        const Camera cm = *reinterpret_cast<const Camera*>(vw.cam[view]);
+        const double* o3 = vw.origin[view];
+        const d3 o{o3[0], o3[1], o3[2]};
+        const int64_t ia = edges[2 * e], ib = edges[2 * e + 1];
+        Projected pa, pb;
+        project_endpoint(cm, load_d3(verts, ia), pa);
+        project_endpoint(cm, load_d3(verts, ib), pb);
+        EdgeSample s;
+        edge_sample(cm, pa, pb, o, s);
+        const bool hu = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_up), st).face >= 0;
+        const bool hl = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_lo), st).face >= 0;
+        const double f = (hu ? 1.0 : 0.0) - (hl ? 1.0 : 0.0);
+        if (f == 0.0) continue;                                   // |f| > 1e-5 (DiffRender.py:244)
+        const int64_t x = (int64_t)s.midx, y = (int64_t)s.midy;   // trunc, like Tensor.to(torch.long)
+        if (!(x < resx - 1 && y < resy - 1 && x >= 0 && y >= 0)) continue;   // out of view (DiffRender.py:478)
+        const double m = vw.soft[view][y * resx + x] - 0.5;       // output is float32 0.5: exact
+        acc += fabs(m);
+        const double coef = m > 0.0 ? -1.0 : (m < 0.0 ? 1.0 : 0.0);   // d |mask - output| / d output
+        const double w = f * coef;
+        if (w == 0.0) continue;
+        const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
+        const AtomicAdd3 add{grad_verts};
+        add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
+        add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1723,6 +1796,33 @@ int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int6
     if (!d_verts || !d_edges || !d_camera || !d_f || !d_coef || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     k_edge_sample_bwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_coef, detach_depth, d_grad_verts);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, const int64_t* d_e2f, int64_t n_edges,
+                      int n_views, const double* const* d_cameras, const double* const* d_origins, const double* const* d_soft_masks,
+                      int resx, int resy, int detach_depth, double* d_loss, double* d_grad_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_edges < 0 || n_views < 0 || resx <= 0 || resy <= 0 || n_edges * kVhViews > (int64_t)UINT32_MAX) return fail(DRT_E_INVALID, "bad size argument");
+    if (n_edges == 0 || n_views == 0) return DRT_OK;
+    if (!d_verts || !d_edges || !d_e2f || !d_cameras || !d_origins || !d_soft_masks || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    drt_scene::Sub& w = s->sub[0];      // list workspace; safe: every pipeline call joins its internal streams before returning
+    for (int v0 = 0; v0 < n_views; v0 += kVhViews) {
+        const int nv = std::min(kVhViews, n_views - v0);
+        VhViews vw{};
+        for (int k = 0; k < nv; ++k) {
+            if (!d_cameras[v0 + k] || !d_origins[v0 + k] || !d_soft_masks[v0 + k]) return fail(DRT_E_INVALID, "null pointer argument");
+            vw.cam[k] = d_cameras[v0 + k]; vw.origin[k] = d_origins[v0 + k]; vw.soft[k] = d_soft_masks[v0 + k];
+        }
+        int rc = ensure_queues(w, n_edges * nv, false);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(s->vcount + 1, 0, sizeof(unsigned), st));
+        k_vh_cull<<<grid_for(n_edges * nv, kPathBlock, 4 * s->n_cu), kPathBlock, 0, st>>>(d_verts, d_e2f, n_edges, nv, vw, reinterpret_cast<uint32_t*>(w.q_idx[0]), s->vcount + 1);
+        k_vh_fused<<<4 * s->n_cu, kTraceBlock, 0, st>>>(trace_ctx(s), d_verts, d_edges, (uint32_t)n_edges, reinterpret_cast<const uint32_t*>(w.q_idx[0]), s->vcount + 1,
+                                                        vw, resx, resy, detach_depth, d_loss, d_grad_verts);
+    }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -20,6 +20,7 @@ PyTorch only owns the tensors and the autograd plumbing.  Gradients reach
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -266,16 +267,40 @@ class Scene:
 
     def primary_visibility(self, silhouette_edge, camera_M, origin, detach_depth=False):
         """(index int64 [M,2] (x, y), output float32 [M]) of the in-view silhouette samples (DiffRender.py:459-479)."""
-        index, output = _EdgeSample.apply(self.vertices, silhouette_edge, camera_M, origin, self, bool(detach_depth))
-        keep = (index[:, 0] < resx - 1) * (index[:, 1] < resy - 1) * (index[:, 0] >= 0) * (index[:, 1] >= 0)
-        return index[keep], output[keep]
+        return _EdgeSample.apply(self.vertices, silhouette_edge, camera_M, origin, self, bool(detach_depth), int(resx), int(resy))
 
+    def vh_loss_fused(self, camera_M, origin, soft_mask):
+        """sum |soft_mask[y, x] - 0.5| over the visible silhouette samples of one view and its vertex gradient
+        (one view of reference optim.py:73-78) without any host round trip."""
+        return self.vh_loss_fused_views([(camera_M, origin, soft_mask)])
+
+    def vh_loss_fused_views(self, views):
+        """The same summed over ``views`` = [(camera_M, origin[3], soft_mask), ...] (the whole of optim.py:73-78):
+        one autograd node, three kernels per view."""
+        flat = []
+        for camera_M, origin, soft_mask in views:
+            flat += [pack_camera(camera_M), origin, soft_mask]
+        return _VhLossFused.apply(self.vertices, self, int(resx), int(resy), *flat)
+
+
+
+_camera_cache = {}
 
 
 def pack_camera(camera_M):
-    """camera_M = (R 4x4, K 3x3, R^-1, K^-1) -> one float64 [50] device tensor (layout of drt_edge.h Camera)."""
+    """camera_M = (R 4x4, K 3x3, R^-1, K^-1) -> one float64 [50] device tensor (layout of drt_edge.h Camera).
+    Cached per camera tuple (keyed on the identity and in-place version of its four tensors): a capture's
+    cameras are constants and the silhouette loss packs eight of them per iteration."""
+    key = tuple(id(t) for t in camera_M)
+    ent = _camera_cache.get(key)
+    if ent is not None and all(r() is t and ver == t._version for r, ver, t in zip(ent[0], ent[1], camera_M)):
+        return ent[2]
     R, K, R_inverse, K_inverse = camera_M
-    return torch.cat([R.reshape(-1), K.reshape(-1), R_inverse.reshape(-1), K_inverse.reshape(-1)]).to(torch.float64).contiguous()
+    packed = torch.cat([R.reshape(-1), K.reshape(-1), R_inverse.reshape(-1), K_inverse.reshape(-1)]).to(torch.float64).contiguous()
+    if len(_camera_cache) > 4096:
+        _camera_cache.clear()
+    _camera_cache[key] = (tuple(weakref.ref(t) for t in camera_M), tuple(t._version for t in camera_M), packed)
+    return packed
 
 
 class _Dihedral(torch.autograd.Function):
@@ -324,7 +349,7 @@ class _EdgeSample(torch.autograd.Function):
     as one function of the vertices."""
 
     @staticmethod
-    def forward(ctx, vertices, sil_edges, camera_M, origin, scene, detach_depth):
+    def forward(ctx, vertices, sil_edges, camera_M, origin, scene, detach_depth, res_x, res_y):
         v = _f64c(vertices.detach(), "vertices")
         edges = sil_edges.contiguous()
         assert edges.dtype == torch.long and edges.dim() == 2 and edges.shape[1] == 2
@@ -336,7 +361,8 @@ class _EdgeSample(torch.autograd.Function):
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), n, cam.data_ptr(),
                                                           o.data_ptr(), index.data_ptr(), f.data_ptr(), _stream()))
-        valid_edge = f.abs() > 1e-5
+        # |f| > 1e-5 (DiffRender.py:244) and inside the view (DiffRender.py:478) in ONE boolean index: one host sync
+        valid_edge = (f.abs() > 1e-5) & (index[:, 0] < res_x - 1) & (index[:, 1] < res_y - 1) & (index[:, 0] >= 0) & (index[:, 1] >= 0)
         index = index[valid_edge]
         output = 0.5 * torch.ones(len(index), device=v.device)       # float32, like the reference (DiffRender.py:251)
         ctx.mark_non_differentiable(index)
@@ -353,4 +379,33 @@ class _EdgeSample(torch.autograd.Function):
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().drt_edge_sample_backward(v.data_ptr(), edges.data_ptr(), edges.shape[0], cam.data_ptr(), f.data_ptr(),
                                                            coef.data_ptr(), int(ctx.detach_depth), grad_v.data_ptr(), _stream()))
-        return grad_v, None, None, None, None, None
+        return grad_v, None, None, None, None, None, None, None
+
+
+class _VhLossFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices, scene, res_x, res_y, *flat):
+        v = _f64c(vertices.detach(), "vertices")
+        loss = torch.zeros((), dtype=torch.float64, device=v.device)
+        grad_v = torch.zeros_like(v)
+        n = len(flat) // 3
+        cams, orgs, softs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        keep = []
+        for k in range(n):
+            o = _f64c(flat[3 * k + 1].detach(), "origin")
+            sm = _f64c(flat[3 * k + 2], "soft_mask")
+            assert sm.numel() == res_x * res_y and o.numel() == 3 and flat[3 * k].numel() == 50
+            keep += [o, sm]
+            cams[k], orgs[k], softs[k] = flat[3 * k].data_ptr(), o.data_ptr(), sm.data_ptr()
+        edges, e2f = scene.Edges, scene.E2F
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().drt_vh_loss_fused(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), e2f.data_ptr(), e2f.shape[0], n,
+                                                    cams, orgs, softs, res_x, res_y, 1, loss.data_ptr(), grad_v.data_ptr(), _stream()))
+        ctx.save_for_backward(grad_v)
+        ctx.n_in = len(flat)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad_v,) = ctx.saved_tensors
+        return (grad_v * g_loss, None, None, None) + (None,) * ctx.n_in

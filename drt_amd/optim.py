@@ -78,7 +78,8 @@ def loss_weights(hp, resy, mean_len):
 class Loss_calculator:
     """Same role and method names as the reference class (optim.py:59-130); every term is evaluated by
     the HIP kernels behind ``drt_amd.diffrender``.  ``fused=True`` uses the one-pass kernels
-    (``Scene.ray_loss_fused`` / ``Scene.sm_loss_fused``) -- same values, no dense intermediates."""
+    (``Scene.ray_loss_fused`` / ``Scene.vh_loss_fused`` / ``Scene.sm_loss_fused``) -- same values, no dense
+    intermediates and no host synchronisation."""
 
     N_SILHOUETTE_VIEWS = 8          # the reference loops over np.arange(0, 72, 9)
 
@@ -97,6 +98,12 @@ class Loss_calculator:
         return (image[pix[:, 1], pix[:, 0]] - out).abs().sum()
 
     def vh_loss(self):
+        if self.fused:
+            views = []
+            for _ in range(self.N_SILHOUETTE_VIEWS):
+                _, _, soft_mask, origin, _, camera_M = self.data.get_view(next(self.silh_view))
+                views.append((camera_M, origin[0], soft_mask))
+            return self.scene.vh_loss_fused_views(views)
         terms = [self._silhouette_term(next(self.silh_view)) for _ in range(self.N_SILHOUETTE_VIEWS)]
         return torch.stack(terms).sum()
 

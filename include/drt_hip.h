@@ -156,6 +156,18 @@ int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int6
                              const double* d_camera, const float* d_f, const double* d_coef,
                              int detach_depth, double* d_grad_verts, void* stream);
 
+/* drt_vh_loss_fused <- Loss_calculator.vh_loss (optim.py:73-78) for n_views views: silhouette_edge +
+ * primary_visibility + sum |soft_mask[y, x] - output| and its vertex gradient, entirely on the device
+ * (the drop-in methods above return dynamically sized tensors and cost two host syncs per view; here the
+ * views are traced together, 16 per launch).  d_edges int64 [E,2] = Scene.Edges, d_e2f int64 [E,2,3] =
+ * Scene.E2F (same edge order).  d_cameras / d_origins / d_soft_masks are HOST arrays of n_views DEVICE
+ * pointers: camera float64 [50], origin float64 [3], soft mask float64 [resy*resx].
+ * *d_loss += loss, d_grad_verts [V,3] += gradient (zero them first). */
+int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, const int64_t* d_e2f,
+                      int64_t n_edges, int n_views, const double* const* d_cameras,
+                      const double* const* d_origins, const double* const* d_soft_masks, int resx, int resy,
+                      int detach_depth, double* d_loss, double* d_grad_verts, void* stream);
+
 /* ---- measurement (bench.py's live per-kernel timing) --------------------------------------------
  * When enabled (on = 1; on = 2 additionally collects the traversal statistics below, which perturbs
  * timing) every kernel of the build / forward / backward / fused pipelines is bracketed by a

@@ -289,6 +289,13 @@ def test_silhouette_branch_vs_golden(Render, hand, name):
     ref = g["grad_vh"]
     assert np.abs(g_vh.cpu().numpy() - ref).max() <= 1e-5
     np.testing.assert_allclose(g_vh.cpu().numpy(), ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+    # fused one-kernel form of the same loss and gradient (no host sync)
+    V3 = V.detach().clone().requires_grad_(True)
+    scene.update_verticex(V3)
+    vhf = scene.vh_loss_fused(cam, origin3, soft)
+    assert vhf.item() == pytest.approx(float(g["vh_loss"]), rel=1e-12)
+    (0.5 * vhf).backward()
+    np.testing.assert_allclose(V3.grad.cpu().numpy(), 0.5 * ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
     # render_mask == primary hit flags of the fixture
     rm = scene.render_mask(o.cuda(), d.cuda())
     assert np.array_equal(np.flatnonzero(rm.cpu().numpy() > 0), g["b1_ind"])
