@@ -42,6 +42,7 @@ SIGNATURES = {
     "drt_silhouette_flags": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
     "drt_edge_sample_forward": (_c.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "drt_edge_sample_backward": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _c.c_int, _P, _P]),
+    "drt_closest_point": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "drt_vh_loss_fused": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "drt_profile_enable": (_c.c_int, [_P, _c.c_int]),
     "drt_profile_read": (_c.c_int, [_P, _P, _P, _P]),

@@ -13,6 +13,7 @@
 
 #include "../../include/drt_hip.h"
 #include "drt_common.h"
+#include "drt_closest.h"
 #include "drt_edge.h"
 #include "drt_lbvh.h"
 #include "drt_path.h"
@@ -1121,6 +1122,20 @@ __global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restric
     add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
 }
 
+// ---- closest point on the mesh (the reference's acceptance metric, README.md:11: vertex-to-surface distance)
+__global__ void __launch_bounds__(kTraceBlock) k_closest_point(TraceCtx c, const int32_t* __restrict__ faces, const float* __restrict__ verts,
+                                                                const double* __restrict__ points, int64_t n, double* __restrict__ dist,
+                                                                int32_t* __restrict__ face, double* __restrict__ closest) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        const Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(points, i), st);
+        dist[i] = sqrt(r.dist2);
+        if (face) face[i] = r.face;
+        if (closest) store_d3(closest, i, r.point);
+    }
+}
+
 // ---- fused silhouette loss: Loss_calculator.vh_loss (reference optim.py:73-78) with no host round trip:
 // the drop-in methods return dynamically sized tensors (two device->host syncs per view); here the
 // silhouette edges of up to kVhViews views are compacted on the device into ONE list and one kernel does
@@ -1796,6 +1811,16 @@ int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int6
     if (!d_verts || !d_edges || !d_camera || !d_f || !d_coef || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     k_edge_sample_bwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_coef, detach_depth, d_grad_verts);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double* d_dist, int32_t* d_face, double* d_closest, void* stream) {
+    CHECK_BUILT(s);
+    if (n < 0) return fail(DRT_E_INVALID, "negative point count");
+    if (n == 0) return DRT_OK;
+    if (!d_points || !d_dist) return fail(DRT_E_INVALID, "null pointer argument");
+    k_closest_point<<<grid_for(n, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), s->faces, s->verts, d_points, n, d_dist, d_face, d_closest);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -6,8 +6,8 @@ reference's optim.py, on the HIP-backed ``drt_amd.diffrender``.
 
 Differences from the reference, all outside the per-view math:
   * the capture comes from any object with the reference's ``Data`` interface (``get_view``,
-    ``ray_view_generator``, ``silh_view_generator``, ``resx``, ``resy``) -- ``SyntheticData``
-    below stands in for the HDF5 captures, which are not distributed (captured_data.py:84-165);
+    ``ray_view_generator``, ``silh_view_generator``, ``resx``, ``resy``): drt_amd.captured_data has the
+    reference's capture classes and ``SyntheticData``, which stands in for the HDF5 captures (not distributed);
   * the MeshLab remesh between passes (optim.py:12-52, an external GUI tool) is a pluggable
     ``remesh`` callable, default: keep the topology;
   * multi-GPU: ``full_batch_step`` shards views over ranks and all-reduces the vertex gradient
@@ -23,6 +23,7 @@ import torch
 from . import diffrender as Render
 from . import dist as ddist
 from . import mesh_io, views
+from .captured_data import Data, Data_Pointgray, Data_Redmi, SyntheticData, get_data  # noqa: F401  (reference optim.py:7, 132-143)
 
 Float = torch.float64
 
@@ -31,43 +32,6 @@ HyperParams = {          # reference config.py:18-39
     "ray_w": 40, "sm_w": 0.08, "vh_w": 2e-3,
     "momentum": 0.95, "start_lr": 0.1, "lr_decay": 0.5, "start_len": 10, "end_len": 1, "num_view": 72,
 }
-
-
-class SyntheticData:
-    """72 turntable views of a ground-truth mesh with the tuple layout of Data.get_view
-    (reference captured_data.py:44-59); everything stays resident on the GPU."""
-
-    def __init__(self, scene_gt, center, extent, resx, resy, num_view=72, device="cuda", n_total=72, view_ids=None, seed=0):
-        self.resx, self.resy, self.num_view, self.n_total = resx, resy, num_view, n_total
-        self.rng = np.random.default_rng(seed)
-
-        def render_gt(o, d):
-            with torch.no_grad():
-                return scene_gt.render_transparent(o, d)
-
-        def hit_gt(o, d):
-            return scene_gt.render_mask(o, d) > 0
-
-        ids = list(range(n_total)) if view_ids is None else list(view_ids)
-        vs = views.make_views(render_gt, hit_gt, center, extent, n_total, resx, resy, device=device, view_ids=ids)
-        self.Views = dict(zip(ids, vs))
-
-    def get_view(self, V_index):
-        return self.Views[V_index]
-
-    def ray_view_generator(self):
-        index = list(np.arange(0, self.n_total, self.n_total // self.num_view))
-        while True:
-            self.rng.shuffle(index)
-            for i in index:
-                yield int(i) % self.n_total
-
-    def silh_view_generator(self):
-        index = list(np.arange(self.n_total))
-        while True:
-            self.rng.shuffle(index)
-            for i in index:
-                yield int(i) % self.n_total
 
 
 def loss_weights(hp, resy, mean_len):

@@ -124,6 +124,20 @@ class optix_mesh:
             _lib.check(_lib.lib().drt_intersect_bruteforce(self._h, Ray.data_ptr(), n, T.data_ptr(), ID.data_ptr(), _stream()))
         return [T, ID]
 
+    def closest_point(self, points, want_face=True, want_point=False):
+        """Distance from each point (float64 [N,3]) to the surface: dist float64 [N] (+ face int32 [N], closest float64 [N,3])."""
+        assert self.builded, "update_mesh must be called first"
+        points = _require(points, torch.float64, 3, "points")
+        self._check_device(points, "points")
+        n = points.size(0)
+        dist = torch.empty(n, dtype=torch.float64, device=points.device)
+        face = torch.empty(n, dtype=torch.int32, device=points.device) if want_face else None
+        closest = torch.empty(n, 3, dtype=torch.float64, device=points.device) if want_point else None
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_closest_point(self._h, points.data_ptr(), n, dist.data_ptr(), face.data_ptr() if want_face else None,
+                                                    closest.data_ptr() if want_point else None, _stream()))
+        return dist, face, closest
+
     def check(self):
         """(number of BVH containment/link violations, tree height); synchronises."""
         v = ctypes.c_int64()

@@ -168,6 +168,14 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
                       const double* const* d_origins, const double* const* d_soft_masks, int resx, int resy,
                       int detach_depth, double* d_loss, double* d_grad_verts, void* stream);
 
+/* drt_closest_point <- the reference's acceptance metric, "average per-vertex distance (Hausdorff
+ * Distance)" against the scanned mesh, which it delegates to meshlabserver (README.md:11; no code in the
+ * repository): for each query point the distance to the closest point of the scene's surface, on the same
+ * LBVH.  d_points float64 [n,3] -> d_dist float64 [n]; optional (nullable) d_face int32 [n] (a face
+ * attaining the minimum) and d_closest float64 [n,3].  float64 arithmetic on the tracer's float32 vertices. */
+int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double* d_dist, int32_t* d_face,
+                      double* d_closest, void* stream);
+
 /* ---- measurement (bench.py's live per-kernel timing) --------------------------------------------
  * When enabled (on = 1; on = 2 additionally collects the traversal statistics below, which perturbs
  * timing) every kernel of the build / forward / backward / fused pipelines is bracketed by a

@@ -318,3 +318,46 @@ def sgd_nesterov_step(param, grad, buf, lr, momentum):
     """torch.optim.SGD(nesterov=True, dampening=0, weight_decay=0) update; buf None on the first step."""
     buf = grad.clone() if buf is None else momentum * buf + grad
     return param - lr * (grad + momentum * buf), buf
+
+
+# --------------------------------------------------------------------------- acceptance metric (SURVEY.md 8f row 2)
+def point_mesh_distance(points, verts, faces, chunk=256):
+    """Brute-force distance from each point to a triangle mesh: min over faces of
+    min(distance to the plane projection when it falls inside the triangle, distance to the three edge
+    segments).  Deliberately NOT the Voronoi-region routine of drt_closest.h: an independent formulation
+    of the same definition.  The reference has no code for this metric (it shells out to meshlabserver,
+    README.md:11), so this row is pinned by the definition only: parity unpinned.
+    Returns (dist [N], face [N])."""
+    P = np.asarray(points, dtype=np.float64)
+    V = np.asarray(verts, dtype=np.float64)
+    F = np.asarray(faces)
+    a, b, c = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
+    n = np.cross(b - a, c - a)
+    nn = (n * n).sum(1)
+
+    def seg_d2(p, s0, s1):
+        e = s1 - s0
+        ee = (e * e).sum(1)
+        t = ((p[:, None, :] - s0[None]) * e[None]).sum(2) / np.where(ee > 0, ee, 1.0)[None]
+        t = np.clip(t, 0.0, 1.0)
+        q = s0[None] + t[..., None] * e[None]
+        r = p[:, None, :] - q
+        return (r * r).sum(2)
+
+    dist = np.empty(len(P))
+    face = np.empty(len(P), dtype=np.int64)
+    for s in range(0, len(P), chunk):
+        p = P[s:s + chunk]
+        d2 = np.minimum(np.minimum(seg_d2(p, a, b), seg_d2(p, b, c)), seg_d2(p, c, a))
+        ap = p[:, None, :] - a[None]
+        h = (ap * n[None]).sum(2)                                  # signed height * |n|
+        with np.errstate(divide="ignore", invalid="ignore"):
+            proj = p[:, None, :] - (h / nn[None])[..., None] * n[None]
+            inside = np.ones(h.shape, dtype=bool)
+            for s0, s1 in ((a, b), (b, c), (c, a)):
+                inside &= (np.cross((s1 - s0)[None], proj - s0[None]) * n[None]).sum(2) >= 0
+            plane_d2 = h * h / nn[None]
+        d2 = np.where(inside & (nn[None] > 0), np.minimum(d2, plane_d2), d2)
+        face[s:s + chunk] = d2.argmin(1)
+        dist[s:s + chunk] = np.sqrt(d2.min(1))
+    return dist, face

@@ -10,6 +10,7 @@
 #include <numeric>
 #include <vector>
 
+#include "../../drt_amd/csrc/drt_closest.h"
 #include "../../drt_amd/csrc/drt_edge.h"
 #include "../../drt_amd/csrc/drt_lbvh.h"
 #include "../../drt_amd/csrc/drt_path.h"
@@ -185,6 +186,17 @@ void hs_intersect(void* h, const float* rays, int64_t n, float* T, int32_t* ID, 
         T[i] = r.t;
         ID[i] = r.face;
         if (visits) visits[i] = v;
+    }
+}
+
+void hs_closest_point(void* h, const double* points, int64_t n, double* dist, int32_t* face, double* closest) {
+    HsScene* s = (HsScene*)h;
+    HostStack hs;
+    for (int64_t i = 0; i < n; ++i) {
+        const Closest r = closest_point(s->wide.data(), s->tris.data(), (int)s->tris.size(), s->faces.data(), s->verts.data(), load_d3(points, i), hs.st);
+        dist[i] = sqrt(r.dist2);
+        face[i] = r.face;
+        store_d3(closest, i, r.point);
     }
 }
 

@@ -443,3 +443,53 @@ def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_closest_point_and_hausdorff(Render, hand, horse50k):
+    """drt_closest_point: oracle brute force on the hand; size-independent properties on the 50k mesh;
+    the acceptance metric of drt_amd.metrics on a displaced copy."""
+    from drt_amd import metrics
+    rng = np.random.default_rng(5)
+    t = _tracer(hand)
+    V32 = hand.vertices.astype(np.float32)
+    lo, hi = V32.min(0), V32.max(0)
+    pts = np.concatenate([rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), size=(1500, 3)),
+                          V32[rng.integers(0, len(V32), 200)].astype(np.float64),
+                          rng.uniform(-1e4, 1e4, size=(20, 3))])
+    dist, face, closest = t.closest_point(torch.tensor(pts, device="cuda"), want_face=True, want_point=True)
+    ref_d, _ = orc.point_mesh_distance(pts, V32, hand.faces)
+    np.testing.assert_allclose(dist.cpu().numpy(), ref_d, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose((torch.tensor(pts, device="cuda") - closest).norm(dim=1).cpu().numpy(), dist.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    assert dist[1500:1700].max().item() < 1e-12 and (face >= 0).all() and (face < len(hand.faces)).all()
+    with pytest.raises(RuntimeError):
+        t.closest_point(torch.tensor(pts, device="cuda", dtype=torch.float32))
+
+    # 50k triangles: every vertex and every face centroid is on the surface; a point pushed out along
+    # the face normal by h from a centroid is at most h away, and exactly h when h is small
+    big = _tracer(horse50k)
+    Vb = torch.tensor(horse50k.vertices.astype(np.float32), device="cuda").double()
+    Fb = torch.tensor(horse50k.faces, device="cuda").long()
+    assert big.closest_point(Vb)[0].max().item() < 1e-12
+    tri = Vb[Fb]
+    cen = tri.mean(1)
+    n = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    n = n / n.norm(dim=1, keepdim=True)
+    assert big.closest_point(cen)[0].max().item() < 1e-5
+    h = 1e-4
+    d_out = big.closest_point(cen + h * n)[0]
+    assert d_out.max().item() <= h * (1 + 1e-9) + 1e-6
+    assert (d_out - h).abs().median().item() < 1e-9
+    # 1-Lipschitz in the query point
+    q = torch.tensor(rng.uniform(-150, 150, size=(20000, 3)), device="cuda")
+    dq = torch.tensor(rng.normal(0, 1.0, size=(20000, 3)), device="cuda")
+    assert ((big.closest_point(q)[0] - big.closest_point(q + dq)[0]).abs() <= dq.norm(dim=1) * (1 + 1e-12) + 1e-12).all()
+
+    # acceptance metric: result = scan displaced along vertex normals by N(0, 0.2)
+    scan = Render.Scene(horse50k, 0)
+    moved = views.displaced_ground_truth(horse50k, 0.2, 1)
+    stats = metrics.hausdorff(moved, scan)
+    assert stats["n"] == len(horse50k.vertices) and 0 <= stats["min"] <= stats["mean"] <= stats["rms"] <= stats["max"] < 1.5
+    assert 0.05 < stats["mean"] < 0.2                      # E|N(0, 0.2)| = 0.16, less where the surface curves
+    sym = metrics.hausdorff(moved, scan, symmetric=True)
+    assert sym["forward"] == stats and sym["hausdorff"] >= stats["max"]
+    assert metrics.hausdorff(scan, scan)["max"] < 1e-12

@@ -245,3 +245,32 @@ def test_dihedral_vs_golden(hostsim):
     gv2 = np.zeros_like(V); gc = -1.0 / (1.0 + cosv)
     hostsim.hs_dihedral(V.ctypes.data, E2F.ctypes.data, len(E2F), 1, None, gc.ctypes.data, None, gv2.ctypes.data)
     np.testing.assert_allclose(gv2, gv, rtol=1e-12, atol=1e-14 * np.abs(gv).max())
+
+
+def test_closest_point_matches_bruteforce(hostsim):
+    """drt_closest.h (BVH-pruned, Voronoi-region routine) == brute force with an independent formulation."""
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    F = np.ascontiguousarray(mesh.faces, dtype=np.int32)
+    V = np.ascontiguousarray(mesh.vertices, dtype=np.float32)
+    h = ctypes.c_void_p(hostsim.hs_create(F.ctypes.data, len(F), V.ctypes.data, len(V)))
+    rng = np.random.default_rng(3)
+    lo, hi = V.min(0), V.max(0)
+    pts = np.concatenate([
+        rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), size=(600, 3)),          # around and inside the mesh
+        V[rng.integers(0, len(V), 100)].astype(np.float64),                                  # exactly on vertices
+        V[F[rng.integers(0, len(F), 100)]].astype(np.float64).mean(1),                        # on faces
+        V[rng.integers(0, len(V), 100)].astype(np.float64) + rng.normal(0, 1e-3, (100, 3)),   # very close to the surface
+        rng.uniform(-1e4, 1e4, size=(20, 3)),                                                 # far away
+    ])
+    pts = np.ascontiguousarray(pts)
+    dist = np.empty(len(pts)); face = np.empty(len(pts), dtype=np.int32); closest = np.empty((len(pts), 3))
+    hostsim.hs_closest_point(h, pts.ctypes.data, len(pts), dist.ctypes.data, face.ctypes.data, closest.ctypes.data)
+    ref_d, _ = orc.point_mesh_distance(pts, V, F)
+    np.testing.assert_allclose(dist, ref_d, rtol=1e-9, atol=1e-9)
+    # the reported point lies on the reported face and realises the distance
+    np.testing.assert_allclose(np.linalg.norm(pts - closest, axis=1), dist, rtol=1e-12, atol=1e-12)
+    d_face, _ = zip(*[orc.point_mesh_distance(pts[i:i + 1], V, F[face[i]:face[i] + 1]) for i in range(0, len(pts), 37)])
+    np.testing.assert_allclose(np.concatenate(d_face), dist[::37], rtol=1e-9, atol=1e-9)
+    assert dist[600:700].max() < 1e-12                        # a vertex is on the surface
+    assert dist[700:800].max() < 1e-4                         # face centroids (float32 vertices, float64 mean)
+    hostsim.hs_destroy(h)
