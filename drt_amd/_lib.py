@@ -44,6 +44,10 @@ SIGNATURES = {
     "drt_edge_sample_backward": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _c.c_int, _P, _P]),
     "drt_closest_point": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "drt_vh_loss_fused": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
+    "drt_remesh_isotropic": (_c.c_int, [_P, _I64, _P, _I64, _D, _c.c_int, _D, _c.c_uint, _c.POINTER(_P)]),
+    "drt_mesh_buf_size": (_c.c_int, [_P, _c.POINTER(_I64), _c.POINTER(_I64), _P]),
+    "drt_mesh_buf_copy": (_c.c_int, [_P, _P, _P]),
+    "drt_mesh_buf_free": (None, [_P]),
     "drt_profile_enable": (_c.c_int, [_P, _c.c_int]),
     "drt_profile_read": (_c.c_int, [_P, _P, _P, _P]),
     "drt_profile_trace_stats": (_c.c_int, [_P, _P]),

@@ -5,7 +5,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "drt_kernels.hip")
+SRC = os.path.join(HERE, "csrc", "drt_kernels.hip")      # gfx950 kernels + device-side C ABI
+SRC_HOST = os.path.join(HERE, "csrc", "drt_remesh.cpp")  # host-only part of the C ABI (remeshing)
 OUT = os.path.join(HERE, "libdrt_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -27,7 +28,7 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC]
+    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC, SRC_HOST]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

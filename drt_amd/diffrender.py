@@ -177,6 +177,25 @@ def ray_loss(out_ori, out_dir, mask, screen_pixel, valid):
     return _RayLoss.apply(out_ori, out_dir, mask, screen_pixel, valid)
 
 
+def edge_tables(F, V):
+    """Edges [E,2], E2F [E,2,3], mean_len (reference DiffRender.py:338-355) on the device of ``F`` / ``V`` by one
+    stable sort of the 3F directed-edge keys -- the reference goes through trimesh's host-side ``group_rows`` /
+    ``edges_face``.  Order as pinned in mesh_io.group_rows_pairs: edges ascend by (min vertex, max vertex); the
+    first face of a pair is the one with the lower directed-edge row.  Asserts watertightness (DiffRender.py:305)."""
+    n_v = V.shape[0]
+    directed = F[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2)           # rows 3f..3f+2 belong to face f
+    lo, hi = directed.min(dim=1).values, directed.max(dim=1).values
+    keys, order = torch.sort(lo * n_v + hi, stable=True)
+    first, second = keys[0::2], keys[1::2]
+    watertight = keys.numel() % 2 == 0 and keys.numel() > 0 and bool(((first == second).all() & (first[1:] > first[:-1]).all()).item())
+    assert watertight, "mesh is not watertight: every edge must be shared by exactly two faces"
+    rows = torch.stack((order[0::2], order[1::2]), dim=1)        # [E,2] directed-edge rows of each edge
+    Edges = torch.stack((lo[rows[:, 0]], hi[rows[:, 0]]), dim=1)
+    E2F = F[rows // 3]
+    mean_len = float((V[directed[:, 0]] - V[directed[:, 1]]).norm(dim=1).mean().item())
+    return Edges, E2F, mean_len
+
+
 class Scene:
     def __init__(self, mesh_path, cuda_device=0):
         self.cuda_device = int(cuda_device)
@@ -191,21 +210,17 @@ class Scene:
 
     def update_mesh(self, mesh_path):
         mesh = mesh_path if isinstance(mesh_path, mesh_io.TriMesh) else mesh_io.load(mesh_path, process=False)
-        assert mesh.is_watertight
         self._mesh = mesh
         self._mesh_stale = False
         self.vertices = torch.tensor(mesh.vertices, dtype=Float, device=self._dev)
         self.faces = torch.tensor(mesh.faces, dtype=torch.long, device=self._dev)
+        self.init_edge()                                  # also the watertightness assert of DiffRender.py:305
         opt_v = self.vertices.detach().to(torch.float32)
         opt_F = self.faces.to(torch.int32)
         self.optix_mesh.update_mesh(opt_F, opt_v)
-        self.init_edge()
 
     def init_edge(self):
-        edges, e2f, mean_len = mesh_io.edge_tables(self._mesh)
-        self.mean_len = mean_len
-        self.Edges = torch.tensor(edges, device=self._dev)
-        self.E2F = torch.tensor(e2f, device=self._dev)
+        self.Edges, self.E2F, self.mean_len = edge_tables(self.faces, self.vertices.detach())
 
     @property
     def mesh(self):

@@ -8,8 +8,8 @@ Differences from the reference, all outside the per-view math:
   * the capture comes from any object with the reference's ``Data`` interface (``get_view``,
     ``ray_view_generator``, ``silh_view_generator``, ``resx``, ``resy``): drt_amd.captured_data has the
     reference's capture classes and ``SyntheticData``, which stands in for the HDF5 captures (not distributed);
-  * the MeshLab remesh between passes (optim.py:12-52, an external GUI tool) is a pluggable
-    ``remesh`` callable, default: keep the topology;
+  * the MeshLab remesh between passes (optim.py:12-52, an external program) is done in-process by
+    drt_amd.remesh (same algorithm and parameters); ``remesh=`` takes any other callable, or None;
   * multi-GPU: ``full_batch_step`` shards views over ranks and all-reduces the vertex gradient
     once per step (drt_amd.dist); the reference is single-GPU and one view per step.
 """
@@ -124,8 +124,14 @@ def setup_opt(scene, lr, HyperParams, hook=True):
     return init_vertices, parameter, opt
 
 
-def optimize(scene, data, HyperParams, remesh=None, output=True, fused=False):
-    """The reference's pass / iteration loop (optim.py:190-215) for an existing scene and data object."""
+def optimize(scene, data, HyperParams, remesh="isotropic", output=True, fused=False):
+    """The reference's pass / iteration loop (optim.py:190-215) for an existing scene and data object.
+    ``remesh``: "isotropic" (default) re-tessellates to ``remesh_len`` before every pass like the reference's
+    ``meshlabserver.remesh`` (optim.py:195), with the in-process remesher of drt_amd.remesh; ``None`` keeps the
+    topology; or any callable ``remesh(scene, remesh_len)``."""
+    if remesh == "isotropic":
+        from .remesh import Meshlabserver
+        remesh = Meshlabserver().remesh
     Render.intIOR = HyperParams["IOR"]
     Render.resy, Render.resx = data.resy, data.resx
     loss_calculator = Loss_calculator(scene, data, HyperParams, fused=fused)

@@ -176,6 +176,28 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
 int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double* d_dist, int32_t* d_face,
                       double* d_closest, void* stream);
 
+/* ---- remeshing between passes (host code; all pointers here are HOST pointers) -------------------------
+ * drt_remesh_isotropic <- Meshlabserver.remesh (optim.py:12-52): MeshLab's "Remeshing: Isotropic Explicit
+ * Remeshing" with Iterations=iterations (3), TargetLen=target_len, CheckSurfDist / MaxSurfDist=max_surf_dist
+ * (1), and the refine / collapse / edge-swap / smooth / reproject steps selected by `flags` (all on in the
+ * reference).  Input: a closed manifold, verts float64 [V,3], faces int32 [F,3].  The result is returned
+ * in an opaque buffer: query its size, copy it out, free it. */
+#define DRT_REMESH_SPLIT 1u
+#define DRT_REMESH_COLLAPSE 2u
+#define DRT_REMESH_FLIP 4u
+#define DRT_REMESH_SMOOTH 8u
+#define DRT_REMESH_REPROJECT 16u
+#define DRT_REMESH_CHECK_DIST 32u
+#define DRT_REMESH_ALL 63u
+typedef struct drt_mesh_buf drt_mesh_buf_t;
+int drt_remesh_isotropic(const double* verts, int64_t n_verts, const int32_t* faces, int64_t n_faces,
+                         double target_len, int iterations, double max_surf_dist, unsigned flags,
+                         drt_mesh_buf_t** out);
+/* stats4 (nullable): edges split, edges collapsed, edges flipped, iterations run */
+int drt_mesh_buf_size(const drt_mesh_buf_t* b, int64_t* n_verts, int64_t* n_faces, int64_t* stats4);
+int drt_mesh_buf_copy(const drt_mesh_buf_t* b, double* verts, int32_t* faces);
+void drt_mesh_buf_free(drt_mesh_buf_t* b);
+
 /* ---- measurement (bench.py's live per-kernel timing) --------------------------------------------
  * When enabled (on = 1; on = 2 additionally collects the traversal statistics below, which perturbs
  * timing) every kernel of the build / forward / backward / fused pipelines is bracketed by a

@@ -416,7 +416,7 @@ def test_optimize_loop_on_synthetic_capture(Render, hand):
 
     scene.update_verticex(scene.vertices.detach())
     before = mean_ray_loss()
-    scene, hist = O.optimize(scene, data, hp, output=False)
+    scene, hist = O.optimize(scene, data, hp, remesh=None, output=False)
     after = mean_ray_loss()
     assert np.isfinite(before) and np.isfinite(after) and torch.isfinite(scene.vertices).all()
     assert after < 0.8 * before, (before, after)
@@ -436,7 +436,7 @@ def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
     from drt_amd import build
     so = str(tmp_path / "libdrt_hip_stack3.so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc] + build.FLAGS + ["-DDRT_STACK_FAST=3", "-o", so, build.SRC])
+    subprocess.check_call([hipcc] + build.FLAGS + ["-DDRT_STACK_FAST=3", "-o", so, build.SRC, build.SRC_HOST])
     env = dict(os.environ, DRT_HIP_LIB=so)
     sel = "test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or test_silhouette_branch_vs_golden"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
@@ -493,3 +493,28 @@ def test_closest_point_and_hausdorff(Render, hand, horse50k):
     sym = metrics.hausdorff(moved, scan, symmetric=True)
     assert sym["forward"] == stats and sym["hausdorff"] >= stats["max"]
     assert metrics.hausdorff(scan, scan)["max"] < 1e-12
+
+
+def test_full_loop_with_remesh_towards_the_scan(Render):
+    """The reference's whole loop (optim.py:190-215): remesh to the pass's target length, optimise, next pass --
+    on a synthetic capture traced through the scanned horse, starting from its visual hull; the acceptance
+    metric (vertex-to-scan distance, README.md:11) must improve."""
+    from drt_amd import metrics, optim as O
+    res = 192
+    Render.intIOR = IOR
+    Render.resx = Render.resy = res
+    scan = mesh_io.read_ply(data_path("horse_scan.ply"))
+    hull = mesh_io.read_ply(data_path("horse_vh.ply"))
+    center, extent = views.mesh_frame(scan.vertices)
+    scan_scene = Render.Scene(scan, 0)
+    data = O.SyntheticData(scan_scene, center, extent, res, res, num_view=24, n_total=24)
+    scene = Render.Scene(hull, 0)
+    before = metrics.hausdorff(scene, scan_scene)
+    hp = dict(O.HyperParams, Pass=3, Iters=60, start_len=6.0, end_len=4.0, start_lr=0.1, num_view=24)
+    scene, _ = O.optimize(scene, data, hp, output=False, fused=True)
+    after = metrics.hausdorff(scene, scan_scene)
+    m = scene.mesh
+    assert m.is_watertight and len(m.faces) != len(hull.faces) and torch.isfinite(scene.vertices).all()
+    el = np.linalg.norm(m.vertices[m.edges[:, 0]] - m.vertices[m.edges[:, 1]], axis=1)
+    assert 3.0 < el.mean() < 5.0                                     # last pass was remeshed to 4 mm
+    assert after["mean"] < before["mean"], (before, after)
