@@ -347,55 +347,60 @@ __global__ void k_refit(const uint32_t* __restrict__ sorted_idx, const int32_t* 
     }
 }
 
-// Binary -> 4-wide collapse (drt_lbvh.h): one thread per binary node; nodes at even depth with
-// more than kLeafMax triangles (and the root) become wide nodes.  Runs after k_refit (kernel
-// boundary = all boxes visible).
+// Binary -> 4-wide collapse (drt_lbvh.h): one thread per binary node with more than kLeafMax triangles
+// (and the root).  The traversal only ever reaches the wide nodes of EVEN-depth binary nodes (a wide node
+// adopts grandchildren), but finding a node's depth means walking its parent links to the root -- a chain
+// of ~30 dependent loads that made this kernel 34 us; building the (unreferenced) odd-depth ones too is a
+// few microseconds of independent work.  Runs after k_refit (kernel boundary = all boxes visible).
 __global__ void k_collapse4(const Node* __restrict__ nodes, const int32_t* __restrict__ parent_inner,
                             const int32_t* __restrict__ range_lo, const int32_t* __restrict__ range_hi, int n,
                             Node4Q* __restrict__ wide) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int inner = n > 1 ? n - 1 : 1;
     if (i >= inner) return;
-    if (i != 0) {
-        if (range_hi[i] - range_lo[i] + 1 <= kLeafMax) return;
-        int depth = 0;
-        for (int32_t link = parent_inner[i]; link >= 0; link = parent_inner[link >> 1]) ++depth;
-        if (depth & 1) return;
-    }
+    if (i != 0 && range_hi[i] - range_lo[i] + 1 <= kLeafMax) return;
     Node4 out;
     collapse4(nodes, range_lo, range_hi, n, i, out);
     wide[i] = node4_quantize(out);
 }
 
-// Diagnostic for the wide tree: every leaf marks its triangle slots and checks its box.
-__global__ void k_wide_check(const Node4Q* __restrict__ wide, const int32_t* __restrict__ parent_inner,
-                             const int32_t* __restrict__ range_lo, const int32_t* __restrict__ range_hi,
-                             const TriRec* __restrict__ tris, int n, const BuildParams* __restrict__ bp,
-                             uint32_t* seen, unsigned long long* violations) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int inner = n > 1 ? n - 1 : 1;
-    if (i >= inner) return;
-    if (i != 0) {
-        if (range_hi[i] - range_lo[i] + 1 <= kLeafMax) return;
-        int depth = 0;
-        for (int32_t link = parent_inner[i]; link >= 0; link = parent_inner[link >> 1]) ++depth;
-        if (depth & 1) return;
-    }
-    const Node4Q nd = wide[i];
-    unsigned long long bad = 0;
-    for (int k = 0; k < 4; ++k) {
-        const int32_t c = nd.child[k];
-        if (c == kEmptyChild || c >= 0) continue;
-        const int first = (~c) >> kLeafBits, count = ((~c) & (kLeafMax - 1)) + 1;
-        for (int j = first; j < first + count; ++j) {
-            if (j < 0 || j >= n) { ++bad; continue; }
-            atomicAdd(&seen[j], 1u);
-            const TriRec t = tris[j];
-            const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, cc{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
-            if (!box_contains(node4q_box(nd, k), box_of_tri(a, b, cc, 0.5f * bp->pad))) ++bad;
+// Diagnostic for the wide tree (one thread, depth-first from the root -- only the nodes a traversal can reach):
+// every leaf marks its triangle slots and checks its box; out[2] = depth of the wide tree.  A traversal keeps at
+// most three postponed children per level, so 3 * depth must fit the spilling stack of k_trace_redo / B1 queries.
+__global__ void k_wide_walk(const Node4Q* __restrict__ wide, const TriRec* __restrict__ tris, int n, const BuildParams* __restrict__ bp,
+                            uint32_t* seen, unsigned long long* out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0 || n <= 0) return;
+    constexpr int kCap = 512;
+    int32_t node[kCap];
+    int16_t level[kCap];
+    int sp = 0;
+    unsigned long long bad = 0, deepest = 0;
+    node[sp] = 0; level[sp] = 1; ++sp;
+    while (sp > 0) {
+        --sp;
+        const Node4Q nd = wide[node[sp]];
+        const int lv = level[sp];
+        if ((unsigned long long)lv > deepest) deepest = lv;
+        for (int k = 0; k < 4; ++k) {
+            const int32_t c = nd.child[k];
+            if (c == kEmptyChild) continue;
+            if (c >= 0) {
+                if (sp < kCap) { node[sp] = c; level[sp] = (int16_t)(lv + 1); ++sp; } else ++bad;
+                continue;
+            }
+            const int first = (~c) >> kLeafBits, count = ((~c) & (kLeafMax - 1)) + 1;
+            for (int j = first; j < first + count; ++j) {
+                if (j < 0 || j >= n) { ++bad; continue; }
+                seen[j] += 1u;
+                const TriRec t = tris[j];
+                const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, cc{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+                if (!box_contains(node4q_box(nd, k), box_of_tri(a, b, cc, 0.5f * bp->pad))) ++bad;
+            }
         }
     }
-    if (bad) atomicAdd(violations, bad);
+    if (3 * deepest > (unsigned long long)(kStackFast + kStackSlowDev)) ++bad;   // would overflow the spilling traversal stack
+    out[0] += bad;
+    out[2] = deepest;
 }
 __global__ void k_seen_check(const uint32_t* __restrict__ seen, int n, unsigned long long* violations) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1417,24 +1422,24 @@ int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays
     return DRT_OK;
 }
 
-int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height) {
+int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height, int32_t* wide_depth) {
     CHECK_BUILT(s);
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long v[2] = {0, 0};
+    unsigned long long v[3] = {0, 0, 0};
     if (s->n_faces) {
-        HIP_TRY(hipMemsetAsync(s->scratch, 0, 2 * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(s->scratch, 0, 3 * sizeof(unsigned long long), st));
         const int n = (int)s->n_faces;
         k_bvh_check<<<(n + 255) / 256, 256, 0, st>>>(s->tris, n, s->params, s->nodes, s->parent_inner, s->parent_leaf, s->scratch);
         // the refit counters are dead after a build: reuse them as per-slot reference counts
         HIP_TRY(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * n, st));
-        const int inner = n > 1 ? n - 1 : 1;
-        k_wide_check<<<(inner + 255) / 256, 256, 0, st>>>(s->wide, s->parent_inner, s->range_lo, s->range_hi, s->tris, n, s->params, s->flags, s->scratch);
+        k_wide_walk<<<1, 64, 0, st>>>(s->wide, s->tris, n, s->params, s->flags, s->scratch);
         k_seen_check<<<(n + 255) / 256, 256, 0, st>>>(s->flags, n, s->scratch);
         HIP_TRY(hipMemcpyAsync(v, s->scratch, sizeof(v), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (n_violations) *n_violations = (int64_t)v[0];
     if (height) *height = (int32_t)v[1];
+    if (wide_depth) *wide_depth = (int32_t)v[2];
     return DRT_OK;
 }
 

@@ -225,28 +225,57 @@ DRT_HD Node4Q node4_quantize(const Node4& f) {
     return q;
 }
 
-// Wide node rooted at binary node i (which must be at even depth with more than kLeafMax
-// triangles below it, or be the root).  Wide nodes keep the index of their binary root.
+DRT_HD float box_area(const Box& b) {
+    const float dx = b.hix - b.lox, dy = b.hiy - b.loy, dz = b.hiz - b.loz;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Wide node rooted at binary node i (more than kLeafMax triangles below it, or the root).  Starts from the
+// two binary children and twice opens the open-able child with the LARGEST surface area (surface-area
+// heuristic: the box a random ray is most likely to enter is the one worth resolving inside this node), so
+// a wide node spans one to three binary levels instead of always exactly two.  Wide nodes keep the index of
+// their binary root; any binary node may become one.
+#ifndef DRT_GREEDY_COLLAPSE
+#define DRT_GREEDY_COLLAPSE 1
+#endif
 DRT_HD void collapse4(const Node* bin, const int32_t* range_lo, const int32_t* range_hi, int n_tris, int i, Node4& out) {
     node4_clear(out);
     if (n_tris <= kLeafMax) {   // whole mesh in one leaf under the root
         node4_set(out, 0, box_union(node_child_box(bin[0], 0), node_child_box(bin[0], 1)), leaf_ref(0, n_tris));
         return;
     }
+    int32_t ref[4];     // >= 0: binary node to descend into; < 0: finished leaf reference
+    Box box[4];
+    bool open[4];
     int k = 0, first, count;
     for (int s = 0; s < 2; ++s) {
         const int32_t c = s == 0 ? bin[i].child0 : bin[i].child1;
-        if (wide_leaf_of(c, range_lo, range_hi, first, count)) {
-            node4_set(out, k++, node_child_box(bin[i], s), leaf_ref(first, count));
-            continue;
-        }
+        box[k] = node_child_box(bin[i], s);
+        open[k] = !wide_leaf_of(c, range_lo, range_hi, first, count);
+        ref[k] = open[k] ? c : leaf_ref(first, count);
+        ++k;
+    }
+    for (int round = 0; round < 2; ++round) {
+        int pick = -1;
+#if DRT_GREEDY_COLLAPSE
+        float best = -1.0f;
+        for (int j = 0; j < k; ++j)
+            if (open[j]) { const float a = box_area(box[j]); if (a > best) { best = a; pick = j; } }
+#else
+        for (int j = 0; j < 2 && pick < 0; ++j) if (open[j] && ref[j] == (j == 0 ? bin[i].child0 : bin[i].child1)) pick = j;
+#endif
+        if (pick < 0) break;
+        const int32_t c = ref[pick];
+        // the opened child's two children take its slot and the next free one
         for (int s2 = 0; s2 < 2; ++s2) {
             const int32_t g = s2 == 0 ? bin[c].child0 : bin[c].child1;
-            const Box gb = node_child_box(bin[c], s2);
-            if (wide_leaf_of(g, range_lo, range_hi, first, count)) node4_set(out, k++, gb, leaf_ref(first, count));
-            else node4_set(out, k++, gb, g);
+            const int slot = s2 == 0 ? pick : k++;
+            box[slot] = node_child_box(bin[c], s2);
+            open[slot] = !wide_leaf_of(g, range_lo, range_hi, first, count);
+            ref[slot] = open[slot] ? g : leaf_ref(first, count);
         }
     }
+    for (int j = 0; j < k; ++j) node4_set(out, j, box[j], ref[j]);
 }
 
 }  // namespace drt

@@ -139,11 +139,14 @@ class optix_mesh:
         return dist, face, closest
 
     def check(self):
-        """(number of BVH containment/link violations, tree height); synchronises."""
+        """(number of BVH containment/link violations, binary tree height); synchronises.  ``self.wide_depth`` = depth of
+        the 4-wide tree the traversal walks (a violation is counted when 3 x depth exceeds the traversal stack)."""
         v = ctypes.c_int64()
         hgt = ctypes.c_int32()
+        wide = ctypes.c_int32()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().drt_bvh_check(self._h, _stream(), ctypes.byref(v), ctypes.byref(hgt)))
+            _lib.check(_lib.lib().drt_bvh_check(self._h, _stream(), ctypes.byref(v), ctypes.byref(hgt), ctypes.byref(wide)))
+        self.wide_depth = wide.value
         return v.value, hgt.value
 
     def sorted_faces(self):

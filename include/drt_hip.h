@@ -65,8 +65,9 @@ int drt_intersect_any(drt_scene_t* s, const float* d_rays, int64_t n_rays,
 int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays,
                              float* d_T, int32_t* d_ID, void* stream);
 /* Diagnostic: number of BVH child boxes that fail to enclose their subtree (0 when the
- * build is sound) and the tree height; host-synchronising. */
-int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height);
+ * build is sound, also counted when the 4-wide tree is too deep for the traversal stack), the binary
+ * tree height and (nullable) the depth of the 4-wide tree; host-synchronising. */
+int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height, int32_t* wide_depth);
 /* Diagnostic: copy the Morton-sorted face order (int32 [F]) to d_order. */
 int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
 

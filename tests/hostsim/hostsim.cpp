@@ -96,9 +96,7 @@ static void build(HsScene& s) {
         s.height = std::max(s.height, depth);
     }
     for (int i = 0; i < inner; ++i) {
-        int depth = 0;
-        for (int32_t link = s.parent_inner[i]; link >= 0; link = s.parent_inner[link >> 1]) ++depth;
-        const bool wide_root = i == 0 || ((depth & 1) == 0 && s.range_hi[i] - s.range_lo[i] + 1 > kLeafMax);
+        const bool wide_root = i == 0 || s.range_hi[i] - s.range_lo[i] + 1 > kLeafMax;   // any of them may be adopted by a wide parent
         if (wide_root) { Node4 full; collapse4(s.nodes.data(), s.range_lo.data(), s.range_hi.data(), n, i, full); s.wide[i] = node4_quantize(full); }
     }
 }

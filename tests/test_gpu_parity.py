@@ -51,6 +51,8 @@ def test_b1_intersect_equals_oracle_bruteforce(hand):
     t = _tracer(hand)
     bad, height = t.check()
     assert bad == 0 and 12 <= height <= 48
+    assert 1 <= t.wide_depth <= height and 3 * t.wide_depth <= 64, (t.wide_depth, height)   # 3 postponed children per level fit the stack
+    print(f"hand: binary height {height}, wide depth {t.wide_depth}")
     f32 = hand.faces.astype(np.int32); v32 = hand.vertices.astype(np.float32)
     rng = np.random.default_rng(3)
     c, ext = views.mesh_frame(hand.vertices)
@@ -123,7 +125,7 @@ def test_lbvh_rebuild_is_sound_and_stable_under_load(horse50k):
         t.intersect(rays)                       # keep the chip busy between builds
         bad, height = t.check()
         assert bad == 0, f"iteration {it}: {bad} BVH violations"
-        assert height <= 48
+        assert height <= 48 and 3 * t.wide_depth <= 64
     t.update_vert(V)
     T, ID = t.intersect(rays)
     assert torch.equal(ID, ref_ID) and torch.equal(T, ref_T)
@@ -134,6 +136,9 @@ def test_lbvh_rebuild_is_sound_and_stable_under_load(horse50k):
 def test_full_size_traversal_equals_gpu_bruteforce(horse50k, res):
     """BASELINE workload size (50 248 triangles, up to 1024x1024 rays): BVH result == exhaustive test."""
     t = _tracer(horse50k)
+    bad, height = t.check()
+    assert bad == 0 and 3 * t.wide_depth <= 64
+    print(f"horse50k: binary height {height}, wide depth {t.wide_depth}")
     for view in (3, 40):
         rays = _camera_rays(horse50k, res, view).cuda()
         T, ID = t.intersect(rays)
