@@ -601,7 +601,7 @@ __device__ __forceinline__ bool hits_top_boxes(const Node4Q* __restrict__ nodes,
 // appends its candidates in 16x4-tile order, so that the 64 rays a traversal wave picks up come from
 // a compact screen region (same BVH nodes, same depth) instead of a 64x1 strip.
 template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+__global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
                                                       const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
                                                       double* __restrict__ out_dir, uint8_t* __restrict__ mask,
                                                       int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w) {
@@ -609,6 +609,8 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double
     __shared__ uint8_t s_flag[kPathBlock];
     __shared__ int s_slot[kPathBlock];
     const int tid = threadIdx.x;
+    // (`nodes` is a __restrict__ parameter of its own, not the TraceCtx struct, so that the compiler can prove the root
+    // node is never clobbered: it is then fetched once, through the scalar cache, instead of by four vector loads per ray)
     // patch = 64 pixels wide x 4 rows (every wave reads one full 1536-byte row segment); tiles of 16x4 pixels
     const int vt = ((tid & 63) >> 4) * 64 + (tid >> 6) * 16 + (tid & 15);   // position of this thread's pixel in tile order
     const int64_t patches_per_row = tile_w > 0 ? tile_w / 64 : 1;
@@ -625,7 +627,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(TraceCtx c, const double
             // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
             if (!FUSED || valid[i]) {
                 o = to_f32(load_d3(origin, i)); d = to_f32(load_d3(dir, i));
-                cand = c.n_tris > 0 && hits_top_boxes(c.nodes, o, d);
+                cand = n_tris > 0 && hits_top_boxes(nodes, o, d);
             }
             if (!cand) {
                 face1[i] = -1;
@@ -1553,7 +1555,7 @@ static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const 
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
     { StageTimer t(s, st, kStageCull);
-      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
+      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
     { StageTimer t(s, st, kStageTrace1);
       k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
       k_trace_redo<false><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, p.r0.face); }
