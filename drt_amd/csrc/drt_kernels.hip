@@ -142,8 +142,10 @@ __global__ void k_cast_verts(const double* __restrict__ v64, float* __restrict__
 }
 
 // One block: scene box over all vertices -> Morton normalisation + leaf padding.
-__global__ void __launch_bounds__(1024) k_bounds(const float* __restrict__ verts, int64_t n_verts, BuildParams* out) {
+__global__ void __launch_bounds__(1024) k_bounds(const float* __restrict__ verts, int64_t n_verts, BuildParams* out,
+                                                 uint32_t* __restrict__ hist_zero, int hist_entries) {
     __shared__ float red[6][16];
+    for (int i = threadIdx.x; i < hist_entries; i += blockDim.x) hist_zero[i] = 0u;   // digit histograms of the fused sort (below)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = threadIdx.x; i < n_verts; i += blockDim.x) {
         for (int a = 0; a < 3; ++a) {
@@ -185,12 +187,15 @@ __device__ __forceinline__ f3 ld_vert(const float* __restrict__ verts, int32_t i
 }
 
 __global__ void k_morton(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n,
-                         const BuildParams* __restrict__ bp, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                         const BuildParams* __restrict__ bp, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                         uint32_t* hist0, int tiles) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const f3 a = ld_vert(verts, faces[3 * i]), b = ld_vert(verts, faces[3 * i + 1]), c = ld_vert(verts, faces[3 * i + 2]);
-    keys[i] = morton30(a, b, c, f3{bp->lox, bp->loy, bp->loz}, f3{bp->ix, bp->iy, bp->iz});
+    const uint32_t key = morton30(a, b, c, f3{bp->lox, bp->loy, bp->loz}, f3{bp->ix, bp->iy, bp->iz});
+    keys[i] = key;
     idx[i] = (uint32_t)i;
+    if (hist0) atomicAdd(&hist0[(key & (kRadix - 1)) * tiles + i / kSortTile], 1u);   // first pass of the fused sort
 }
 
 // ---- LSD radix sort, 8 bits per pass, stable; three launches per pass -------------------
@@ -262,6 +267,68 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_scatter(const uint32_t* __r
             for (int w = 0; w < wave; ++w) pos += wcount[w][digit];
             keys_out[pos] = key;
             idx_out[pos] = val;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < kWaves; ++w) { add += wcount[w][tid]; wcount[w][tid] = 0; }
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+// Fused pass for small meshes (tiles <= kSortFusedTiles): the per-tile digit offsets are derived inside the scatter
+// from the [kRadix x tiles] histogram (every block redundantly reduces it: a few thousand words), and the scatter
+// counts the NEXT pass's histogram while it places the keys (the destination tile is known then).  One launch per
+// pass instead of three: a 50 k-triangle sort is bound by launch count, not by work.
+constexpr int kSortFusedTiles = 128;
+__global__ void __launch_bounds__(kSortBlock) k_sort_pass_fused(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out, int n, int shift,
+                                                                const uint32_t* __restrict__ hist, uint32_t* hist_next, int tiles) {
+    constexpr int kWaves = kSortBlock / 64;
+    __shared__ uint32_t running[kRadix];
+    __shared__ uint32_t wcount[kWaves][kRadix];
+    __shared__ uint32_t scan[kRadix];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // offsets of this tile: (keys with a smaller digit) + (keys with this digit in earlier tiles); thread = digit
+    uint32_t total = 0, before = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const uint32_t v = hist[tid * tiles + t];
+        before += t < (int)blockIdx.x ? v : 0u;
+        total += v;
+    }
+    scan[tid] = total;
+    for (int w = 0; w < kWaves; ++w) wcount[w][tid] = 0;
+    __syncthreads();
+    for (int off = 1; off < kRadix; off <<= 1) {
+        const uint32_t v = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    running[tid] = scan[tid] - total + before;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = base + r * kSortBlock + tid;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t val = valid ? idx_in[i] : 0u;
+        const uint32_t digit = (key >> shift) & (kRadix - 1);
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool set = (digit >> bit) & 1u;
+            const unsigned long long bm = __ballot(valid && set);
+            peers &= set ? bm : ~bm;
+        }
+        const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcount[wave][digit] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[digit] + rank;
+            for (int w = 0; w < wave; ++w) pos += wcount[w][digit];
+            keys_out[pos] = key;
+            idx_out[pos] = val;
+            if (hist_next) atomicAdd(&hist_next[((key >> (shift + 8)) & (kRadix - 1)) * tiles + pos / kSortTile], 1u);
         }
         __syncthreads();
         uint32_t add = 0;
@@ -1242,7 +1309,7 @@ static int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
         HIP_TRY(hipMalloc(&s->keys[k], sizeof(uint32_t) * F));
         HIP_TRY(hipMalloc(&s->idx[k], sizeof(uint32_t) * F));
     }
-    HIP_TRY(hipMalloc(&s->hist, sizeof(uint32_t) * kRadix * tiles));
+    HIP_TRY(hipMalloc(&s->hist, sizeof(uint32_t) * kRadix * tiles * 4));   // one table per radix pass (fused sort)
     HIP_TRY(hipMalloc(&s->parent_inner, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->parent_leaf, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->flags, sizeof(uint32_t) * F));
@@ -1258,14 +1325,21 @@ static int rebuild_impl(drt_scene* s, hipStream_t st) {
     const int n = (int)s->n_faces;
     s->built = true;
     if (n == 0) return DRT_OK;
-    k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params);
-    k_morton<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->params, s->keys[0], s->idx[0]);
     const int tiles = (n + kSortTile - 1) / kSortTile;
+    const bool fused_sort = tiles <= kSortFusedTiles;
+    const int table = kRadix * tiles;
+    k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params, s->hist, fused_sort ? 4 * table : 0);
+    k_morton<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->params, s->keys[0], s->idx[0], fused_sort ? s->hist : nullptr, tiles);
     int cur = 0;
-    for (int shift = 0; shift < 30; shift += 8) {
-        k_sort_hist<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], n, shift, s->hist, tiles);
-        k_sort_scan<<<1, 1024, 0, st>>>(s->hist, kRadix * tiles);
-        k_sort_scatter<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], s->idx[cur], s->keys[cur ^ 1], s->idx[cur ^ 1], n, shift, s->hist, tiles);
+    for (int shift = 0, pass = 0; shift < 30; shift += 8, ++pass) {
+        if (fused_sort) {
+            k_sort_pass_fused<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], s->idx[cur], s->keys[cur ^ 1], s->idx[cur ^ 1], n, shift,
+                                                            s->hist + pass * table, pass < 3 ? s->hist + (pass + 1) * table : nullptr, tiles);
+        } else {
+            k_sort_hist<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], n, shift, s->hist, tiles);
+            k_sort_scan<<<1, 1024, 0, st>>>(s->hist, kRadix * tiles);
+            k_sort_scatter<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], s->idx[cur], s->keys[cur ^ 1], s->idx[cur ^ 1], n, shift, s->hist, tiles);
+        }
         cur ^= 1;
     }
     // four passes -> result is back in buffer 0
