@@ -93,6 +93,9 @@ class _RenderTransparent(torch.autograd.Function):
         ctx.scene = scene
         ctx.ior = (float(ior_int), float(ior_ext))
         ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)
+        # an output the loss does not use must reach backward() as None, not as a materialised [N,3] float64 zero tensor:
+        # the reference's ray_loss detaches out_ori (optim.py:100), and filling 1.8 GB of zeros per step cost 0.3 ms
+        ctx.set_materialize_grads(False)
         mask_b = mask.view(torch.bool)
         ctx.mark_non_differentiable(mask_b)
         scene.last_face1, scene.last_face2 = face1, face2
@@ -102,6 +105,8 @@ class _RenderTransparent(torch.autograd.Function):
     def backward(ctx, g_ori, g_dir, g_mask):
         v, o, d, face1, face2, valid_idx, n_valid = ctx.saved_tensors
         grad_v = torch.zeros_like(v)
+        if g_ori is None and g_dir is None:
+            return grad_v, None, None, None, None, None
         g_ori = None if g_ori is None else _f64c(g_ori, "grad_out_ori")
         g_dir = None if g_dir is None else _f64c(g_dir, "grad_out_dir")
         with torch.cuda.device(o.device):
