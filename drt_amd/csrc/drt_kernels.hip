@@ -1007,26 +1007,92 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ray_loss forward: loss, dense d loss / d out_dir, and (optionally) the list of contributing rays so
 // that the backward can rescale only those rows instead of streaming the whole [N,3] tensor again.
+// Three things bound the obvious one-ray-per-thread version (tools/ubench/ray_loss_probe.py, 75.5 M rays): 1-byte loads
+// of the flags (the vector-memory pipeline is paid per instruction: 0.42 ms for 0.3 GB), 8-byte strided stores of the
+// (mostly zero) gradient, and one returning atomic per block iteration on the list counter (a single word sustains
+// ~90 of them per microsecond: 3.3 ms when the contributing rays are scattered).  So: a thread takes FOUR consecutive
+// rays (one 4-byte load of `valid`, three of `mask`), a wave zero-fills its 6 KB of gradient with lane-consecutive 16-byte
+// stores (16-byte stores at a 96-byte lane stride were 3x slower: partial lines) and the block collects row indices in LDS,
+// reserving list space with one atomic per ~2000 rows.
+struct alignas(16) Dbl2 { double a, b; };
+constexpr int kLossRays = 4;                        // rays per thread
+constexpr int kLossBuf = 2048;                      // >= 2 x the 1024 rows one block iteration can add
 __global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
                                                           const uint8_t* __restrict__ mask, const double* __restrict__ screen_pixel,
                                                           const uint8_t* __restrict__ valid, int64_t n, double* loss,
                                                           double* __restrict__ g_out_dir, int32_t* __restrict__ list, unsigned* list_count) {
-    __shared__ unsigned s_tmp[kPathWaves + 1];
+    __shared__ unsigned s_tmp[kPathWaves + 2];      // wave totals, [kPathWaves] rows buffered, [kPathWaves + 1] reserved list base
+    __shared__ int32_t s_buf[kLossBuf];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    if (threadIdx.x == 0) s_tmp[kPathWaves] = 0u;
+    __syncthreads();
+    auto flush = [&]() {                            // reached by the whole block
+        const unsigned cnt = s_tmp[kPathWaves];
+        if (threadIdx.x == 0) s_tmp[kPathWaves + 1] = cnt ? atomicAdd(list_count, cnt) : 0u;
+        __syncthreads();
+        const unsigned base = s_tmp[kPathWaves + 1];
+        for (unsigned k = threadIdx.x; k < cnt; k += kPathBlock) list[base + k] = s_buf[k];
+        __syncthreads();
+        if (threadIdx.x == 0) s_tmp[kPathWaves] = 0u;
+        __syncthreads();
+    };
     double acc = 0.0;
-    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
-        const int64_t i = base + threadIdx.x;
-        bool on = false;
-        if (i < n) {
-            d3 g{0.0, 0.0, 0.0};
-            on = valid[i] && mask[3 * i];
-            if (on) acc += ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g);
-            if (g_out_dir) store_d3(g_out_dir, i, g);
+    const int64_t span = (int64_t)kLossRays * kPathBlock;
+    for (int64_t base = blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
+        const int64_t i0 = base + kLossRays * (int64_t)threadIdx.x;
+        bool on[kLossRays] = {false, false, false, false};
+        d3 g[kLossRays] = {d3{0.0, 0.0, 0.0}, d3{0.0, 0.0, 0.0}, d3{0.0, 0.0, 0.0}, d3{0.0, 0.0, 0.0}};
+        const bool full = i0 + kLossRays - 1 < n;
+        if (full) {
+            const uint32_t v4 = *reinterpret_cast<const uint32_t*>(valid + i0);
+            const uint32_t* mp = reinterpret_cast<const uint32_t*>(mask + 3 * i0);
+            const uint32_t m0 = mp[0], m1 = mp[1], m2 = mp[2];
+            on[0] = (v4 & 0xFFu) && (m0 & 0xFFu);                 // mask[3 i0]
+            on[1] = (v4 & 0xFF00u) && (m0 & 0xFF000000u);         // mask[3 i0 + 3]
+            on[2] = (v4 & 0xFF0000u) && (m1 & 0xFF0000u);         // mask[3 i0 + 6]
+            on[3] = (v4 & 0xFF000000u) && (m2 & 0xFF00u);         // mask[3 i0 + 9]
+        } else {
+            for (int k = 0; k < kLossRays; ++k) on[k] = i0 + k < n && valid[i0 + k] && mask[3 * (i0 + k)];
+        }
+        for (int k = 0; k < kLossRays; ++k)
+            if (on[k]) acc += ray_loss_term(load_d3(out_ori, i0 + k), load_d3(out_dir, i0 + k), load_d3(screen_pixel, i0 + k), g[k]);
+        if (g_out_dir) {
+            const int64_t w0 = i0 - kLossRays * (int64_t)lane;                  // first ray of this wave: 256 rays = 6144 contiguous bytes
+            if (w0 + kLossRays * 64 <= n) {
+                // zeros for the whole run with fully coalesced 16-byte stores (lane-consecutive), then the few rows that
+                // carry a gradient are overwritten -- after the zero stores have been acknowledged (s_waitcnt)
+                Dbl2* q = reinterpret_cast<Dbl2*>(g_out_dir + 3 * w0);
+                for (int j = 0; j < 6; ++j) q[j * 64 + lane] = Dbl2{0.0, 0.0};
+                if (__ballot(on[0] | on[1] | on[2] | on[3]) != 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int k = 0; k < kLossRays; ++k) if (on[k]) store_d3(g_out_dir, i0 + k, g[k]);
+                }
+            } else {
+                for (int k = 0; k < kLossRays; ++k) if (i0 + k < n) store_d3(g_out_dir, i0 + k, g[k]);
+            }
         }
         if (list) {
-            const int slot = block_push(on, list_count, s_tmp);
-            if (slot >= 0) list[slot] = (int32_t)i;
+            unsigned long long m[kLossRays];
+            unsigned before[kLossRays], tot = 0;
+            for (int k = 0; k < kLossRays; ++k) { m[k] = __ballot(on[k]); before[k] = tot; tot += (unsigned)__popcll(m[k]); }
+            if (lane == 0) s_tmp[wave] = tot;
+            __syncthreads();
+            unsigned wbase = s_tmp[kPathWaves], add = 0;
+            for (int w = 0; w < kPathWaves; ++w) { const unsigned c = s_tmp[w]; if (w < wave) wbase += c; add += c; }
+            if (add) {                               // block-uniform
+                for (int k = 0; k < kLossRays; ++k)
+                    if (on[k]) s_buf[wbase + before[k] + (unsigned)__popcll(m[k] & lower)] = (int32_t)(i0 + k);
+                __syncthreads();
+                if (threadIdx.x == 0) s_tmp[kPathWaves] += add;
+                __syncthreads();
+                if (s_tmp[kPathWaves] > kLossBuf - kLossRays * kPathBlock) flush();
+            } else {
+                __syncthreads();
+            }
         }
     }
+    if (list) flush();
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
 }
@@ -1748,7 +1814,7 @@ int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t
     if (n_rays == 0) return DRT_OK;
     if (!d_out_ori || !d_out_dir || !d_mask || !d_screen_pixel || !d_valid || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_list == nullptr) != (d_n_list == nullptr)) return fail(DRT_E_INVALID, "d_list and d_n_list go together");
-    k_ray_loss<<<grid_for(n_rays, kPathBlock, 4096), kPathBlock, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays,
+    k_ray_loss<<<grid_for((n_rays + kLossRays - 1) / kLossRays, kPathBlock, 4096), kPathBlock, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays,
                                                                                           d_loss, d_grad_out_dir, d_list, d_n_list);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
