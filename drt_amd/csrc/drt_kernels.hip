@@ -747,6 +747,8 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
                 if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
             }
         }
+        // nine out of ten patches are pure background: one barrier (with an OR-reduction) instead of the six of the push
+        if (!__syncthreads_or(cand ? 1 : 0)) continue;
         int slot;
         if (tile_w > 0) {
             s_flag[vt] = cand ? 1 : 0;
