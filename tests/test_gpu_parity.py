@@ -523,3 +523,31 @@ def test_full_loop_with_remesh_towards_the_scan(Render):
     el = np.linalg.norm(m.vertices[m.edges[:, 0]] - m.vertices[m.edges[:, 1]], axis=1)
     assert 3.0 < el.mean() < 5.0                                     # last pass was remeshed to 4 mm
     assert after["mean"] < before["mean"], (before, after)
+
+
+def test_large_mesh_uses_the_unfused_sort_and_stays_exact():
+    """327 680 triangles: above the 262 144 where the build switches from the fused radix passes to the
+    three-kernel passes; the tree must be sound and the traversal must equal the exhaustive test."""
+    sphere = mesh_io.icosphere(7, radius=60.0, noise=0.02, seed=4)
+    assert len(sphere.faces) == 327680
+    t = _tracer(sphere)
+    bad, height = t.check()
+    assert bad == 0 and 3 * t.wide_depth <= 64, (bad, height, t.wide_depth)
+    order = t.sorted_faces().cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(len(sphere.faces)))
+    rays = _camera_rays(sphere, 192, 11).cuda()
+    T, ID = t.intersect(rays)
+    assert 0.1 < (ID >= 0).float().mean().item() < 0.9
+    sel = torch.arange(0, rays.shape[0], 7, device="cuda")
+    Tb, IDb = t.intersect_bruteforce(rays[sel].contiguous())
+    assert torch.equal(ID[sel], IDb) and torch.equal(T[sel], Tb)
+    # and the pipeline on it: exit rays of valid paths are unit vectors, re-tracing them hits nothing
+    from drt_amd import diffrender as Render
+    Render.intIOR = IOR
+    scene = Render.Scene(sphere, 0)
+    o, d = rays[:, :3].double().contiguous(), rays[:, 3:].double().contiguous()
+    oo, od, m = scene.render_transparent(o, d)
+    ok = m[:, 0]
+    assert 0.005 < ok.float().mean().item() < 0.9, ok.float().mean().item()
+    assert (od[ok].norm(dim=1) - 1).abs().max().item() < 1e-12
+    assert not scene.optix_mesh.intersect_any(torch.cat([oo[ok].float(), od[ok].float()], 1)).any()
