@@ -27,6 +27,7 @@ import torch
 
 from . import _lib, mesh_io
 from .optix_mesh import optix_mesh, _stream
+from .stepwise import Intersection, StepwiseMixin  # noqa: F401  (Dintersect / refract_ray / trace2 / project_vert)
 
 debug = False
 resy = 960
@@ -201,7 +202,7 @@ def edge_tables(F, V):
     return Edges, E2F, mean_len
 
 
-class Scene:
+class Scene(StepwiseMixin):
     def __init__(self, mesh_path, cuda_device=0):
         self.cuda_device = int(cuda_device)
         self.optix_mesh = optix_mesh(self.cuda_device)

@@ -551,3 +551,52 @@ def test_large_mesh_uses_the_unfused_sort_and_stays_exact():
     assert 0.005 < ok.float().mean().item() < 0.9, ok.float().mean().item()
     assert (od[ok].norm(dim=1) - 1).abs().max().item() < 1e-12
     assert not scene.optix_mesh.intersect_any(torch.cat([oo[ok].float(), od[ok].float()], 1)).any()
+
+
+@pytest.mark.parametrize("name", ["hand_r64_v5", "hand_r128_v41"])
+def test_stepwise_methods_vs_golden(Render, hand, name):
+    """Scene.Dintersect / refract_ray / trace2 / project_vert (the reference's internal methods, DiffRender.py:481-546)
+    bounce by bounce against the reference's own intermediate values."""
+    g = golden(name)
+    res = int(g["res"])
+    Render.resx = Render.resy = res
+    Render.intIOR = float(g["ior"])
+    o, d, _, _ = fixture_view(g)
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+    V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    ray = Render.Ray(o.cuda(), d.cuda())
+    hit1, hitted = scene.Dintersect(ray)
+    assert isinstance(hit1, Render.Intersection) and int(hitted.sum()) == int(g["hit1_count"]) == len(hit1)
+    np.testing.assert_array_equal(hit1.ray.ray_ind.cpu().numpy(), g["b1_ind"])
+    np.testing.assert_array_equal(hit1.faces_ind.cpu().numpy(), g["b1_face"])
+    for key, val in (("b1_u", hit1.u), ("b1_v", hit1.v), ("b1_t", hit1.t)):
+        np.testing.assert_allclose(val.detach().cpu().numpy(), g[key], rtol=1e-10, atol=1e-12)
+    refracted, inside = scene.refract_ray(hit1)
+    np.testing.assert_allclose(hit1.n.detach().cpu().numpy(), g["b1_n"], rtol=1e-10, atol=1e-12)      # flipped in place where leaving
+    np.testing.assert_array_equal(refracted.cpu().numpy(), g["b1_refracted"])
+    np.testing.assert_allclose(inside.origin.detach().cpu().numpy(), g["b1_new_o"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(inside.direction.detach().cpu().numpy(), g["b1_new_d"], rtol=1e-10, atol=1e-12)
+    # both bounces, then the same loss as through the fused pipeline: values and vertex gradient agree
+    out = scene.trace2(ray)
+    occluded = scene.optix_intersect(out)[1]
+    np.testing.assert_array_equal(occluded.cpu().numpy(), g["occluded"])
+    keep = torch.logical_not(occluded)
+    np.testing.assert_array_equal(out.ray_ind[keep].cpu().numpy(), g["valid_ind"])
+    np.testing.assert_allclose(out.origin[keep].detach().cpu().numpy(), g["out_ori"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(out.direction[keep].detach().cpu().numpy(), g["out_dir"], rtol=1e-10, atol=1e-12)
+    rng = np.random.default_rng(int(g["lin_seed"]))
+    w_ori = torch.tensor(rng.standard_normal((res * res, 3)), device="cuda")
+    w_dir = torch.tensor(rng.standard_normal((res * res, 3)), device="cuda")
+    idx = out.ray_ind[keep]
+    lin = (out.origin[keep] * w_ori[idx]).sum() + (out.direction[keep] * w_dir[idx]).sum()
+    assert lin.item() == pytest.approx(float(g["lin"]), rel=1e-10)
+    lin.backward()
+    ref = g["grad_lin"]
+    np.testing.assert_allclose(V.grad.cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    # project_vert: truncation towards zero of K R [V|1]
+    cam = tuple(torch.tensor(g[k], dtype=torch.float64, device="cuda") for k in ("R", "K", "Rinv", "Kinv"))
+    pix = scene.project_vert(cam, V.detach())
+    hom = np.concatenate([hand.vertices, np.ones((len(hand.vertices), 1))], 1)
+    c = g["K"] @ (g["R"] @ hom.T)[:3]
+    np.testing.assert_array_equal(pix.cpu().numpy(), np.trunc(c[:2] / c[2]).T.astype(np.int64))
