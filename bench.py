@@ -318,9 +318,28 @@ def main():
         step(False)
         prof2 = scene.optix_mesh.profile_read()
         tstats = scene.optix_mesh.trace_stats()
+    # and K more untimed steps with the two internal pipelines serialised on one stream (profile level 3): every kernel
+    # timed ALONE.  In the timed region the HBM-bound k_cull of one sub-batch overlaps the latency-bound k_trace of the
+    # other, which makes the step faster and each of the two kernels look slower.
+    prof_iso = None
+    if not args.no_extras:
+        scene.optix_mesh.profile_enable(3)
+        step(False)
+        scene.optix_mesh.profile_read()
+        for _ in range(args.steps):
+            step(False)
+        prof_iso = scene.optix_mesh.profile_read()
     scene.optix_mesh.profile_enable(0)
     if rank == 0:
         out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world)
+        if prof_iso:
+            iso = roofline(prof_iso, args, P, len(my_views), n_verts, n_faces, elapsed, world)
+            dom = out["roofline"]["kernel"][2:]
+            out["roofline"]["isolated"] = {
+                "kernel": "k_" + dom, "achieved": iso["stages"][dom]["alg_GBps"], "frac": round(iso["stages"][dom]["alg_GBps"] / HBM_PEAK_GBS, 5),
+                "avg_launch_ms": iso["stages"][dom]["avg_launch_ms"],
+                "stages_avg_launch_ms": {k: v["avg_launch_ms"] for k, v in iso["stages"].items()},
+                "note": "same K steps, untimed, with the internal pipelines serialised on one stream: each kernel's duration and rate when it has the GPU to itself"}
         for k, (ws, ls, rf, mx) in tstats.items():
             if ws and k in out["roofline"]["stages"]:
                 out["roofline"]["stages"][k].update({"node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),

@@ -107,6 +107,7 @@ struct drt_scene {
     // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream
     bool prof_on = false;
     bool prof_stats = false;                  // level 2: k_trace also accumulates visit statistics (adds contended atomics)
+    bool prof_serial = false;                 // level 3: sub-batches run on ONE internal stream, so that each kernel is timed alone
     std::vector<hipEvent_t> prof_ev;          // pool, used pairwise
     std::vector<int> prof_stage;              // stage id of pair k
     size_t prof_used = 0;                     // events handed out since the last read
@@ -1741,6 +1742,7 @@ static Plan plan_call(const drt_scene* s, int64_t n_rays, int tile_w) {
     count = (n_rays + size - 1) / size;
     Plan pl;
     pl.size = size; pl.count = (int)count; pl.streams = count < s->n_sub ? (int)count : s->n_sub;
+    if (s->prof_serial) pl.streams = 1;     // measurement mode: the same sub-batches, one after the other on one stream
     return pl;
 }
 
@@ -1926,7 +1928,8 @@ int drt_profile_enable(drt_scene_t* s, int on) {
         HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(unsigned long long) * (kProfStages + 12)));
     }
     s->prof_on = on != 0;
-    s->prof_stats = on >= 2;
+    s->prof_stats = on == 2;
+    s->prof_serial = on == 3;
     return DRT_OK;
 }
 

@@ -159,7 +159,8 @@ class optix_mesh:
 
     def profile_enable(self, on=1):
         """1: bracket every pipeline kernel with hipEvents on its launch stream (bench.py's live timing);
-        2: also collect traversal statistics (perturbs timing); 0: off."""
+        2: also collect traversal statistics (perturbs timing); 3: timers with the pipelines serialised on one internal
+        stream (each kernel timed alone); 0: off."""
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().drt_profile_enable(self._h, int(on)))
 

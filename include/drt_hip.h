@@ -201,7 +201,9 @@ void drt_mesh_buf_free(drt_mesh_buf_t* b);
 
 /* ---- measurement (bench.py's live per-kernel timing) --------------------------------------------
  * When enabled (on = 1; on = 2 additionally collects the traversal statistics below, which perturbs
- * timing) every kernel of the build / forward / backward / fused pipelines is bracketed by a
+ * timing; on = 3 runs the sub-batches of a call one after the other on ONE internal stream instead of two, so that
+ * every kernel is timed alone -- the default overlaps the HBM-bound and the latency-bound kernels of two sub-batches,
+ * which stretches both) every kernel of the build / forward / backward / fused pipelines is bracketed by a
  * hipEvent pair on the stream it is launched on.  drt_profile_read synchronises that stream and
  * returns, per stage, the summed kernel time in ms, the number of launches and the number of work
  * items (rays in the stage's input queue) since the previous read.  Arrays have DRT_PROFILE_STAGES
