@@ -21,7 +21,7 @@ import torch
 from . import captured_data, diffrender as Render, mesh_io, metrics, optim, views
 
 
-def run(HyperParams, data_path="./data/", result_path="./result/", capture=None, res=None, fused=True, output=True, device=0):
+def run(HyperParams, data_path="./data/", result_path="./result/", capture=None, res=None, fused=True, output=True, device=0, n_views=72):
     name = HyperParams["name"]
     hull_path = os.path.join(data_path, f"{name}_vh.ply")
     scan_path = os.path.join(data_path, f"{name}_scan.ply")
@@ -35,7 +35,7 @@ def run(HyperParams, data_path="./data/", result_path="./result/", capture=None,
         Render.resx, Render.resy = resx, resy
         gt = scan_scene if scan_scene is not None else Render.Scene(views.displaced_ground_truth(scene.mesh, 0.5, 0), device)
         center, extent = views.mesh_frame(gt.mesh.vertices)
-        data = captured_data.SyntheticData(gt, center, extent, resx, resy, num_view=HyperParams["num_view"], name=name)
+        data = captured_data.SyntheticData(gt, center, extent, resx, resy, num_view=min(HyperParams["num_view"], n_views), n_total=n_views, name=name)
     report = {"name": name, "resx": data.resx, "resy": data.resy, "views": data.n_total, "hull_faces": int(scene.faces.shape[0])}
     if scan_scene is not None:
         report["hull_to_scan"] = metrics.hausdorff(scene, scan_scene)
@@ -63,7 +63,8 @@ def main(argv=None):
     ap.add_argument("--res", type=int, default=512, help="resolution of the synthetic capture")
     ap.add_argument("--passes", type=int, default=optim.HyperParams["Pass"])
     ap.add_argument("--iters", type=int, default=optim.HyperParams["Iters"])
-    ap.add_argument("--num-view", type=int, default=optim.HyperParams["num_view"])
+    ap.add_argument("--num-view", type=int, default=optim.HyperParams["num_view"], help="views the refraction loss cycles through")
+    ap.add_argument("--views", type=int, default=72, help="views of the synthetic capture (the real captures have 72)")
     ap.add_argument("--ior", type=float, default=optim.HyperParams["IOR"])
     ap.add_argument("--dropin", action="store_true", help="use the reference-shaped (unfused) loss terms")
     ap.add_argument("--seed", type=int, default=0)
@@ -71,7 +72,7 @@ def main(argv=None):
     import numpy as np
     np.random.seed(a.seed)
     hp = dict(optim.HyperParams, name=a.name, Pass=a.passes, Iters=a.iters, num_view=a.num_view, IOR=a.ior)
-    _, report = run(hp, a.data_path, a.result_path, a.capture, a.res, fused=not a.dropin)
+    _, report = run(hp, a.data_path, a.result_path, a.capture, a.res, fused=not a.dropin, n_views=a.views)
     print(json.dumps(report))
 
 
