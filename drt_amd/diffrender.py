@@ -145,6 +145,8 @@ class _RayLoss(torch.autograd.Function):
         g, rows, n_rows = ctx.saved_tensors
         if g is None:
             return None, None, None, None, None
+        if g.numel() == 0:                       # no rays: an empty tensor has no storage to pass down
+            return None, g, None, None, None
         # scale only the contributing rows (a few % of the rays) instead of streaming the dense tensor again;
         # out_ori is detached in the reference's loss (optim.py:100): no gradient for it
         sc = g_loss.detach().to(torch.float64).reshape(1).contiguous()

@@ -600,3 +600,42 @@ def test_stepwise_methods_vs_golden(Render, hand, name):
     hom = np.concatenate([hand.vertices, np.ones((len(hand.vertices), 1))], 1)
     c = g["K"] @ (g["R"] @ hom.T)[:3]
     np.testing.assert_array_equal(pix.cpu().numpy(), np.trunc(c[:2] / c[2]).T.astype(np.int64))
+
+
+def test_pipeline_ragged_and_empty_inputs(Render, hand):
+    """render_transparent / ray_loss / the fused loss on ray counts that are not multiples of anything (and zero):
+    every ray is independent, so a prefix of a view must give the prefix of the view's result, bit for bit."""
+    g = golden("hand_r64_v23")
+    res = int(g["res"])
+    Render.resx = Render.resy = res
+    Render.intIOR = float(g["ior"])
+    o, d, sp, valid = fixture_view(g)
+    o, d, sp, valid = o.cuda(), d.cuda(), sp.cuda(), valid.cuda()
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+    V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda")
+    scene.update_verticex(V)
+    with torch.no_grad():
+        full = scene.render_transparent(o, d)
+    first_valid = int(torch.nonzero(full[2][:, 0])[0])
+    for n in (0, 1, 63, 257, 1000, first_valid + 1, res * res - 1):
+        Vn = V.clone().requires_grad_(True)
+        scene.update_verticex(Vn)
+        oo, od, m = scene.render_transparent(o[:n].contiguous(), d[:n].contiguous())
+        assert oo.shape == (n, 3) and od.shape == (n, 3) and m.shape == (n, 3) and m.dtype == torch.bool
+        assert torch.equal(oo.detach(), full[0][:n]) and torch.equal(od.detach(), full[1][:n]) and torch.equal(m, full[2][:n])
+        loss = Render.ray_loss(oo, od, m, sp[:n].contiguous(), valid[:n].contiguous())
+        fused = scene.ray_loss_fused(o[:n].contiguous(), d[:n].contiguous(), sp[:n].contiguous(), valid[:n].contiguous())
+        assert fused.item() == pytest.approx(loss.item(), rel=1e-12, abs=1e-300)
+        if n == 0 or not bool((m[:, 0] & valid[:n]).any()):
+            assert loss.item() == 0.0
+        loss.backward()
+        grad = Vn.grad.clone()
+        assert torch.isfinite(grad).all()
+        Vf = V.clone().requires_grad_(True)
+        scene.update_verticex(Vf)
+        scene.ray_loss_fused(o[:n].contiguous(), d[:n].contiguous(), sp[:n].contiguous(), valid[:n].contiguous()).backward()
+        assert torch.allclose(Vf.grad, grad, rtol=1e-9, atol=1e-12 * max(1.0, grad.abs().max().item()))
+    # a loss with no target at all
+    scene.update_verticex(V.clone().requires_grad_(True))
+    oo, od, m = scene.render_transparent(o, d)
+    assert Render.ray_loss(oo, od, m, sp, torch.zeros_like(valid)).item() == 0.0
