@@ -639,3 +639,43 @@ def test_pipeline_ragged_and_empty_inputs(Render, hand):
     scene.update_verticex(V.clone().requires_grad_(True))
     oo, od, m = scene.render_transparent(o, d)
     assert Render.ray_loss(oo, od, m, sp, torch.zeros_like(valid)).item() == 0.0
+
+
+def test_silhouette_loss_edge_cases(Render, hand):
+    """Fused silhouette loss over more views than one launch takes (16), with an off-screen camera among them, equals the
+    sum of the drop-in per-view terms; zero views and zero query points are fine."""
+    res = 96
+    Render.resx = Render.resy = res
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+    V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda")
+    c, ext = views.mesh_frame(hand.vertices)
+    cams = views.turntable_cameras(c, ext, 19, res, res)
+    rng = np.random.default_rng(2)
+    vs = []
+    for k, cam in enumerate(cams):
+        R, K, Rinv, Kinv = [np.array(a) for a in cam]
+        if k == 7:                                   # principal point far off: every sample falls outside the image
+            K = K.copy(); K[0, 2] += 10 * res; Kinv = np.linalg.inv(K)
+        cam_t = tuple(torch.tensor(a, dtype=torch.float64, device="cuda") for a in (R, K, Rinv, Kinv))
+        origin3 = torch.tensor(Rinv[:3, 3], dtype=torch.float64, device="cuda")
+        soft = torch.tensor(rng.random(res * res), dtype=torch.float64, device="cuda")
+        vs.append((cam_t, origin3, soft))
+    Va = V.clone().requires_grad_(True)
+    scene.update_verticex(Va)
+    total = scene.vh_loss_fused_views(vs)
+    total.backward()
+    Vb = V.clone().requires_grad_(True)
+    scene.update_verticex(Vb)
+    ref = torch.zeros((), dtype=torch.float64, device="cuda")
+    for k, (cam_t, origin3, soft) in enumerate(vs):
+        edges = scene.silhouette_edge(origin3)
+        pix, out = scene.primary_visibility(edges, cam_t, origin3, detach_depth=True)
+        if k == 7:
+            assert pix.shape[0] == 0 and out.shape[0] == 0
+        ref = ref + (soft.view(res, res)[pix[:, 1], pix[:, 0]] - out).abs().sum()
+    ref.backward()
+    assert total.item() == pytest.approx(ref.item(), rel=1e-12)
+    assert torch.allclose(Va.grad, Vb.grad, rtol=1e-9, atol=1e-12 * Vb.grad.abs().max().item())
+    assert scene.vh_loss_fused_views([]).item() == 0.0
+    dist, face, closest = scene.optix_mesh.closest_point(torch.zeros((0, 3), dtype=torch.float64, device="cuda"), want_point=True)
+    assert dist.shape == (0,) and face.shape == (0,) and closest.shape == (0, 3)
