@@ -207,3 +207,19 @@ def test_tracer_edge_cases():
     # un-normalised direction: t scales inversely (silhouette probes use such rays, DiffRender.py:222-224)
     T2, _ = orc.trace_closest(faces, verts, np.array([[0.2, 0.2, 1, 0, 0, -4]], np.float32))
     assert T2[0] == 0.25
+
+
+def test_stepwise_hit_terms_vs_golden(hand):
+    """drt_amd.stepwise.hit_point_terms (what Scene.Dintersect computes per hit) on the CPU against the reference's
+    own u, v, t, n of the first bounce."""
+    from drt_amd import stepwise
+    g = golden("hand_r128_v5")
+    o, d, _, _ = fixture_view(g)
+    ind, face = torch.tensor(g["b1_ind"]), torch.tensor(g["b1_face"])
+    tri = torch.tensor(hand.vertices)[torch.tensor(hand.faces)[face]]
+    u, v, t, n = stepwise.hit_point_terms(o[ind], d[ind], tri)
+    # the fixture's normals are stored after refract_ray flipped the leaving ones: compare up to that sign
+    sign = torch.sign((n * torch.tensor(g["b1_n"])).sum(1, keepdim=True))
+    for got, key in ((u, "b1_u"), (v, "b1_v"), (t, "b1_t"), (n * sign, "b1_n")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-10, atol=1e-12)
+    assert (u >= -1e-12).all() and (v >= -1e-12).all() and (u + v <= 1 + 1e-12).all() and (t > 0).all()
