@@ -776,12 +776,20 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
     st.fast = &lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast; st.sp = 0; st.overflow = false;
     const unsigned n = *n_ptr;
     const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * kPathWaves + (threadIdx.x >> 6), n_waves = gridDim.x * kPathWaves;
-    // Work assignment without atomics: the list is cut into groups of 64 consecutive rays (one 8x8 screen
-    // tile when k_cull ordered it so) and wave w owns groups w, w + n_waves, w + 2 n_waves, ...: coherent
-    // within a group, statistically balanced across waves.  `taken` counts the rays this wave has started.
+    // Work assignment without atomics, XCD-aware: workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
+    // b % 8), and every XCD has its own L2.  The list -- in tile order, so neighbouring entries walk the same part of the
+    // tree -- is therefore cut into 8 contiguous parts, one per XCD, and only WITHIN its part are the groups of 64
+    // consecutive rays interleaved over that XCD's waves (wave w owns groups w, w + W, w + 2W, ... of the part: coherent
+    // within a group, statistically balanced across waves).  `taken` counts the rays this wave has started.
+    constexpr unsigned kXcd = 8;
     const unsigned n_groups = (n + 63u) >> 6;
-    const unsigned my_groups = wave < n_groups ? (n_groups - wave + n_waves - 1) / n_waves : 0u;
+    const bool split = gridDim.x % kXcd == 0 && n_groups >= 64u * kXcd;
+    const unsigned xcd = split ? blockIdx.x % kXcd : 0u, parts = split ? kXcd : 1u;
+    const unsigned wave = (split ? blockIdx.x / kXcd : blockIdx.x) * kPathWaves + (threadIdx.x >> 6);
+    const unsigned n_waves = (split ? gridDim.x / kXcd : gridDim.x) * kPathWaves;
+    const unsigned part_lo = (unsigned)((unsigned long long)n_groups * xcd / parts), part_hi = (unsigned)((unsigned long long)n_groups * (xcd + 1) / parts);
+    const unsigned part_groups = part_hi - part_lo;
+    const unsigned my_groups = wave < part_groups ? (part_groups - wave + n_waves - 1) / n_waves : 0u;
     const unsigned my_rays = my_groups << 6;      // upper bound; indices >= n are skipped
     unsigned taken = 0;
     int32_t slot = -1;
@@ -792,7 +800,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         if (idle != 0 && taken < my_rays && (__popcll(idle) >= refill_min || idle == ~0ull)) {
             if (slot < 0) {
                 const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-                const unsigned k = (((j >> 6) * n_waves + wave) << 6) | (j & 63u);
+                const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
                 if (j < my_rays && k < n) {
                     const float* e = rays + 6 * (int64_t)k;
                     trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
