@@ -52,12 +52,14 @@ def _tracer_lib():
         return _LIB
     so = os.path.join(_HERE, "_build", "liboracle_tracer.so")
     src = os.path.join(_HERE, "tracer.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "bvh_tracer.c"))):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     lib = ctypes.CDLL(so)
     lib.oracle_trace_closest.restype = ctypes.c_int
     lib.oracle_trace_closest.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    lib.oracle_trace_closest_bvh.restype = ctypes.c_int
+    lib.oracle_trace_closest_bvh.argtypes = lib.oracle_trace_closest.argtypes
     lib.oracle_num_threads.restype = ctypes.c_int
     _LIB = lib
     return lib
@@ -68,8 +70,11 @@ def num_threads():
 
 
 # --------------------------------------------------------------------------- tracer
-def trace_closest(faces_i32, verts_f32, rays_f32):
-    """Brute-force closest hit. faces i32 [F,3], verts f32 [V,3], rays f32 [N,6] -> (T f32 [N], ID i32 [N])."""
+USE_BVH = False      # bench.py's second cpu_baseline figure flips this: same contract, tree instead of the loop over every face
+
+
+def trace_closest(faces_i32, verts_f32, rays_f32, bvh=None):
+    """Closest hit (brute force; oracle/bvh_tracer.c when ``bvh``/USE_BVH). faces i32 [F,3], verts f32 [V,3], rays f32 [N,6] -> (T f32 [N], ID i32 [N])."""
     faces = np.ascontiguousarray(faces_i32, dtype=np.int32)
     verts = np.ascontiguousarray(verts_f32, dtype=np.float32)
     rays = np.ascontiguousarray(rays_f32, dtype=np.float32)
@@ -77,8 +82,8 @@ def trace_closest(faces_i32, verts_f32, rays_f32):
     T = np.empty(n, dtype=np.float32)
     ID = np.empty(n, dtype=np.int32)
     if n:
-        rc = _tracer_lib().oracle_trace_closest(faces.ctypes.data, faces.shape[0], verts.ctypes.data, verts.shape[0],
-                                                rays.ctypes.data, n, T.ctypes.data, ID.ctypes.data)
+        fn = _tracer_lib().oracle_trace_closest_bvh if (USE_BVH if bvh is None else bvh) else _tracer_lib().oracle_trace_closest
+        rc = fn(faces.ctypes.data, faces.shape[0], verts.ctypes.data, verts.shape[0], rays.ctypes.data, n, T.ctypes.data, ID.ctypes.data)
         if rc != 0:
             raise MemoryError("oracle tracer allocation failed")
     return T, ID

@@ -223,3 +223,25 @@ def test_stepwise_hit_terms_vs_golden(hand):
     for got, key in ((u, "b1_u"), (v, "b1_v"), (t, "b1_t"), (n * sign, "b1_n")):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-10, atol=1e-12)
     assert (u >= -1e-12).all() and (v >= -1e-12).all() and (u + v <= 1 + 1e-12).all() and (t > 0).all()
+
+
+def test_oracle_bvh_tracer_equals_bruteforce(hand):
+    """oracle/bvh_tracer.c (the cpu_baseline's second figure) gives bit-identical T and ID, including rays with zero
+    direction components and rays from inside the mesh; and the golden face ids."""
+    f32, v32 = hand.faces.astype(np.int32), hand.vertices.astype(np.float32)
+    g = golden("hand_r128_v23")
+    o, d, _, _ = fixture_view(g)
+    cam = np.concatenate([o.numpy(), d.numpy()], 1).astype(np.float32)
+    rng = np.random.default_rng(9)
+    c, ext = views.mesh_frame(hand.vertices)
+    extra = np.concatenate([rng.uniform(-0.6, 0.6, (4000, 3)) * ext + c, rng.standard_normal((4000, 3)) * rng.uniform(0.05, 20, (4000, 1))], 1).astype(np.float32)
+    extra[:200, 3] = 0; extra[200:400, 4] = 0; extra[400:600, 5] = 0; extra[600:700, 3:5] = 0
+    rays = np.concatenate([cam, extra])
+    T0, I0 = orc.trace_closest(f32, v32, rays, bvh=False)
+    T1, I1 = orc.trace_closest(f32, v32, rays, bvh=True)
+    assert np.array_equal(I0, I1) and np.array_equal(T0, T1)
+    hit = np.flatnonzero(I0[:len(cam)] >= 0)
+    assert np.array_equal(hit, g["b1_ind"]) and np.array_equal(I1[hit], g["b1_face"])
+    assert (I0[len(cam):] >= 0).mean() > 0.2
+    Te, Ie = orc.trace_closest(np.zeros((0, 3), np.int32), v32, rays[:5], bvh=True)
+    assert (Ie == -1).all() and (Te == -1).all()
