@@ -140,3 +140,12 @@ int oracle_trace_closest_bvh(const int32_t *faces, int64_t n_faces, const float 
     free(b.order); free(b.nodes);
     return 0;
 }
+
+/* thread count of the following OpenMP regions of this library (both tracers) */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -69,7 +69,14 @@ def num_threads():
     return int(_tracer_lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    """OpenMP threads of the C tracers (PyTorch's own pool: torch.set_num_threads)."""
+    _tracer_lib().oracle_set_num_threads(int(n))
+
+
 # --------------------------------------------------------------------------- tracer
+TRACER_THREADS = None  # None: whatever OpenMP picks; bench.py sets all cores here and keeps PyTorch's pool small (below)
+TORCH_THREADS = None   # restored after every tracer call when TRACER_THREADS is set
 USE_BVH = False      # bench.py's second cpu_baseline figure flips this: same contract, tree instead of the loop over every face
 
 
@@ -83,7 +90,13 @@ def trace_closest(faces_i32, verts_f32, rays_f32, bvh=None):
     ID = np.empty(n, dtype=np.int32)
     if n:
         fn = _tracer_lib().oracle_trace_closest_bvh if (USE_BVH if bvh is None else bvh) else _tracer_lib().oracle_trace_closest
+        if TRACER_THREADS:
+            # PyTorch and this library may share one OpenMP runtime (one thread-count setting): the C tracer scales to every
+            # core, PyTorch's small float64 ops collapse with 256 threads (30 s instead of 0.14 s for a 512x512 view)
+            set_num_threads(TRACER_THREADS)
         rc = fn(faces.ctypes.data, faces.shape[0], verts.ctypes.data, verts.shape[0], rays.ctypes.data, n, T.ctypes.data, ID.ctypes.data)
+        if TRACER_THREADS and TORCH_THREADS:
+            torch.set_num_threads(TORCH_THREADS)
         if rc != 0:
             raise MemoryError("oracle tracer allocation failed")
     return T, ID
