@@ -237,7 +237,7 @@ def main():
         grad = torch.nan_to_num(grad, nan=0.0, posinf=None, neginf=None)
         return grad.clamp_(-1.0, 1.0)
 
-    opt = torch.optim.SGD([parameter], lr=0.1, momentum=0.95, nesterov=True)
+    opt = torch.optim.SGD([parameter], lr=0.1, momentum=0.95, nesterov=True, foreach=False)   # see drt_amd.optim.setup_opt
     w_ray = 40 * 217.5 / res / res             # reference optim.py:127 with config.py defaults
 
     def step(record):

@@ -1383,8 +1383,15 @@ __global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const doub
     Stack st = make_stack(lds, c);
     const unsigned n = *count;
     double acc = 0.0;
-    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
-        const uint32_t item = list[k], view = item / n_edges;
+    // Two lanes per edge, one probe ray each: the rays graze the silhouette and take a few hundred node visits, and with
+    // only a few thousand edges per view the kernel lasts as long as its longest lane -- tracing the two probes of an
+    // edge one after the other in one lane doubled that.
+    constexpr unsigned kPairs = kTraceBlock / 2;
+    const int side = threadIdx.x & 1;
+    for (unsigned base = blockIdx.x * kPairs; base < n; base += gridDim.x * kPairs) {       // block-uniform trip count (shuffles below)
+        const unsigned k = base + (threadIdx.x >> 1);
+        const bool live = k < n;
+        const uint32_t item = live ? list[k] : 0u, view = item / n_edges;
         const int64_t e = item - view * n_edges;
         const Camera cm = *reinterpret_cast<const Camera*>(vw.cam[view]);
         const double* o3 = vw.origin[view];
@@ -1395,9 +1402,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const doub
         project_endpoint(cm, load_d3(verts, ib), pb);
         EdgeSample s;
         edge_sample(cm, pa, pb, o, s);
-        const bool hu = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_up), st).face >= 0;
-        const bool hl = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_lo), st).face >= 0;
-        const double f = (hu ? 1.0 : 0.0) - (hl ? 1.0 : 0.0);
+        const int mine = live && traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(side == 0 ? s.dir_up : s.dir_lo), st).face >= 0 ? 1 : 0;
+        const int other = __shfl_xor(mine, 1);
+        if (!live || side != 0) continue;                         // the even lane of the pair finishes the edge
+        const double f = (double)mine - (double)other;           // hit(up) - hit(lo)
         if (f == 0.0) continue;                                   // |f| > 1e-5 (DiffRender.py:244)
         const int64_t x = (int64_t)s.midx, y = (int64_t)s.midy;   // trunc, like Tensor.to(torch.long)
         if (!(x < resx - 1 && y < resy - 1 && x >= 0 && y >= 0)) continue;   // out of view (DiffRender.py:478)

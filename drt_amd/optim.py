@@ -120,7 +120,9 @@ def setup_opt(scene, lr, HyperParams, hook=True):
     parameter = torch.zeros(init_vertices.shape, dtype=Float, requires_grad=True, device=init_vertices.device)
     if hook:
         parameter.register_hook(limit_hook)
-    opt = torch.optim.SGD([parameter], lr=lr, momentum=HyperParams["momentum"], nesterov=True)
+    # foreach=False: the multi-tensor kernels of the default implementation take ~35 us each for this ONE small tensor
+    # (four per step: 0.14 ms of a 1.2 ms iteration); the single-tensor path does the same arithmetic in ~5 us ops
+    opt = torch.optim.SGD([parameter], lr=lr, momentum=HyperParams["momentum"], nesterov=True, foreach=False)
     return init_vertices, parameter, opt
 
 
