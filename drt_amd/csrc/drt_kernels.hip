@@ -103,7 +103,9 @@ struct drt_scene {
     int sub_per_stream = 1;        // sub-batches dealt to each stream (when the call is large enough)
     int64_t min_sub_rays = 1 << 24;   // do not cut a call into sub-batches smaller than this
     hipEvent_t fork_ev = nullptr;
-    unsigned* vcount = nullptr;    // [1] valid rays of the whole call
+    unsigned* vcount = nullptr;    // [0] valid rays of the whole call, [1] silhouette items of drt_vh_loss_fused
+    uint32_t* vh_list = nullptr;   // (view, edge) items of drt_vh_loss_fused: its own buffer, so that the call may run on
+    int64_t vh_cap = 0;            //   another stream than a pipeline call (which owns the Sub workspaces)
     // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream
     bool prof_on = false;
     bool prof_stats = false;                  // level 2: k_trace also accumulates visit statistics (adds contended atomics)
@@ -1575,6 +1577,7 @@ void drt_destroy(drt_scene_t* s) {
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     (void)hipFree(s->vcount);
+    (void)hipFree(s->vh_list);
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
     for (auto& e : s->prof_ev) (void)hipEventDestroy(e);
     (void)hipFree(s->prof_counts);
@@ -2056,7 +2059,12 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
     if (n_edges == 0 || n_views == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_e2f || !d_cameras || !d_origins || !d_soft_masks || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    drt_scene::Sub& w = s->sub[0];      // list workspace; safe: every pipeline call joins its internal streams before returning
+    const int64_t need = n_edges * std::min(kVhViews, n_views);
+    if (need > s->vh_cap) {
+        (void)hipFree(s->vh_list); s->vh_list = nullptr; s->vh_cap = 0;
+        HIP_TRY(hipMalloc(&s->vh_list, sizeof(uint32_t) * need));
+        s->vh_cap = need;
+    }
     for (int v0 = 0; v0 < n_views; v0 += kVhViews) {
         const int nv = std::min(kVhViews, n_views - v0);
         VhViews vw{};
@@ -2064,11 +2072,9 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
             if (!d_cameras[v0 + k] || !d_origins[v0 + k] || !d_soft_masks[v0 + k]) return fail(DRT_E_INVALID, "null pointer argument");
             vw.cam[k] = d_cameras[v0 + k]; vw.origin[k] = d_origins[v0 + k]; vw.soft[k] = d_soft_masks[v0 + k];
         }
-        int rc = ensure_queues(w, n_edges * nv, false);
-        if (rc) return rc;
         HIP_TRY(hipMemsetAsync(s->vcount + 1, 0, sizeof(unsigned), st));
-        k_vh_cull<<<grid_for(n_edges * nv, kPathBlock, 4 * s->n_cu), kPathBlock, 0, st>>>(d_verts, d_e2f, n_edges, nv, vw, reinterpret_cast<uint32_t*>(w.q_idx[0]), s->vcount + 1);
-        k_vh_fused<<<4 * s->n_cu, kTraceBlock, 0, st>>>(trace_ctx(s), d_verts, d_edges, (uint32_t)n_edges, reinterpret_cast<const uint32_t*>(w.q_idx[0]), s->vcount + 1,
+        k_vh_cull<<<grid_for(n_edges * nv, kPathBlock, 4 * s->n_cu), kPathBlock, 0, st>>>(d_verts, d_e2f, n_edges, nv, vw, s->vh_list, s->vcount + 1);
+        k_vh_fused<<<4 * s->n_cu, kTraceBlock, 0, st>>>(trace_ctx(s), d_verts, d_edges, (uint32_t)n_edges, s->vh_list, s->vcount + 1,
                                                         vw, resx, resy, detach_depth, d_loss, d_grad_verts);
     }
     HIP_TRY(hipGetLastError());
