@@ -45,6 +45,24 @@ __global__ void __launch_bounds__(256, 8) k_stream(const double* __restrict__ o,
     if (acc == 12345.678) *sink = acc;
 }
 
+// R4: four rays per thread (all loads issued before the first use), for LOW-occupancy launches: can a streaming pass that
+// leaves most wave slots to a co-running latency-bound kernel still reach the HBM rate?
+__global__ void __launch_bounds__(256) k_stream4(const double* __restrict__ o, const double* __restrict__ d, int64_t n, double* sink) {
+    double acc = 0;
+    for (int64_t base = blockIdx.x * 1024ll; base < n; base += gridDim.x * 1024ll) {
+        double v[24];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = base + r * 256 + threadIdx.x;
+            v[6 * r + 0] = o[3 * i]; v[6 * r + 1] = o[3 * i + 1]; v[6 * r + 2] = o[3 * i + 2];
+            v[6 * r + 3] = d[3 * i]; v[6 * r + 4] = d[3 * i + 1]; v[6 * r + 5] = d[3 * i + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) acc += v[k];
+    }
+    if (acc == 12345.678) *sink = acc;
+}
+
 int main() {
     const int64_t n = 36ll * 1024 * 1024;     // one sub-batch of the bench (36 views of 1024 x 1024)
     double *o, *d, *oo, *od, *sink; uint8_t* mask; int32_t *f1, *f2;
@@ -67,5 +85,21 @@ int main() {
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep) printf("grid %6d  %-26s %7.3f ms  %6.2f TB/s\n", grid, names[mode], ms, bytes[mode] * n / ms / 1e9);
             }
+    for (int grid : {256, 512, 1024, 2048})
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            k_stream4<<<grid, 256>>>(o, d, n, sink);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep) printf("grid %6d  R4 four rays per thread    %7.3f ms  %6.2f TB/s\n", grid, ms, 48.0 * n / ms / 1e9);
+        }
+    for (int grid : {256, 512, 1024})
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            k_stream<0><<<grid, 256>>>(o, d, n, oo, od, mask, f1, f2, sink);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep) printf("grid %6d  R1 one ray per thread      %7.3f ms  %6.2f TB/s\n", grid, ms, 48.0 * n / ms / 1e9);
+        }
     return 0;
 }
