@@ -144,19 +144,19 @@ DRT_HD void slab_node4q(F4 c0, F4 c1, F4 c2, f3 inv, f3 oi, float best_t, float 
     const float bx = fmaf(c0.x, inv.x, oi.x), by = fmaf(c0.y, inv.y, oi.y), bz = fmaf(c0.z, inv.z, oi.z);
     const uint32_t qlox = f32_bits(c1.z), qloy = f32_bits(c1.w), qloz = f32_bits(c2.x);
     const uint32_t qhix = f32_bits(c2.y), qhiy = f32_bits(c2.z), qhiz = f32_bits(c2.w);
+    // the near and far planes of every child follow from the sign of the direction (ax has the sign of inv.x: scales are
+    // positive, safe_inv never returns 0): six selects per node instead of a min/max pair per child and axis
+    const uint32_t nx = ax >= 0.0f ? qlox : qhix, fx = ax >= 0.0f ? qhix : qlox;
+    const uint32_t ny = ay >= 0.0f ? qloy : qhiy, fy = ay >= 0.0f ? qhiy : qloy;
+    const uint32_t nz = az >= 0.0f ? qloz : qhiz, fz = az >= 0.0f ? qhiz : qloz;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < 4; ++k) {
-        float t0 = fmaf(q_byte(qlox, k), ax, bx), t1 = fmaf(q_byte(qhix, k), ax, bx);
-        float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
-        t0 = fmaf(q_byte(qloy, k), ay, by); t1 = fmaf(q_byte(qhiy, k), ay, by);
-        tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
-        t0 = fmaf(q_byte(qloz, k), az, bz); t1 = fmaf(q_byte(qhiz, k), az, bz);
-        tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
-        tmin = fmaxf(tmin, 0.0f);
-        t[k] = tmin;
-        h[k] = tmin <= fminf(tmax, best_t);
+        const float tn = fmaxf(fmaxf(fmaf(q_byte(nx, k), ax, bx), fmaf(q_byte(ny, k), ay, by)), fmaxf(fmaf(q_byte(nz, k), az, bz), 0.0f));
+        const float tf = fminf(fminf(fmaf(q_byte(fx, k), ax, bx), fmaf(q_byte(fy, k), ay, by)), fminf(fmaf(q_byte(fz, k), az, bz), best_t));
+        t[k] = tn;
+        h[k] = tn <= tf;
     }
 }
 
