@@ -1,0 +1,84 @@
+// tools/bvhq/bvhq.cpp -- EXPERIMENT (not product, not test): how many node visits does the traversal of drt_traverse.h
+// need on a binary tree given explicitly (e.g. a SAH build made offline) compared with the Morton LBVH the product builds?
+// Same refit / collapse / quantisation / traversal headers as the kernels; only the binary topology differs.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <numeric>
+#include <vector>
+
+#include "../../drt_amd/csrc/drt_lbvh.h"
+#include "../../drt_amd/csrc/drt_traverse.h"
+
+using namespace drt;
+
+struct Tree {
+    std::vector<Node> nodes; std::vector<Node4Q> wide; std::vector<int32_t> lo, hi; std::vector<TriRec> tris;
+};
+
+static Box refit(Tree& t, int32_t c, const std::vector<Box>& leaf) {      // returns the box of child reference c, fills ranges
+    if (c < 0) return leaf[~c];
+    Node& n = t.nodes[c];
+    const Box a = refit(t, n.child0, leaf), b = refit(t, n.child1, leaf);
+    node_set_child_box(t.nodes[c], 0, a); node_set_child_box(t.nodes[c], 1, b);
+    auto rlo = [&](int32_t x) { return x < 0 ? ~x : t.lo[x]; };
+    auto rhi = [&](int32_t x) { return x < 0 ? ~x : t.hi[x]; };
+    t.lo[c] = std::min(rlo(n.child0), rlo(n.child1)); t.hi[c] = std::max(rhi(n.child0), rhi(n.child1));
+    return box_union(a, b);
+}
+
+extern "C" {
+// order[k] = face in slot k; child0/child1[i] for inner node i (root 0): >= 0 inner, < 0 leaf ~slot.  When child0 == nullptr the
+// tree is the product's: Morton order (order is then an OUTPUT) + Karras hierarchy.
+double bvhq_visits(const int32_t* faces, int64_t n_faces, const float* verts, int64_t n_verts, int32_t* order,
+                   const int32_t* child0, const int32_t* child1, const float* rays, int64_t n_rays, int32_t* ID_out, double* leaf_visits_out) {
+    const int n = (int)n_faces;
+    auto V = [&](int32_t i) { return f3{verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]}; };
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n_verts; ++i) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], verts[3 * i + a]); hi[a] = fmaxf(hi[a], verts[3 * i + a]); }
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    const float pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
+    Tree t;
+    t.nodes.assign(n - 1, Node{}); t.lo.assign(n - 1, 0); t.hi.assign(n - 1, 0); t.wide.assign(n - 1, Node4Q{}); t.tris.resize(n);
+    if (!child0) {
+        const f3 inv{1.0f / ex, 1.0f / ey, 1.0f / ez};
+        std::vector<uint32_t> key(n), idx(n), keys(n);
+        for (int i = 0; i < n; ++i) key[i] = morton30(V(faces[3 * i]), V(faces[3 * i + 1]), V(faces[3 * i + 2]), f3{lo[0], lo[1], lo[2]}, inv);
+        std::iota(idx.begin(), idx.end(), 0u);
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        for (int k = 0; k < n; ++k) { keys[k] = key[idx[k]]; order[k] = (int32_t)idx[k]; }
+        for (int i = 0; i < n - 1; ++i) { int32_t l, r, a, b; lbvh_children(keys.data(), n, i, l, r, a, b); t.nodes[i].child0 = l; t.nodes[i].child1 = r; }
+    } else {
+        for (int i = 0; i < n - 1; ++i) { t.nodes[i].child0 = child0[i]; t.nodes[i].child1 = child1[i]; }
+    }
+    std::vector<Box> leaf(n);
+    for (int k = 0; k < n; ++k) {
+        const int32_t f = order[k];
+        const f3 a = V(faces[3 * f]), b = V(faces[3 * f + 1]), c = V(faces[3 * f + 2]);
+        t.tris[k] = make_tri(a, b, c, f);
+        leaf[k] = box_of_tri(a, b, c, pad);
+    }
+    refit(t, 0, leaf);
+    for (int i = 0; i < n - 1; ++i)
+        if (i == 0 || t.hi[i] - t.lo[i] + 1 > kLeafMax) { Node4 full; collapse4(t.nodes.data(), t.lo.data(), t.hi.data(), n, i, full); t.wide[i] = node4_quantize(full); }
+    int32_t fast[8], slow[512];
+    Stack st; st.fast = fast; st.stride = 1; st.depth_fast = 8; st.slow = slow; st.sp = 0;
+    double total = 0, leafs = 0;
+    for (int64_t r = 0; r < n_rays; ++r) {
+        const f3 o{rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]}, d{rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]};
+        TravState s;
+        trav_init(s, st, o, d);
+        uint64_t vis = 1, lv = 0;
+        for (;;) {
+            const bool is_leaf = s.cur < 0;
+            lv += is_leaf;
+            if (trav_step<false>(t.wide.data(), t.tris.data(), s, st)) break;
+            ++vis;
+        }
+        total += (double)vis; leafs += (double)lv;
+        ID_out[r] = s.best_face;
+    }
+    if (leaf_visits_out) *leaf_visits_out = leafs / (double)n_rays;
+    return total / (double)n_rays;
+}
+}
