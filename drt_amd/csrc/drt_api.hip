@@ -1,0 +1,133 @@
+// drt_api.hip -- scene lifetime, error string, measurement entry points of the C ABI (include/drt_hip.h).
+#include "drt_scene.h"
+
+static thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+const char* drt_last_error(void) { return g_err; }
+int drt_version(void) { return 1; }
+
+int drt_create(int device, drt_scene_t** out) {
+    if (!out) return fail(DRT_E_INVALID, "out is null");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(DRT_E_INVALID, "device %d out of range (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    drt_scene* s = new (std::nothrow) drt_scene();
+    if (!s) return fail(DRT_E_NOMEM, "host allocation failed");
+    s->device = device;
+    hipError_t e = hipMalloc(&s->params, sizeof(BuildParams));
+    if (e == hipSuccess) e = hipMalloc(&s->slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
+    if (e == hipSuccess) e = hipMalloc(&s->scratch, sizeof(unsigned long long) * 8);
+    if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
+    if (const char* ev = getenv("DRT_STREAMS")) { const int v = atoi(ev); if (v >= 1 && v <= drt_scene::kMaxSub) s->n_sub = v; }
+    if (const char* ev = getenv("DRT_SUB_PER_STREAM")) { const int v = atoi(ev); if (v >= 1 && v <= 16) s->sub_per_stream = v; }
+    if (const char* ev = getenv("DRT_MIN_SUB_LOG2")) { const int v = atoi(ev); if (v >= 12 && v <= 30) s->min_sub_rays = (int64_t)1 << v; }
+    for (int k = 0; k < s->n_sub && e == hipSuccess; ++k) {
+        drt_scene::Sub& w = s->sub[k];
+        e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * 8);
+        if (e == hipSuccess) e = hipMalloc(&w.slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
+    }
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
+        int per_cu;
+        per_cu = query_blocks_per_cu();           // drt_trace.hip: resident 128-thread blocks of the B1 query kernels
+        s->grid_trace = s->n_cu * per_cu;
+        if (s->grid_trace > kTraceGridMax) s->grid_trace = kTraceGridMax;
+        per_cu = pipeline_blocks_per_cu();        // drt_pipeline.hip: resident 256-thread blocks of k_trace
+        s->grid_path = s->n_cu * per_cu;
+        if (s->grid_path * 2 > kTraceGridMax) s->grid_path = kTraceGridMax / 2;
+        // tuning knobs (measurement only; defaults are the tuned values)
+        if (const char* e = getenv("DRT_TRACE_BPC")) { const int v = atoi(e); if (v >= 1 && v * s->n_cu * 2 <= kTraceGridMax) s->grid_path = v * s->n_cu; }
+        if (const char* e = getenv("DRT_INNER_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->inner_min = v; }
+        if (const char* e = getenv("DRT_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->refill_min = v; }
+        if (const char* e = getenv("DRT_CHUNK_LOG2")) { const int v = atoi(e); if (v >= 16 && v <= 30) s->chunk_rays = (int64_t)1 << v; }
+    }
+    if (e != hipSuccess) {
+        drt_destroy(s);
+        return fail(DRT_E_HIP, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return DRT_OK;
+}
+
+void drt_destroy(drt_scene_t* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    scene_free_mesh(s);
+    (void)hipFree(s->params);
+    (void)hipFree(s->slow_stack);
+    (void)hipFree(s->scratch);
+    for (int j = 0; j < drt_scene::kMaxSub; ++j) {
+        drt_scene::Sub& w = s->sub[j];
+        for (int k = 0; k < 3; ++k) { (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]); }
+        (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2); (void)hipFree(w.qcount); (void)hipFree(w.slow_stack); (void)hipFree(w.redo);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
+    (void)hipFree(s->vcount);
+    (void)hipFree(s->vh_list);
+    if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+    for (auto& e : s->prof_ev) (void)hipEventDestroy(e);
+    (void)hipFree(s->prof_counts);
+    delete s;
+}
+
+int drt_profile_enable(drt_scene_t* s, int on) {
+    CHECK_SCENE(s);
+    if (on && s->prof_ev.empty()) {
+        s->prof_ev.resize(8192);
+        s->prof_stage.resize(4096);
+        for (auto& e : s->prof_ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipMalloc(&s->prof_counts, sizeof(unsigned long long) * (kProfStages + 12)));
+        HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(unsigned long long) * (kProfStages + 12)));
+    }
+    s->prof_on = on != 0;
+    s->prof_stats = on == 2;
+    s->prof_serial = on == 3;
+    return DRT_OK;
+}
+
+int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out) {
+    CHECK_SCENE(s);
+    if (!ms_out || !launches_out || !items_out) return fail(DRT_E_INVALID, "null pointer argument");
+    for (int k = 0; k < kProfStages; ++k) { ms_out[k] = 0.0; launches_out[k] = 0; items_out[k] = 0; }
+    if (s->prof_ev.empty()) return DRT_OK;
+    HIP_TRY(hipStreamSynchronize(s->prof_stream));
+    for (size_t k = 0; k + 1 < s->prof_used; k += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->prof_ev[k], s->prof_ev[k + 1]));
+        const int stg = s->prof_stage[k / 2];
+        ms_out[stg] += ms;
+        launches_out[stg] += 1;
+    }
+    unsigned long long h[kProfStages + 12];
+    HIP_TRY(hipMemcpy(h, s->prof_counts, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < kProfStages; ++k) items_out[k] = (int64_t)h[k];
+    for (int k = 0; k < 12; ++k) s->trace_stats[k] = (int64_t)h[kProfStages + k];
+    HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(h)));
+    s->prof_used = 0;
+    return DRT_OK;
+}
+
+int drt_profile_trace_stats(drt_scene_t* s, int64_t* out12) {
+    CHECK_SCENE(s);
+    if (!out12) return fail(DRT_E_INVALID, "null pointer argument");
+    for (int k = 0; k < 12; ++k) out12[k] = s->trace_stats[k];
+    return DRT_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,509 @@
+// drt_build.hip -- the on-GPU LBVH build (every update_vert), its diagnostics, and the mesh-update entry points.
+#include "drt_device.h"
+
+void scene_free_mesh(drt_scene* s) {
+    (void)hipFree(s->faces); (void)hipFree(s->verts); (void)hipFree(s->nodes); (void)hipFree(s->tris);
+    (void)hipFree(s->keys[0]); (void)hipFree(s->keys[1]); (void)hipFree(s->idx[0]); (void)hipFree(s->idx[1]);
+    (void)hipFree(s->hist); (void)hipFree(s->parent_inner); (void)hipFree(s->parent_leaf); (void)hipFree(s->flags);
+    s->faces = nullptr; s->verts = nullptr; s->nodes = nullptr; s->tris = nullptr;
+    s->keys[0] = s->keys[1] = s->idx[0] = s->idx[1] = nullptr;
+    s->hist = nullptr; s->parent_inner = s->parent_leaf = nullptr; s->flags = nullptr;
+    s->cap_faces = s->cap_verts = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// build kernels
+// ------------------------------------------------------------------------------------------
+__global__ void k_cast_verts(const double* __restrict__ v64, float* __restrict__ v32, int64_t n3) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x)
+        v32[i] = (float)v64[i];
+}
+
+// One block: scene box over all vertices -> Morton normalisation + leaf padding.
+__global__ void __launch_bounds__(1024) k_bounds(const float* __restrict__ verts, int64_t n_verts, BuildParams* out,
+                                                 uint32_t* __restrict__ hist_zero, int hist_entries) {
+    __shared__ float red[6][16];
+    for (int i = threadIdx.x; i < hist_entries; i += blockDim.x) hist_zero[i] = 0u;   // digit histograms of the fused sort (below)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = threadIdx.x; i < n_verts; i += blockDim.x) {
+        for (int a = 0; a < 3; ++a) {
+            const float v = verts[3 * i + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; ++w)
+            for (int a = 0; a < 3; ++a) {
+                red[a][0] = fminf(red[a][0], red[a][w]);
+                red[3 + a][0] = fmaxf(red[3 + a][0], red[3 + a][w]);
+            }
+        const float ex = red[3][0] - red[0][0], ey = red[4][0] - red[1][0], ez = red[5][0] - red[2][0];
+        out->lox = red[0][0]; out->loy = red[1][0]; out->loz = red[2][0];
+        out->ix = ex > 0.f ? 1.0f / ex : 0.f;
+        out->iy = ey > 0.f ? 1.0f / ey : 0.f;
+        out->iz = ez > 0.f ? 1.0f / ez : 0.f;
+        out->pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
+        out->reserved = 0;
+    }
+}
+
+__device__ __forceinline__ f3 ld_vert(const float* __restrict__ verts, int32_t i) {
+    return f3{verts[3 * (int64_t)i], verts[3 * (int64_t)i + 1], verts[3 * (int64_t)i + 2]};
+}
+
+__global__ void k_morton(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n,
+                         const BuildParams* __restrict__ bp, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                         uint32_t* hist0, int tiles) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 a = ld_vert(verts, faces[3 * i]), b = ld_vert(verts, faces[3 * i + 1]), c = ld_vert(verts, faces[3 * i + 2]);
+    const uint32_t key = morton30(a, b, c, f3{bp->lox, bp->loy, bp->loz}, f3{bp->ix, bp->iy, bp->iz});
+    keys[i] = key;
+    idx[i] = (uint32_t)i;
+    if (hist0) atomicAdd(&hist0[(key & (kRadix - 1)) * tiles + i / kSortTile], 1u);   // first pass of the fused sort
+}
+
+// ---- LSD radix sort, 8 bits per pass, stable; three launches per pass -------------------
+__global__ void __launch_bounds__(kSortBlock) k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift,
+                                                          uint32_t* __restrict__ hist, int tiles) {
+    __shared__ uint32_t cnt[kRadix];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = base + r * kSortBlock + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * tiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// Exclusive scan of hist[0..total) in place, one block of 1024 threads.
+__global__ void __launch_bounds__(1024) k_sort_scan(uint32_t* __restrict__ hist, int total) {
+    __shared__ uint32_t part[1024];
+    const int chunk = (total + 1023) / 1024;
+    const int b = threadIdx.x * chunk, e = min(b + chunk, total);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += hist[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int i = b; i < e; ++i) {
+        const uint32_t h = hist[i];
+        hist[i] = run;
+        run += h;
+    }
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                             int n, int shift, const uint32_t* __restrict__ hist, int tiles) {
+    constexpr int kWaves = kSortBlock / 64;
+    __shared__ uint32_t running[kRadix];
+    __shared__ uint32_t wcount[kWaves][kRadix];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    running[tid] = hist[tid * tiles + blockIdx.x];
+    for (int w = 0; w < kWaves; ++w) wcount[w][tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = base + r * kSortBlock + tid;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t val = valid ? idx_in[i] : 0u;
+        const uint32_t digit = (key >> shift) & (kRadix - 1);
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool set = (digit >> bit) & 1u;
+            const unsigned long long bm = __ballot(valid && set);
+            peers &= set ? bm : ~bm;
+        }
+        const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcount[wave][digit] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[digit] + rank;
+            for (int w = 0; w < wave; ++w) pos += wcount[w][digit];
+            keys_out[pos] = key;
+            idx_out[pos] = val;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < kWaves; ++w) { add += wcount[w][tid]; wcount[w][tid] = 0; }
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+// Fused pass for small meshes (tiles <= kSortFusedTiles): the per-tile digit offsets are derived inside the scatter
+// from the [kRadix x tiles] histogram (every block redundantly reduces it: a few thousand words), and the scatter
+// counts the NEXT pass's histogram while it places the keys (the destination tile is known then).  One launch per
+// pass instead of three: a 50 k-triangle sort is bound by launch count, not by work.
+constexpr int kSortFusedTiles = 128;
+__global__ void __launch_bounds__(kSortBlock) k_sort_pass_fused(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out, int n, int shift,
+                                                                const uint32_t* __restrict__ hist, uint32_t* hist_next, int tiles) {
+    constexpr int kWaves = kSortBlock / 64;
+    __shared__ uint32_t running[kRadix];
+    __shared__ uint32_t wcount[kWaves][kRadix];
+    __shared__ uint32_t scan[kRadix];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // offsets of this tile: (keys with a smaller digit) + (keys with this digit in earlier tiles); thread = digit
+    uint32_t total = 0, before = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const uint32_t v = hist[tid * tiles + t];
+        before += t < (int)blockIdx.x ? v : 0u;
+        total += v;
+    }
+    scan[tid] = total;
+    for (int w = 0; w < kWaves; ++w) wcount[w][tid] = 0;
+    __syncthreads();
+    for (int off = 1; off < kRadix; off <<= 1) {
+        const uint32_t v = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    running[tid] = scan[tid] - total + before;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const int i = base + r * kSortBlock + tid;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t val = valid ? idx_in[i] : 0u;
+        const uint32_t digit = (key >> shift) & (kRadix - 1);
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool set = (digit >> bit) & 1u;
+            const unsigned long long bm = __ballot(valid && set);
+            peers &= set ? bm : ~bm;
+        }
+        const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcount[wave][digit] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[digit] + rank;
+            for (int w = 0; w < wave; ++w) pos += wcount[w][digit];
+            keys_out[pos] = key;
+            idx_out[pos] = val;
+            if (hist_next) atomicAdd(&hist_next[((key >> (shift + 8)) & (kRadix - 1)) * tiles + pos / kSortTile], 1u);
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (int w = 0; w < kWaves; ++w) { add += wcount[w][tid]; wcount[w][tid] = 0; }
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+// ---- hierarchy ---------------------------------------------------------------------------
+__global__ void k_hierarchy(const uint32_t* __restrict__ keys, int n, Node* __restrict__ nodes,
+                            int32_t* __restrict__ parent_inner, int32_t* __restrict__ parent_leaf,
+                            uint32_t* __restrict__ flags, int32_t* __restrict__ range_lo, int32_t* __restrict__ range_hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) parent_inner[0] = -1;
+    if (n == 1) {   // degenerate: one triangle under a root whose second child is an empty box
+        if (i == 0) {
+            Node nd;
+            node_set_child_box(nd, 0, box_empty());
+            node_set_child_box(nd, 1, box_empty());
+            nd.child0 = ~0; nd.child1 = ~0; nd.pad0 = nd.pad1 = 0;
+            nodes[0] = nd;
+            parent_leaf[0] = 0;
+            range_lo[0] = 0; range_hi[0] = 0;
+            flags[0] = 1;   // the single leaf is the "second" arrival: it stops at the root
+        }
+        return;
+    }
+    if (i >= n - 1) return;
+    int32_t l, r, lo, hi;
+    lbvh_children(keys, n, i, l, r, lo, hi);
+    range_lo[i] = lo; range_hi[i] = hi;
+    nodes[i].child0 = l; nodes[i].child1 = r; nodes[i].pad0 = 0; nodes[i].pad1 = 0;
+    if (l >= 0) parent_inner[l] = i * 2 + 0; else parent_leaf[~l] = i * 2 + 0;
+    if (r >= 0) parent_inner[r] = i * 2 + 1; else parent_leaf[~r] = i * 2 + 1;
+    flags[i] = 0;
+}
+
+// A child box occupies three aligned 8-byte granules of its parent node: (lo.x,hi.x) (lo.y,hi.y) (lo.z,hi.z).
+__device__ __forceinline__ unsigned long long* box_granule(Node* nodes, int parent, int slot, int axis) {
+    float* f = reinterpret_cast<float*>(nodes + parent);
+    const int off = axis == 2 ? 8 + 2 * slot : 4 * slot + 2 * axis;
+    return reinterpret_cast<unsigned long long*>(f + off);
+}
+__device__ __forceinline__ unsigned long long pack2(float a, float b) {
+    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+}
+
+// One thread per leaf: write the triangle record, then carry boxes towards the root.  The second
+// thread to arrive at a node owns it.  Per-XCD L2s and per-CU L1s are not coherent on MI355X, so the
+// box hand-off between workgroups goes through agent-scope accesses on BOTH sides: the producer
+// writes its three 8-byte granules with relaxed agent-scope atomic stores (write-through, sc1),
+// drains them (s_waitcnt vmcnt(0)) and only then bumps the node's counter; the second arriver reads
+// the sibling's granules with relaxed agent-scope atomic loads (bypass L1).  No fences: a fence per
+// tree level (L2 write-back + L1 invalidate, ~3.5 us) made this kernel 235 us; this form is ~5x
+// shorter.  drt_bvh_check verifies every box after the fact (tests run it under load).
+__global__ void k_refit(const uint32_t* __restrict__ sorted_idx, const int32_t* __restrict__ faces,
+                        const float* __restrict__ verts, int n, BuildParams* bp, TriRec* __restrict__ tris,
+                        Node* nodes, const int32_t* __restrict__ parent_inner,
+                        const int32_t* __restrict__ parent_leaf, uint32_t* flags) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t face = (int32_t)sorted_idx[k];
+    const f3 a = ld_vert(verts, faces[3 * face]), b = ld_vert(verts, faces[3 * face + 1]), c = ld_vert(verts, faces[3 * face + 2]);
+    tris[k] = make_tri(a, b, c, face);
+    Box box = box_of_tri(a, b, c, bp->pad);
+    int32_t link = parent_leaf[k];
+    while (link >= 0) {
+        const int p = link >> 1, slot = link & 1;
+        __hip_atomic_store(box_granule(nodes, p, slot, 0), pack2(box.lox, box.hix), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(box_granule(nodes, p, slot, 1), pack2(box.loy, box.hiy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(box_granule(nodes, p, slot, 2), pack2(box.loz, box.hiz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        const unsigned long long gx = __hip_atomic_load(box_granule(nodes, p, slot ^ 1, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long gy = __hip_atomic_load(box_granule(nodes, p, slot ^ 1, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long gz = __hip_atomic_load(box_granule(nodes, p, slot ^ 1, 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const Box sib{__uint_as_float((unsigned)gx), __uint_as_float((unsigned)gy), __uint_as_float((unsigned)gz),
+                      __uint_as_float((unsigned)(gx >> 32)), __uint_as_float((unsigned)(gy >> 32)), __uint_as_float((unsigned)(gz >> 32))};
+        box = box_union(box, sib);
+        link = parent_inner[p];
+    }
+}
+
+// Binary -> 4-wide collapse (drt_lbvh.h): one thread per binary node with more than kLeafMax triangles
+// (and the root).  The traversal only ever reaches the wide nodes of EVEN-depth binary nodes (a wide node
+// adopts grandchildren), but finding a node's depth means walking its parent links to the root -- a chain
+// of ~30 dependent loads that made this kernel 34 us; building the (unreferenced) odd-depth ones too is a
+// few microseconds of independent work.  Runs after k_refit (kernel boundary = all boxes visible).
+__global__ void k_collapse4(const Node* __restrict__ nodes, const int32_t* __restrict__ parent_inner,
+                            const int32_t* __restrict__ range_lo, const int32_t* __restrict__ range_hi, int n,
+                            Node4Q* __restrict__ wide) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int inner = n > 1 ? n - 1 : 1;
+    if (i >= inner) return;
+    if (i != 0 && range_hi[i] - range_lo[i] + 1 <= kLeafMax) return;
+    Node4 out;
+    collapse4(nodes, range_lo, range_hi, n, i, out);
+    wide[i] = node4_quantize(out);
+}
+
+// Diagnostic for the wide tree (one thread, depth-first from the root -- only the nodes a traversal can reach):
+// every leaf marks its triangle slots and checks its box; out[2] = depth of the wide tree.  A traversal keeps at
+// most three postponed children per level, so 3 * depth must fit the spilling stack of k_trace_redo / B1 queries.
+__global__ void k_wide_walk(const Node4Q* __restrict__ wide, const TriRec* __restrict__ tris, int n, const BuildParams* __restrict__ bp,
+                            uint32_t* seen, unsigned long long* out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0 || n <= 0) return;
+    constexpr int kCap = 512;
+    int32_t node[kCap];
+    int16_t level[kCap];
+    int sp = 0;
+    unsigned long long bad = 0, deepest = 0;
+    node[sp] = 0; level[sp] = 1; ++sp;
+    while (sp > 0) {
+        --sp;
+        const Node4Q nd = wide[node[sp]];
+        const int lv = level[sp];
+        if ((unsigned long long)lv > deepest) deepest = lv;
+        for (int k = 0; k < 4; ++k) {
+            const int32_t c = nd.child[k];
+            if (c == kEmptyChild) continue;
+            if (c >= 0) {
+                if (sp < kCap) { node[sp] = c; level[sp] = (int16_t)(lv + 1); ++sp; } else ++bad;
+                continue;
+            }
+            const int first = (~c) >> kLeafBits, count = ((~c) & (kLeafMax - 1)) + 1;
+            for (int j = first; j < first + count; ++j) {
+                if (j < 0 || j >= n) { ++bad; continue; }
+                seen[j] += 1u;
+                const TriRec t = tris[j];
+                const f3 a{t.v0x, t.v0y, t.v0z}, b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, cc{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+                if (!box_contains(node4q_box(nd, k), box_of_tri(a, b, cc, 0.5f * bp->pad))) ++bad;
+            }
+        }
+    }
+    if (3 * deepest > (unsigned long long)(kStackFast + kStackSlowDev)) ++bad;   // would overflow the spilling traversal stack
+    out[0] += bad;
+    out[2] = deepest;
+}
+__global__ void k_seen_check(const uint32_t* __restrict__ seen, int n, unsigned long long* violations) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && seen[j] != 1u) atomicAdd(violations, 1ull);
+}
+
+// Diagnostic: every ancestor's child box must enclose the padded box of leaf k.
+__global__ void k_bvh_check(const TriRec* __restrict__ tris, int n, const BuildParams* __restrict__ bp,
+                            const Node* __restrict__ nodes, const int32_t* __restrict__ parent_inner,
+                            const int32_t* __restrict__ parent_leaf, unsigned long long* violations) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const TriRec t = tris[k];
+    const f3 a{t.v0x, t.v0y, t.v0z};
+    // e1/e2 were rounded from b - a; rebuild the leaf box conservatively from a, a+e1, a+e2
+    const f3 b{t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z}, c{t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+    const Box leaf = box_of_tri(a, b, c, 0.5f * bp->pad);
+    int32_t link = parent_leaf[k];
+    int32_t child_expect = ~k;
+    unsigned long long bad = 0, depth = 0;
+    while (link >= 0) {
+        ++depth;
+        const int p = link >> 1, slot = link & 1;
+        const Node nd = nodes[p];
+        if ((slot == 0 ? nd.child0 : nd.child1) != child_expect) ++bad;
+        if (!box_contains(node_child_box(nd, slot), leaf)) ++bad;
+        child_expect = p;
+        link = parent_inner[p];
+    }
+    if (child_expect != 0 && n > 1) ++bad;   // must end at the root
+    if (bad) atomicAdd(violations, bad);
+    atomicMax(violations + 1, depth);   // tree height = deepest leaf
+}
+
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
+    if (n_faces <= s->cap_faces && n_verts <= s->cap_verts) return DRT_OK;
+    scene_free_mesh(s);
+    const int64_t F = n_faces > 0 ? n_faces : 1, V = n_verts > 0 ? n_verts : 1;
+    const int64_t tiles = (F + kSortTile - 1) / kSortTile;
+    HIP_TRY(hipMalloc(&s->faces, sizeof(int32_t) * 3 * F));
+    HIP_TRY(hipMalloc(&s->verts, sizeof(float) * 3 * V));
+    HIP_TRY(hipMalloc(&s->nodes, sizeof(Node) * F));
+    HIP_TRY(hipMalloc(&s->wide, sizeof(Node4Q) * F));
+    HIP_TRY(hipMalloc(&s->range_lo, sizeof(int32_t) * F));
+    HIP_TRY(hipMalloc(&s->range_hi, sizeof(int32_t) * F));
+    HIP_TRY(hipMalloc(&s->tris, sizeof(TriRec) * F));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc(&s->keys[k], sizeof(uint32_t) * F));
+        HIP_TRY(hipMalloc(&s->idx[k], sizeof(uint32_t) * F));
+    }
+    HIP_TRY(hipMalloc(&s->hist, sizeof(uint32_t) * kRadix * tiles * 4));   // one table per radix pass (fused sort)
+    HIP_TRY(hipMalloc(&s->parent_inner, sizeof(int32_t) * F));
+    HIP_TRY(hipMalloc(&s->parent_leaf, sizeof(int32_t) * F));
+    HIP_TRY(hipMalloc(&s->flags, sizeof(uint32_t) * F));
+    s->cap_faces = F;
+    s->cap_verts = V;
+    return DRT_OK;
+}
+
+static int rebuild_impl(drt_scene* s, hipStream_t st) {
+    const int n = (int)s->n_faces;
+    s->built = true;
+    if (n == 0) return DRT_OK;
+    const int tiles = (n + kSortTile - 1) / kSortTile;
+    const bool fused_sort = tiles <= kSortFusedTiles;
+    const int table = kRadix * tiles;
+    k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params, s->hist, fused_sort ? 4 * table : 0);
+    k_morton<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->params, s->keys[0], s->idx[0], fused_sort ? s->hist : nullptr, tiles);
+    int cur = 0;
+    for (int shift = 0, pass = 0; shift < 30; shift += 8, ++pass) {
+        if (fused_sort) {
+            k_sort_pass_fused<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], s->idx[cur], s->keys[cur ^ 1], s->idx[cur ^ 1], n, shift,
+                                                            s->hist + pass * table, pass < 3 ? s->hist + (pass + 1) * table : nullptr, tiles);
+        } else {
+            k_sort_hist<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], n, shift, s->hist, tiles);
+            k_sort_scan<<<1, 1024, 0, st>>>(s->hist, kRadix * tiles);
+            k_sort_scatter<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], s->idx[cur], s->keys[cur ^ 1], s->idx[cur ^ 1], n, shift, s->hist, tiles);
+        }
+        cur ^= 1;
+    }
+    // four passes -> result is back in buffer 0
+    const int inner = n > 1 ? n - 1 : 1;
+    k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags, s->range_lo, s->range_hi);
+    k_refit<<<(n + 255) / 256, 256, 0, st>>>(s->idx[cur], s->faces, s->verts, n, s->params, s->tris, s->nodes,
+                                             s->parent_inner, s->parent_leaf, s->flags);
+    k_collapse4<<<(inner + 255) / 256, 256, 0, st>>>(s->nodes, s->parent_inner, s->range_lo, s->range_hi, n, s->wide);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int rebuild(drt_scene* s, hipStream_t st) {
+    StageTimer t(s, st, kStageBuild);
+    return rebuild_impl(s, st);
+}
+
+extern "C" {
+
+int drt_update_mesh(drt_scene_t* s, const int32_t* d_faces, int64_t n_faces, const float* d_verts, int64_t n_verts, void* stream) {
+    CHECK_SCENE(s);
+    if (n_faces < 0 || n_verts < 0 || (n_faces && !d_faces) || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "bad mesh arguments");
+    if (n_faces > (int64_t)1 << 30) return fail(DRT_E_INVALID, "too many faces");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_capacity(s, n_faces, n_verts);
+    if (rc) return rc;
+    s->n_faces = n_faces;
+    s->n_verts = n_verts;
+    if (n_faces) HIP_TRY(hipMemcpyAsync(s->faces, d_faces, sizeof(int32_t) * 3 * n_faces, hipMemcpyDeviceToDevice, st));
+    if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
+    return rebuild(s, st);
+}
+
+int drt_update_vert(drt_scene_t* s, const float* d_verts, int64_t n_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_verts != s->n_verts || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "vertex count %lld != %lld", (long long)n_verts, (long long)s->n_verts);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
+    return rebuild(s, st);
+}
+
+int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_verts != s->n_verts || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "vertex count %lld != %lld", (long long)n_verts, (long long)s->n_verts);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_verts) k_cast_verts<<<grid_for(3 * n_verts, 256, 1024), 256, 0, st>>>(d_verts, s->verts, 3 * n_verts);
+    return rebuild(s, st);
+}
+
+int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height, int32_t* wide_depth) {
+    CHECK_BUILT(s);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long v[3] = {0, 0, 0};
+    if (s->n_faces) {
+        HIP_TRY(hipMemsetAsync(s->scratch, 0, 3 * sizeof(unsigned long long), st));
+        const int n = (int)s->n_faces;
+        k_bvh_check<<<(n + 255) / 256, 256, 0, st>>>(s->tris, n, s->params, s->nodes, s->parent_inner, s->parent_leaf, s->scratch);
+        // the refit counters are dead after a build: reuse them as per-slot reference counts
+        HIP_TRY(hipMemsetAsync(s->flags, 0, sizeof(uint32_t) * n, st));
+        k_wide_walk<<<1, 64, 0, st>>>(s->wide, s->tris, n, s->params, s->flags, s->scratch);
+        k_seen_check<<<(n + 255) / 256, 256, 0, st>>>(s->flags, n, s->scratch);
+        HIP_TRY(hipMemcpyAsync(v, s->scratch, sizeof(v), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (n_violations) *n_violations = (int64_t)v[0];
+    if (height) *height = (int32_t)v[1];
+    if (wide_depth) *wide_depth = (int32_t)v[2];
+    return DRT_OK;
+}
+
+int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream) {
+    CHECK_BUILT(s);
+    if (s->n_faces && !d_order) return fail(DRT_E_INVALID, "d_order is null");
+    if (s->n_faces) HIP_TRY(hipMemcpyAsync(d_order, s->idx[0], sizeof(int32_t) * s->n_faces, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DRT_OK;
+}
+
+
+}  // extern "C"

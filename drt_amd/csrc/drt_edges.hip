@@ -1,0 +1,288 @@
+// drt_edges.hip -- silhouette (visual-hull) and smoothness branches, per unique edge.
+#include "drt_device.h"
+
+// ---- silhouette and smoothness branches (per unique edge) -------------------------------------
+__device__ __forceinline__ void load_face64(const double* __restrict__ verts, const int64_t* __restrict__ f, d3& v0, d3& v1, d3& v2) {
+    v0 = load_d3(verts, f[0]); v1 = load_d3(verts, f[1]); v2 = load_d3(verts, f[2]);
+}
+
+// cos of the dihedral angle of every edge (reference DiffRender.py:440-443)
+__global__ void __launch_bounds__(256) k_dihedral_fwd(const double* __restrict__ verts, const int64_t* __restrict__ e2f, int64_t n,
+                                                      double* __restrict__ cos_out) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    d3 v0, v1, v2;
+    FaceNormal a, b;
+    load_face64(verts, e2f + 6 * e, v0, v1, v2); face_normal(v0, v1, v2, a);
+    load_face64(verts, e2f + 6 * e + 3, v0, v1, v2); face_normal(v0, v1, v2, b);
+    cos_out[e] = dot(a.n, b.n);
+}
+
+// MODE 0: adjoint of k_dihedral_fwd for a given d loss / d cos.
+// MODE 1: sm_loss = sum -log(1 + cos) (reference optim.py:82-89) and its vertex gradient in one pass.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_dihedral_bwd(const double* __restrict__ verts, const int64_t* __restrict__ e2f, int64_t n,
+                                                      const double* __restrict__ g_cos, double* loss, double* grad_verts) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double term = 0.0;
+    if (e < n) {
+        d3 v0, v1, v2;
+        FaceNormal a, b;
+        const int64_t* fa = e2f + 6 * e;
+        const int64_t* fb = fa + 3;
+        load_face64(verts, fa, v0, v1, v2); face_normal(v0, v1, v2, a);
+        load_face64(verts, fb, v0, v1, v2); face_normal(v0, v1, v2, b);
+        double g;
+        if (MODE == 0) {
+            g = g_cos[e];
+        } else {
+            const double c = dot(a.n, b.n);
+            term = -log(1.0 + c);
+            g = -1.0 / (1.0 + c);
+        }
+        const d3 z{0.0, 0.0, 0.0};
+        d3 g0 = z, g1 = z, g2 = z;
+        const AtomicAdd3 add{grad_verts};
+        face_normal_backward(a, g * b.n, g0, g1, g2);
+        add((int32_t)fa[0], g0); add((int32_t)fa[1], g1); add((int32_t)fa[2], g2);
+        g0 = z; g1 = z; g2 = z;
+        face_normal_backward(b, g * a.n, g0, g1, g2);
+        add((int32_t)fb[0], g0); add((int32_t)fb[1], g1); add((int32_t)fb[2], g2);
+    }
+    if (MODE == 1) {
+        term = wave_sum(term);
+        if ((threadIdx.x & 63) == 0 && term != 0.0) unsafeAtomicAdd(loss, term);
+    }
+}
+
+// silhouette test per unique edge (reference DiffRender.py:445-457)
+__global__ void __launch_bounds__(256) k_silhouette_flags(const double* __restrict__ verts, const int64_t* __restrict__ e2f, int64_t n,
+                                                          const double* __restrict__ origin3, uint8_t* __restrict__ flags) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const d3 o{origin3[0], origin3[1], origin3[2]};
+    d3 a0, b0, v1, v2;
+    FaceNormal a, b;
+    load_face64(verts, e2f + 6 * e, a0, v1, v2); face_normal(a0, v1, v2, a);
+    load_face64(verts, e2f + 6 * e + 3, b0, v1, v2); face_normal(b0, v1, v2, b);
+    flags[e] = silhouette_flag(a, a0, b, b0, o) ? 1 : 0;
+}
+
+// primary_visibility + primary_edge_sample.forward for every silhouette edge: project the two
+// endpoints, probe one pixel either side of the edge midpoint with any-hit rays, f = hit+ - hit-.
+__global__ void __launch_bounds__(kTraceBlock) k_edge_sample_fwd(TraceCtx c, const double* __restrict__ verts, const int64_t* __restrict__ edges,
+                                                                  int64_t n, const Camera* __restrict__ cam, const double* __restrict__ origin3,
+                                                                  int64_t* __restrict__ index, float* __restrict__ f_out) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    const Camera cm = *cam;
+    const d3 o{origin3[0], origin3[1], origin3[2]};
+    for (int64_t e = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kTraceBlock) {
+        Projected pa, pb;
+        project_endpoint(cm, load_d3(verts, edges[2 * e]), pa);
+        project_endpoint(cm, load_d3(verts, edges[2 * e + 1]), pb);
+        EdgeSample s;
+        edge_sample(cm, pa, pb, o, s);
+        const bool hu = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_up), st).face >= 0;
+        const bool hl = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_lo), st).face >= 0;
+        f_out[e] = (hu ? 1.0f : 0.0f) - (hl ? 1.0f : 0.0f);
+        index[2 * e] = (int64_t)s.midx;       // truncation toward zero, like Tensor.to(torch.long)
+        index[2 * e + 1] = (int64_t)s.midy;
+    }
+}
+
+// Adjoint: dE_pos[e, endpoint, :] = -N_e * f_e * coef_e for both endpoints (reference
+// DiffRender.py:236-242, 263-267), chained through the projection to the two vertices.
+__global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restrict__ verts, const int64_t* __restrict__ edges, int64_t n,
+                                                         const Camera* __restrict__ cam, const float* __restrict__ f,
+                                                         const double* __restrict__ coef, int detach_depth, double* grad_verts) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double w = (double)f[e] * coef[e];
+    if (w == 0.0) return;
+    const Camera cm = *cam;
+    const int64_t ia = edges[2 * e], ib = edges[2 * e + 1];
+    Projected pa, pb;
+    project_endpoint(cm, load_d3(verts, ia), pa);
+    project_endpoint(cm, load_d3(verts, ib), pb);
+    const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
+    const AtomicAdd3 add{grad_verts};
+    add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
+    add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
+}
+
+// ---- fused silhouette loss: Loss_calculator.vh_loss (reference optim.py:73-78) with no host round trip:
+// the drop-in methods return dynamically sized tensors (two device->host syncs per view); here the
+// silhouette edges of up to kVhViews views are compacted on the device into ONE list and one kernel does
+// projection, probe rays, the loss term |soft_mask[y, x] - 0.5| and its vertex gradient.  Views are
+// batched because a view has only a few thousand silhouette edges and its probe rays graze the surface:
+// a per-view launch is bound by the latency of its longest traversal, not by throughput.
+constexpr int kVhViews = 16;
+struct VhViews {
+    const double* cam[kVhViews];
+    const double* origin[kVhViews];
+    const double* soft[kVhViews];
+};
+
+__global__ void __launch_bounds__(kPathBlock) k_vh_cull(const double* __restrict__ verts, const int64_t* __restrict__ e2f, int64_t n_edges,
+                                                         int n_views, VhViews vw, uint32_t* __restrict__ list, unsigned* count) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    const int64_t n = n_edges * n_views;
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        const int64_t k = base + threadIdx.x;
+        bool sil = false;
+        if (k < n) {
+            const int64_t e = k % n_edges;
+            const double* o3 = vw.origin[k / n_edges];
+            d3 a0, b0, v1, v2;
+            FaceNormal a, b;
+            load_face64(verts, e2f + 6 * e, a0, v1, v2); face_normal(a0, v1, v2, a);
+            load_face64(verts, e2f + 6 * e + 3, b0, v1, v2); face_normal(b0, v1, v2, b);
+            sil = silhouette_flag(a, a0, b, b0, d3{o3[0], o3[1], o3[2]});
+        }
+        const int slot = block_push(sil, count, s_tmp);
+        if (slot >= 0) list[slot] = (uint32_t)k;
+    }
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const double* __restrict__ verts, const int64_t* __restrict__ edges,
+                                                           uint32_t n_edges, const uint32_t* __restrict__ list, const unsigned* __restrict__ count,
+                                                           VhViews vw, int resx, int resy, int detach_depth, double* loss, double* grad_verts) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    const unsigned n = *count;
+    double acc = 0.0;
+    // Two lanes per edge, one probe ray each: the rays graze the silhouette and take a few hundred node visits, and with
+    // only a few thousand edges per view the kernel lasts as long as its longest lane -- tracing the two probes of an
+    // edge one after the other in one lane doubled that.
+    constexpr unsigned kPairs = kTraceBlock / 2;
+    const int side = threadIdx.x & 1;
+    for (unsigned base = blockIdx.x * kPairs; base < n; base += gridDim.x * kPairs) {       // block-uniform trip count (shuffles below)
+        const unsigned k = base + (threadIdx.x >> 1);
+        const bool live = k < n;
+        const uint32_t item = live ? list[k] : 0u, view = item / n_edges;
+        const int64_t e = item - view * n_edges;
+        const Camera cm = *reinterpret_cast<const Camera*>(vw.cam[view]);
+        const double* o3 = vw.origin[view];
+        const d3 o{o3[0], o3[1], o3[2]};
+        const int64_t ia = edges[2 * e], ib = edges[2 * e + 1];
+        Projected pa, pb;
+        project_endpoint(cm, load_d3(verts, ia), pa);
+        project_endpoint(cm, load_d3(verts, ib), pb);
+        EdgeSample s;
+        edge_sample(cm, pa, pb, o, s);
+        const int mine = live && traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(side == 0 ? s.dir_up : s.dir_lo), st).face >= 0 ? 1 : 0;
+        const int other = __shfl_xor(mine, 1);
+        if (!live || side != 0) continue;                         // the even lane of the pair finishes the edge
+        const double f = (double)mine - (double)other;           // hit(up) - hit(lo)
+        if (f == 0.0) continue;                                   // |f| > 1e-5 (DiffRender.py:244)
+        const int64_t x = (int64_t)s.midx, y = (int64_t)s.midy;   // trunc, like Tensor.to(torch.long)
+        if (!(x < resx - 1 && y < resy - 1 && x >= 0 && y >= 0)) continue;   // out of view (DiffRender.py:478)
+        const double m = vw.soft[view][y * resx + x] - 0.5;       // output is float32 0.5: exact
+        acc += fabs(m);
+        const double coef = m > 0.0 ? -1.0 : (m < 0.0 ? 1.0 : 0.0);   // d |mask - output| / d output
+        const double w = f * coef;
+        if (w == 0.0) continue;
+        const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
+        const AtomicAdd3 add{grad_verts};
+        add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
+        add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+}
+
+extern "C" {
+
+int drt_dihedral_forward(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, double* d_cos, void* stream) {
+    if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_verts || !d_e2f || !d_cos) return fail(DRT_E_INVALID, "null pointer argument");
+    k_dihedral_fwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, d_cos);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_dihedral_backward(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, const double* d_grad_cos,
+                          double* d_grad_verts, void* stream) {
+    if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_verts || !d_e2f || !d_grad_cos || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    k_dihedral_bwd<0><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, d_grad_cos, nullptr, d_grad_verts);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_sm_loss_fused(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, double* d_loss, double* d_grad_verts, void* stream) {
+    if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_verts || !d_e2f || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    k_dihedral_bwd<1><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, nullptr, d_loss, d_grad_verts);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_silhouette_flags(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, const double* d_origin3, uint8_t* d_flags, void* stream) {
+    if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_verts || !d_e2f || !d_origin3 || !d_flags) return fail(DRT_E_INVALID, "null pointer argument");
+    k_silhouette_flags<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, d_origin3, d_flags);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera,
+                            const double* d_origin3, int64_t* d_index, float* d_f, void* stream) {
+    CHECK_BUILT(s);
+    if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_verts || !d_edges || !d_camera || !d_origin3 || !d_index || !d_f) return fail(DRT_E_INVALID, "null pointer argument");
+    k_edge_sample_fwd<<<grid_for(n_edges, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(
+        trace_ctx(s), d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_origin3, d_index, d_f);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera, const float* d_f,
+                             const double* d_coef, int detach_depth, double* d_grad_verts, void* stream) {
+    if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_verts || !d_edges || !d_camera || !d_f || !d_coef || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    k_edge_sample_bwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_coef, detach_depth, d_grad_verts);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, const int64_t* d_e2f, int64_t n_edges,
+                      int n_views, const double* const* d_cameras, const double* const* d_origins, const double* const* d_soft_masks,
+                      int resx, int resy, int detach_depth, double* d_loss, double* d_grad_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_edges < 0 || n_views < 0 || resx <= 0 || resy <= 0 || n_edges * kVhViews > (int64_t)UINT32_MAX) return fail(DRT_E_INVALID, "bad size argument");
+    if (n_edges == 0 || n_views == 0) return DRT_OK;
+    if (!d_verts || !d_edges || !d_e2f || !d_cameras || !d_origins || !d_soft_masks || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t need = n_edges * std::min(kVhViews, n_views);
+    if (need > s->vh_cap) {
+        (void)hipFree(s->vh_list); s->vh_list = nullptr; s->vh_cap = 0;
+        HIP_TRY(hipMalloc(&s->vh_list, sizeof(uint32_t) * need));
+        s->vh_cap = need;
+    }
+    for (int v0 = 0; v0 < n_views; v0 += kVhViews) {
+        const int nv = std::min(kVhViews, n_views - v0);
+        VhViews vw{};
+        for (int k = 0; k < nv; ++k) {
+            if (!d_cameras[v0 + k] || !d_origins[v0 + k] || !d_soft_masks[v0 + k]) return fail(DRT_E_INVALID, "null pointer argument");
+            vw.cam[k] = d_cameras[v0 + k]; vw.origin[k] = d_origins[v0 + k]; vw.soft[k] = d_soft_masks[v0 + k];
+        }
+        HIP_TRY(hipMemsetAsync(s->vcount + 1, 0, sizeof(unsigned), st));
+        k_vh_cull<<<grid_for(n_edges * nv, kPathBlock, 4 * s->n_cu), kPathBlock, 0, st>>>(d_verts, d_e2f, n_edges, nv, vw, s->vh_list, s->vcount + 1);
+        k_vh_fused<<<4 * s->n_cu, kTraceBlock, 0, st>>>(trace_ctx(s), d_verts, d_edges, (uint32_t)n_edges, s->vh_list, s->vcount + 1,
+                                                        vw, resx, resy, detach_depth, d_loss, d_grad_verts);
+    }
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,881 @@
+// drt_pipeline.hip -- the two-bounce refraction path (render_transparent), its backward, ray_loss and the fused loss.
+#include "drt_device.h"
+
+// ---- the two-bounce refraction path as a compacted wavefront pipeline ---------------------
+//
+// Only ~5-25 % of camera rays hit the object and the three traversals of a path have very
+// different lengths.  One thread per ray start-to-end leaves most lanes idle (measured on the
+// first version: 25 % VALU lane utilisation with the SIMDs issue-bound), so the path is cut
+// into stages that hand COMPACT ray lists to each other:
+//   k_cull     all rays : slab test against the wide root's child boxes; definite miss -> write
+//                         zeros (pure HBM streaming); candidate -> R0 (index + float32 ray)
+//   k_trace    R0       : closest hit -> R0.face                    (persistent, lanes refilled)
+//   k_shade1   R0       : miss -> zeros; hit -> float64 bounce #1; refracted -> R1
+//   k_trace    R1       : closest hit -> R1.face
+//   k_shade2   R1       : miss/TIR -> zeros; else float64 bounces #1+#2 -> provisional outputs, R2
+//   k_trace    R2 (any) : occlusion test of the exit ray -> R2.face
+//   k_finish   R2       : occluded -> zeros; survivors -> list of valid rays (for the backward)
+// k_trace never diverges on "what kind of ray is this": it only walks the BVH, and a lane whose
+// ray ends takes the next ray of its wave's segment at once, so waves stay full.  The float64
+// shading runs in the k_shade kernels over dense lists with no traversal in them.
+// A list push costs ONE returning atomic per 256-thread block iteration (a single counter word
+// sustains only ~90 returning atomics per microsecond on MI355X).
+
+struct RayList {
+    int32_t* idx;     // ray index within the chunk
+    float* ray;       // [cap,6] float32 origin, direction -- exactly what the tracer sees
+    int32_t* face;    // [cap] traversal result
+};
+struct Pipe {
+    RayList r0, r1, r2;
+    unsigned* count;   // [0..2] list sizes of the sub-batch in flight, [4..6] rays handed to k_trace_redo per stage
+    unsigned* valid;   // number of valid rays of the whole call (shared by all sub-batches)
+    int32_t* redo;     // list entries whose traversal overflowed the LDS stack
+};
+
+
+// Staged list append.  A returning atomic on one counter word is served at ~90 per microsecond, and the 2048 resident
+// blocks of a shading kernel all arrive at it together: one push per 256-entry block iteration made k_shade1/2 and
+// k_finish wait on the counter for more than half of their time.  A block therefore collects its survivors in LDS
+// (index + float32 ray) and reserves list space once per ~500-700 of them; the copy-out is fully coalesced.
+constexpr int kStageCap = 768;                       // 21.5 KB: six blocks per CU keep their LDS
+struct StageMem {
+    int32_t idx[kStageCap];
+    float ray[kStageCap * 6];
+    unsigned n, base, wtot[kPathWaves];
+};
+__device__ __forceinline__ void stage_init(StageMem& m) {
+    if (threadIdx.x == 0) m.n = 0u;
+    __syncthreads();
+}
+// whole block; m.n must be stable (a barrier since its last update)
+__device__ __forceinline__ void stage_flush(StageMem& m, const RayList& out, unsigned* counter) {
+    const unsigned cnt = m.n;
+    if (threadIdx.x == 0) m.base = cnt ? atomicAdd(counter, cnt) : 0u;
+    __syncthreads();
+    const unsigned base = m.base;
+    for (unsigned k = threadIdx.x; k < cnt; k += kPathBlock) out.idx[base + k] = m.idx[k];
+    if (out.ray) for (unsigned k = threadIdx.x; k < 6u * cnt; k += kPathBlock) out.ray[6 * (int64_t)base + k] = m.ray[k];
+    __syncthreads();
+    if (threadIdx.x == 0) m.n = 0u;
+    __syncthreads();
+}
+// whole block, once per block iteration (<= kPathBlock new entries)
+__device__ __forceinline__ void stage_push(StageMem& m, bool pred, int32_t i, f3 o, f3 d, const RayList& out, unsigned* counter) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long mask = __ballot(pred);
+    if (lane == 0) m.wtot[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    unsigned slot = m.n, tot = 0;
+    for (int w = 0; w < kPathWaves; ++w) { const unsigned c = m.wtot[w]; if (w < wave) slot += c; tot += c; }
+    if (pred) {
+        slot += (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+        m.idx[slot] = i;
+        if (out.ray) { float* e = m.ray + 6 * slot; e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) m.n += tot;
+    __syncthreads();
+    if (m.n > kStageCap - kPathBlock) stage_flush(m, out, counter);
+}
+
+
+__device__ __forceinline__ Stack make_stack256(int32_t (*lds)[kPathBlock], const TraceCtx& c) {
+    Stack st;
+    st.fast = &lds[0][threadIdx.x];
+    st.stride = kPathBlock;
+    st.depth_fast = kStackFast;
+    st.slow = c.slow_stack + ((int64_t)blockIdx.x * kPathBlock + threadIdx.x) * kStackSlowDev;
+    st.sp = 0;
+    return st;
+}
+
+__device__ __forceinline__ void write_dead(int64_t i, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face2) {
+    const d3 z{0.0, 0.0, 0.0};
+    store_d3(out_ori, i, z);
+    store_d3(out_dir, i, z);
+    mask[3 * i] = 0; mask[3 * i + 1] = 0; mask[3 * i + 2] = 0;
+    face2[i] = -1;
+}
+
+__device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
+    float* e = ray + 6 * (int64_t)slot;
+    e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z;
+}
+
+// Conservative "can this ray touch the mesh at all": two levels of the wide tree (the root's
+// children, then the children of every inner child the ray enters).  k_cull is HBM-bound, so these
+// <= 20 slab tests are free, and every ray they reject is one the traversal stages never see.
+__device__ __forceinline__ unsigned hit_mask4(const Node4Q* __restrict__ node, f3 inv, f3 oi) {
+    const F4* np = reinterpret_cast<const F4*>(node);
+    const int32_t* ch = node->child;
+    float t[4];
+    bool h[4];
+    slab_node4q(np[0], np[1], np[2], inv, oi, INFINITY, t, h);
+    return (unsigned)(h[0] & (ch[0] != kEmptyChild)) | ((unsigned)(h[1] & (ch[1] != kEmptyChild)) << 1) |
+           ((unsigned)(h[2] & (ch[2] != kEmptyChild)) << 2) | ((unsigned)(h[3] & (ch[3] != kEmptyChild)) << 3);
+}
+
+__device__ __forceinline__ bool hits_top_boxes(const Node4Q* __restrict__ nodes, f3 o, f3 d) {
+    const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
+    const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
+    const unsigned m = hit_mask4(nodes, inv, oi);
+    if (m == 0) return false;
+    bool any = false;
+    for (int k = 0; k < 4; ++k) {
+        if (!((m >> k) & 1u)) continue;
+        const int32_t c = nodes[0].child[k];
+        if (c < 0) { any = true; continue; }            // a leaf directly under the root
+        any |= hit_mask4(nodes + c, inv, oi) != 0;
+    }
+    return any;
+}
+
+// `tile_w` > 0: the rays are rows of an image `tile_w` pixels wide (any number of images of a
+// multiple-of-4 height, concatenated).  A block then takes a 64x4 pixel patch per iteration and
+// appends its candidates in 16x4-tile order, so that the 64 rays a traversal wave picks up come from
+// a compact screen region (same BVH nodes, same depth) instead of a 64x1 strip.
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                      const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
+                                                      double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    __shared__ uint8_t s_flag[kPathBlock];
+    __shared__ int s_slot[kPathBlock];
+    const int tid = threadIdx.x;
+    // (`nodes` is a __restrict__ parameter of its own, not the TraceCtx struct, so that the compiler can prove the root
+    // node is never clobbered: it is then fetched once, through the scalar cache, instead of by four vector loads per ray)
+    // patch = 64 pixels wide x 4 rows (every wave reads one full 1536-byte row segment); tiles of 16x4 pixels
+    const int vt = ((tid & 63) >> 4) * 64 + (tid >> 6) * 16 + (tid & 15);   // position of this thread's pixel in tile order
+    const int64_t patches_per_row = tile_w > 0 ? tile_w / 64 : 1;
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        int64_t i = base + tid;
+        if (tile_w > 0) {
+            const int64_t patch = base / kPathBlock;
+            const int64_t y = 4 * (patch / patches_per_row) + (tid >> 6), x = 64 * (patch % patches_per_row) + (tid & 63);
+            i = y * tile_w + x;
+        }
+        bool cand = false;
+        f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f};
+        if (i < n) {
+            // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
+            if (!FUSED || valid[i]) {
+                o = to_f32(load_d3(origin, i)); d = to_f32(load_d3(dir, i));
+                cand = n_tris > 0 && hits_top_boxes(nodes, o, d);
+            }
+            if (!cand) {
+                face1[i] = -1;
+                if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
+            }
+        }
+        // nine out of ten patches are pure background: one barrier (with an OR-reduction) instead of the six of the push
+        if (!__syncthreads_or(cand ? 1 : 0)) continue;
+        int slot;
+        if (tile_w > 0) {
+            s_flag[vt] = cand ? 1 : 0;
+            __syncthreads();
+            s_slot[tid] = block_push(s_flag[tid] != 0, &p.count[0], s_tmp);   // ranks in tile order
+            __syncthreads();
+            slot = s_slot[vt];
+            __syncthreads();
+        } else {
+            slot = block_push(cand, &p.count[0], s_tmp);
+        }
+        if (slot >= 0) { p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d); }
+    }
+}
+
+// Persistent traversal over a ray list.  Each wave owns a contiguous segment of the list; a lane
+// whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
+template <bool ANY>
+__global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
+                                                       int32_t* __restrict__ out_face, int32_t* __restrict__ redo_list, unsigned* redo_count,
+                                                       int refill_min, int inner_min, unsigned long long* stats) {
+    __shared__ int32_t lds[kStackFast + 1][kPathBlock];     // + the dump slot of FastStack: 20 x 1 KB x 8 blocks = the CU's 160 KB
+    FastStack st;
+    st.fast = &lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast; st.sp = 0; st.overflow = false;
+    const unsigned n = *n_ptr;
+    const int lane = threadIdx.x & 63;
+    // Work assignment without atomics, XCD-aware: workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
+    // b % 8), and every XCD has its own L2.  The list -- in tile order, so neighbouring entries walk the same part of the
+    // tree -- is therefore cut into 8 contiguous parts, one per XCD, and only WITHIN its part are the groups of 64
+    // consecutive rays interleaved over that XCD's waves (wave w owns groups w, w + W, w + 2W, ... of the part: coherent
+    // within a group, statistically balanced across waves).  `taken` counts the rays this wave has started.
+    constexpr unsigned kXcd = 8;
+    const unsigned n_groups = (n + 63u) >> 6;
+    const bool split = gridDim.x % kXcd == 0 && n_groups >= 64u * kXcd;
+    const unsigned xcd = split ? blockIdx.x % kXcd : 0u, parts = split ? kXcd : 1u;
+    const unsigned wave = (split ? blockIdx.x / kXcd : blockIdx.x) * kPathWaves + (threadIdx.x >> 6);
+    const unsigned n_waves = (split ? gridDim.x / kXcd : gridDim.x) * kPathWaves;
+    const unsigned part_lo = (unsigned)((unsigned long long)n_groups * xcd / parts), part_hi = (unsigned)((unsigned long long)n_groups * (xcd + 1) / parts);
+    const unsigned part_groups = part_hi - part_lo;
+    const unsigned my_groups = wave < part_groups ? (part_groups - wave + n_waves - 1) / n_waves : 0u;
+    const unsigned my_rays = my_groups << 6;      // upper bound; indices >= n are skipped
+    unsigned taken = 0;
+    int32_t slot = -1;
+    TravState s;
+    unsigned long long wave_steps = 0, lane_steps = 0, refills = 0;   // wave-uniform diagnostics (scalar registers)
+    for (;;) {
+        const unsigned long long idle = __ballot(slot < 0);
+        if (idle != 0 && taken < my_rays && (__popcll(idle) >= refill_min || idle == ~0ull)) {
+            if (slot < 0) {
+                const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
+                if (j < my_rays && k < n) {
+                    const float* e = rays + 6 * (int64_t)k;
+                    trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+                    st.overflow = false;
+                    slot = (int32_t)k;
+                }
+            }
+            taken += (unsigned)__popcll(idle);
+            ++refills;
+        }
+        const unsigned long long busy = __ballot(slot >= 0);
+        if (busy == 0) break;
+        // inner phase ("while-while"): lanes at inner nodes keep descending; lanes that reached a leaf
+        // wait, so that the (longer) triangle code runs once for many lanes instead of on every step
+        for (;;) {
+            const bool at_inner = slot >= 0 && s.cur >= 0;
+            const unsigned long long mi = __ballot(at_inner);
+            if (mi == 0) break;
+            if (__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(mi);
+            if (at_inner) {
+                const bool done = trav_inner(c.nodes, s, st);
+                if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to k_trace_redo
+                    redo_list[atomicAdd(redo_count, 1u)] = slot;
+                    slot = -1;
+                } else if (done) {
+                    out_face[slot] = s.best_face;
+                    slot = -1;
+                }
+            }
+        }
+        // leaf phase
+        const bool at_leaf = slot >= 0 && s.cur < 0;
+        const unsigned long long ml = __ballot(at_leaf);
+        if (ml != 0) {
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(ml);
+            if (at_leaf && trav_leaf<ANY>(c.tris, s, st)) {
+                out_face[slot] = s.best_face;
+                slot = -1;
+            }
+        }
+    }
+    if (stats && lane == 0 && wave_steps) {
+        atomicAdd(stats + 0, wave_steps);
+        atomicAdd(stats + 1, lane_steps);
+        atomicAdd(stats + 2, refills);
+        atomicMax(stats + 3, wave_steps);
+    }
+}
+
+// Second pass for the rays whose traversal overflowed the LDS-only stack of k_trace: one thread per
+// ray, spilling stack.  Normally the list is empty and the kernel returns at once.
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_trace_redo(TraceCtx c, const float* __restrict__ rays, const int32_t* __restrict__ redo_list,
+                                                             const unsigned* __restrict__ redo_count, int32_t* __restrict__ out_face) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    const unsigned n = *redo_count;
+    if (n == 0) return;
+    Stack st = make_stack(lds, c);
+    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
+        const int32_t slot = redo_list[k];
+        const float* e = rays + 6 * (int64_t)slot;
+        out_face[slot] = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st).face;
+    }
+}
+
+// R0 -> R1: primary hit -> float64 bounce #1 -> refracted ray
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                        double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
+    __shared__ StageMem stage;
+    stage_init(stage);
+    const unsigned n0 = p.count[0];
+    // each block takes one contiguous run of the list, so that its survivors stay in list (= screen tile) order
+    const unsigned per_block = ((n0 + gridDim.x - 1) / gridDim.x + kPathBlock - 1) / kPathBlock * kPathBlock;
+    const unsigned first = blockIdx.x * per_block, last = min(n0, first + per_block);
+    for (unsigned base = first; base < last; base += kPathBlock) {
+        const unsigned k = base + threadIdx.x;
+        bool ok = false;
+        int64_t i = 0;
+        f3 o2{0.f, 0.f, 0.f}, d2{0.f, 0.f, 1.f};
+        if (k < n0) {
+            i = p.r0.idx[k];
+            const int32_t f1 = p.r0.face[k];
+            face1[i] = f1;
+            if (f1 >= 0) {
+                d3 v0, v1, v2;
+                int32_t vid[3];
+                Bounce b;
+                load_tri64(c, f1, v0, v1, v2, vid);
+                bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+                ok = !b.tir;
+                o2 = to_f32(b.new_o); d2 = to_f32(b.wt);
+            }
+            if (!ok && !FUSED) write_dead(i, out_ori, out_dir, mask, face2);
+        }
+        stage_push(stage, ok, (int32_t)i, o2, d2, p.r1, &p.count[1]);
+    }
+    stage_flush(stage, p.r1, &p.count[1]);
+}
+
+// R1 -> R2: second hit -> float64 bounces #1 and #2 -> provisional exit ray
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock) k_shade2(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                        double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
+    __shared__ StageMem stage;
+    stage_init(stage);
+    const unsigned n1 = p.count[1];
+    const unsigned per_block = ((n1 + gridDim.x - 1) / gridDim.x + kPathBlock - 1) / kPathBlock * kPathBlock;
+    const unsigned first = blockIdx.x * per_block, last = min(n1, first + per_block);
+    for (unsigned base = first; base < last; base += kPathBlock) {
+        const unsigned k = base + threadIdx.x;
+        bool ok = false;
+        int64_t i = 0;
+        f3 o3{0.f, 0.f, 0.f}, d3f{0.f, 0.f, 1.f};
+        if (k < n1) {
+            i = p.r1.idx[k];
+            const int32_t f2 = p.r1.face[k];
+            if (f2 >= 0) {
+                d3 v0, v1, v2;
+                int32_t vid[3];
+                Bounce b;
+                load_tri64(c, face1[i], v0, v1, v2, vid);
+                bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+                const d3 o2 = b.new_o, d2 = b.wt;
+                load_tri64(c, f2, v0, v1, v2, vid);
+                bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
+                ok = !b.tir;
+                if (ok) {
+                    o3 = to_f32(b.new_o); d3f = to_f32(b.wt);
+                    face2[i] = f2;
+                    if (!FUSED) {
+                        store_d3(out_ori, i, b.new_o);
+                        store_d3(out_dir, i, b.wt);
+                        mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
+                    }
+                }
+            }
+            if (!ok) { if (FUSED) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
+        }
+        stage_push(stage, ok, (int32_t)i, o3, d3f, p.r2, &p.count[2]);
+    }
+    stage_flush(stage, p.r2, &p.count[2]);
+}
+
+// R2: occluded exit rays die; survivors are appended to the caller's list of valid rays (global index).
+__global__ void __launch_bounds__(kPathBlock) k_finish(double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        int32_t* __restrict__ face2, Pipe p, int64_t chunk_base, int32_t* __restrict__ valid_idx) {
+    __shared__ StageMem stage;
+    stage_init(stage);
+    const RayList out{valid_idx, nullptr, nullptr};              // index-only list
+    const unsigned n2 = p.count[2];
+    const unsigned per_block = ((n2 + gridDim.x - 1) / gridDim.x + kPathBlock - 1) / kPathBlock * kPathBlock;
+    const unsigned first = blockIdx.x * per_block, last = min(n2, first + per_block);
+    for (unsigned base = first; base < last; base += kPathBlock) {
+        const unsigned k = base + threadIdx.x;
+        bool keep = false;
+        int64_t i = 0;
+        if (k < n2) {
+            i = p.r2.idx[k];
+            keep = p.r2.face[k] < 0;
+            if (!keep) write_dead(i, out_ori, out_dir, mask, face2);
+        }
+        if (valid_idx) stage_push(stage, keep, (int32_t)(chunk_base + i), f3{0.f, 0.f, 0.f}, f3{0.f, 0.f, 0.f}, out, p.valid);
+    }
+    if (valid_idx) stage_flush(stage, out, p.valid);
+}
+
+__global__ void k_store_count(const unsigned* __restrict__ count, int64_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (int64_t)*count;
+}
+
+
+// Vertex-gradient accumulation through an LDS hash table.  The float64 scatter is bound by the
+// chip's atomic rate (measured 22.6 G global_atomic_add_f64 per second, tools/ubench/atomic_scope.hip,
+// independent of scope or per-XCD privatisation), and neighbouring rays hit neighbouring triangles
+// that share vertices: a block first sums its contributions per vertex in LDS (ds_add_f64 after a
+// compare-and-swap probe on the key) and then issues three global atomics per DISTINCT vertex.
+constexpr int kHashBits = 11, kHashSize = 1 << kHashBits;      // 2048 slots: 8 KB keys + 48 KB sums
+constexpr int kBwdBatch = 1024;                                 // rays per table fill (6 vertex refs each)
+
+struct HashAdd3 {
+    int32_t* keys;      // LDS [kHashSize]
+    double* sums;       // LDS [kHashSize * 3]
+    double* g;          // global fallback / final target
+    __device__ __forceinline__ void operator()(int32_t v, d3 a) const {
+        unsigned h = ((unsigned)v * 2654435761u) >> (32 - kHashBits);
+#pragma unroll 1
+        for (int probe = 0; probe < 24; ++probe) {
+            int32_t k = keys[h];
+            if (k == -1) k = atomicCAS(&keys[h], -1, v);
+            if (k == -1 || k == v) {
+                __hip_atomic_fetch_add(&sums[3 * h + 0], a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sums[3 * h + 1], a.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sums[3 * h + 2], a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+            }
+            h = (h + 1) & (kHashSize - 1);
+        }
+        AtomicAdd3{g}(v, a);     // table crowded: straight to memory
+    }
+};
+
+__device__ __forceinline__ void hash_clear(int32_t* keys, double* sums) {
+    for (int i = threadIdx.x; i < kHashSize; i += blockDim.x) keys[i] = -1;
+    for (int i = threadIdx.x; i < 3 * kHashSize; i += blockDim.x) sums[i] = 0.0;
+    __syncthreads();
+}
+__device__ __forceinline__ void hash_flush(int32_t* keys, double* sums, double* g) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHashSize; i += blockDim.x) {
+        const int32_t v = keys[i];
+        if (v >= 0) AtomicAdd3{g}(v, d3{sums[3 * i], sums[3 * i + 1], sums[3 * i + 2]});
+    }
+    __syncthreads();
+}
+
+// Backward without a saved list: compact the rays whose path completed (face2 >= 0).
+__global__ void __launch_bounds__(kPathBlock) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, int64_t chunk_base,
+                                                               int32_t* __restrict__ list, unsigned* counter) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        const int64_t i = base + threadIdx.x;
+        const int slot = block_push(i < n && face2[i] >= 0, counter, s_tmp);
+        if (slot >= 0) list[slot] = (int32_t)(chunk_base + i);
+    }
+}
+
+// Backward (full waves over the list of valid rays): recompute both bounces from (face1, face2),
+// reverse them, scatter the six vertex gradients.
+__global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                    const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
+                                                    const double* __restrict__ g_out_ori, const double* __restrict__ g_out_dir,
+                                                    double* grad_verts, const int32_t* __restrict__ list, const unsigned* __restrict__ n_u32,
+                                                    const int64_t* __restrict__ n_i64) {
+    __shared__ int32_t hkeys[kHashSize];
+    __shared__ double hsums[3 * kHashSize];
+    const int64_t n = n_i64 ? *n_i64 : (int64_t)*n_u32;
+    const HashAdd3 add{hkeys, hsums, grad_verts};
+    for (int64_t base = blockIdx.x * (int64_t)kBwdBatch; base < n; base += (int64_t)gridDim.x * kBwdBatch) {
+        hash_clear(hkeys, hsums);
+        const int64_t end = base + kBwdBatch < n ? base + kBwdBatch : n;
+        for (int64_t k = base + threadIdx.x; k < end; k += blockDim.x) {
+            const int64_t i = list[k];
+            const d3 z{0.0, 0.0, 0.0};
+            const d3 g_ori = g_out_ori ? load_d3(g_out_ori, i) : z;
+            const d3 g_dir = g_out_dir ? load_d3(g_out_dir, i) : z;
+            path_recompute_backward(c, load_d3(origin, i), load_d3(dir, i), face1[i], face2[i], g_ori, g_dir, add);
+        }
+        hash_flush(hkeys, hsums, grad_verts);
+    }
+}
+
+
+// ray_loss forward: loss, dense d loss / d out_dir, and (optionally) the list of contributing rays so
+// that the backward can rescale only those rows instead of streaming the whole [N,3] tensor again.
+// Three things bound the obvious one-ray-per-thread version (tools/ubench/ray_loss_probe.py, 75.5 M rays): 1-byte loads
+// of the flags (the vector-memory pipeline is paid per instruction: 0.42 ms for 0.3 GB), 8-byte strided stores of the
+// (mostly zero) gradient, and one returning atomic per block iteration on the list counter (a single word sustains
+// ~90 of them per microsecond: 3.3 ms when the contributing rays are scattered).  So: a thread takes FOUR consecutive
+// rays (one 4-byte load of `valid`, three of `mask`), a wave zero-fills its 6 KB of gradient with lane-consecutive 16-byte
+// stores (16-byte stores at a 96-byte lane stride were 3x slower: partial lines) and the block collects row indices in LDS,
+// reserving list space with one atomic per ~2000 rows.
+struct alignas(16) Dbl2 { double a, b; };
+constexpr int kLossRays = 4;                        // rays per thread
+constexpr int kLossBuf = 2048;                      // >= 2 x the 1024 rows one block iteration can add
+__global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
+                                                          const uint8_t* __restrict__ mask, const double* __restrict__ screen_pixel,
+                                                          const uint8_t* __restrict__ valid, int64_t n, double* loss,
+                                                          double* __restrict__ g_out_dir, int32_t* __restrict__ list, unsigned* list_count) {
+    __shared__ unsigned s_tmp[kPathWaves + 2];      // wave totals, [kPathWaves] rows buffered, [kPathWaves + 1] reserved list base
+    __shared__ int32_t s_buf[kLossBuf];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    if (threadIdx.x == 0) s_tmp[kPathWaves] = 0u;
+    __syncthreads();
+    auto flush = [&]() {                            // reached by the whole block
+        const unsigned cnt = s_tmp[kPathWaves];
+        if (threadIdx.x == 0) s_tmp[kPathWaves + 1] = cnt ? atomicAdd(list_count, cnt) : 0u;
+        __syncthreads();
+        const unsigned base = s_tmp[kPathWaves + 1];
+        for (unsigned k = threadIdx.x; k < cnt; k += kPathBlock) list[base + k] = s_buf[k];
+        __syncthreads();
+        if (threadIdx.x == 0) s_tmp[kPathWaves] = 0u;
+        __syncthreads();
+    };
+    double acc = 0.0;
+    const int64_t span = (int64_t)kLossRays * kPathBlock;
+    for (int64_t base = blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
+        const int64_t i0 = base + kLossRays * (int64_t)threadIdx.x;
+        bool on[kLossRays] = {false, false, false, false};
+        d3 g[kLossRays] = {d3{0.0, 0.0, 0.0}, d3{0.0, 0.0, 0.0}, d3{0.0, 0.0, 0.0}, d3{0.0, 0.0, 0.0}};
+        const bool full = i0 + kLossRays - 1 < n;
+        if (full) {
+            const uint32_t v4 = *reinterpret_cast<const uint32_t*>(valid + i0);
+            const uint32_t* mp = reinterpret_cast<const uint32_t*>(mask + 3 * i0);
+            const uint32_t m0 = mp[0], m1 = mp[1], m2 = mp[2];
+            on[0] = (v4 & 0xFFu) && (m0 & 0xFFu);                 // mask[3 i0]
+            on[1] = (v4 & 0xFF00u) && (m0 & 0xFF000000u);         // mask[3 i0 + 3]
+            on[2] = (v4 & 0xFF0000u) && (m1 & 0xFF0000u);         // mask[3 i0 + 6]
+            on[3] = (v4 & 0xFF000000u) && (m2 & 0xFF00u);         // mask[3 i0 + 9]
+        } else {
+            for (int k = 0; k < kLossRays; ++k) on[k] = i0 + k < n && valid[i0 + k] && mask[3 * (i0 + k)];
+        }
+        for (int k = 0; k < kLossRays; ++k)
+            if (on[k]) acc += ray_loss_term(load_d3(out_ori, i0 + k), load_d3(out_dir, i0 + k), load_d3(screen_pixel, i0 + k), g[k]);
+        if (g_out_dir) {
+            const int64_t w0 = i0 - kLossRays * (int64_t)lane;                  // first ray of this wave: 256 rays = 6144 contiguous bytes
+            if (w0 + kLossRays * 64 <= n) {
+                // zeros for the whole run with fully coalesced 16-byte stores (lane-consecutive), then the few rows that
+                // carry a gradient are overwritten -- after the zero stores have been acknowledged (s_waitcnt)
+                Dbl2* q = reinterpret_cast<Dbl2*>(g_out_dir + 3 * w0);
+                for (int j = 0; j < 6; ++j) q[j * 64 + lane] = Dbl2{0.0, 0.0};
+                if (__ballot(on[0] | on[1] | on[2] | on[3]) != 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int k = 0; k < kLossRays; ++k) if (on[k]) store_d3(g_out_dir, i0 + k, g[k]);
+                }
+            } else {
+                for (int k = 0; k < kLossRays; ++k) if (i0 + k < n) store_d3(g_out_dir, i0 + k, g[k]);
+            }
+        }
+        if (list) {
+            unsigned long long m[kLossRays];
+            unsigned before[kLossRays], tot = 0;
+            for (int k = 0; k < kLossRays; ++k) { m[k] = __ballot(on[k]); before[k] = tot; tot += (unsigned)__popcll(m[k]); }
+            if (lane == 0) s_tmp[wave] = tot;
+            __syncthreads();
+            unsigned wbase = s_tmp[kPathWaves], add = 0;
+            for (int w = 0; w < kPathWaves; ++w) { const unsigned c = s_tmp[w]; if (w < wave) wbase += c; add += c; }
+            if (add) {                               // block-uniform
+                for (int k = 0; k < kLossRays; ++k)
+                    if (on[k]) s_buf[wbase + before[k] + (unsigned)__popcll(m[k] & lower)] = (int32_t)(i0 + k);
+                __syncthreads();
+                if (threadIdx.x == 0) s_tmp[kPathWaves] += add;
+                __syncthreads();
+                if (s_tmp[kPathWaves] > kLossBuf - kLossRays * kPathBlock) flush();
+            } else {
+                __syncthreads();
+            }
+        }
+    }
+    if (list) flush();
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+}
+
+// x[list[k], 0..2] *= *scale
+__global__ void __launch_bounds__(256) k_scale_rows3(double* __restrict__ x, const int32_t* __restrict__ list, const unsigned* __restrict__ n_ptr,
+                                                     const double* __restrict__ scale) {
+    const unsigned n = *n_ptr;
+    const double sc = *scale;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int64_t i = list[k];
+        x[3 * i] *= sc; x[3 * i + 1] *= sc; x[3 * i + 2] *= sc;
+    }
+}
+
+// Fused loss, last stage (full waves over Q2): recompute the path in float64, loss term, adjoint.
+__global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                        const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
+                                                        const int32_t* __restrict__ face2, Pipe p, double* loss, double* grad_verts,
+                                                        unsigned long long* n_valid) {
+    __shared__ int32_t hkeys[kHashSize];
+    __shared__ double hsums[3 * kHashSize];
+    const unsigned n2 = p.count[2];
+    const HashAdd3 add{hkeys, hsums, grad_verts};
+    double acc = 0.0;
+    unsigned cnt = 0;
+    for (unsigned base = blockIdx.x * kBwdBatch; base < n2; base += gridDim.x * kBwdBatch) {
+        hash_clear(hkeys, hsums);
+        const unsigned end = base + kBwdBatch < n2 ? base + kBwdBatch : n2;
+        for (unsigned k = base + threadIdx.x; k < end; k += blockDim.x) {
+            if (p.r2.face[k] >= 0) continue;   // occluded exit ray
+            const int64_t i = p.r2.idx[k];
+            const int32_t f2 = face2[i];
+            const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+            d3 v0, v1, v2;
+            int32_t vid1[3], vid2[3];
+            Bounce b1, b2;
+            load_tri64(c, face1[i], v0, v1, v2, vid1);
+            bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b1);
+            load_tri64(c, f2, v0, v1, v2, vid2);
+            bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
+            d3 g_dir;
+            acc += ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
+            ++cnt;
+            const d3 z{0.0, 0.0, 0.0};
+            d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
+            bounce_backward(b2, z, g_dir, ga, gb, gc, g_o, g_d);
+            add(vid2[0], ga); add(vid2[1], gb); add(vid2[2], gc);
+            ga = z; gb = z; gc = z;
+            bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
+            add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
+        }
+        hash_flush(hkeys, hsums, grad_verts);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+    if (n_valid && cnt) atomicAdd(n_valid, (unsigned long long)cnt);
+}
+
+
+__global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // sub-batches on different streams may report concurrently: atomics
+    atomicAdd(&tot[kStageCull], n_rays);
+    atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
+    atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
+    atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[2]);
+    atomicAdd(&tot[fused ? kStageLossBwdFused : kStageFinish], (unsigned long long)qcount[2]);
+}
+__global__ void k_prof_counts_bwd(const unsigned* __restrict__ vcount, unsigned long long n_rays, unsigned long long* __restrict__ tot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    tot[kStageCollect] += n_rays;
+    tot[kStageBackward] += vcount[0];
+}
+
+// Queue workspace for one chunk of `n` rays (grown, never shrunk).  Growing frees the old buffers,
+// which synchronises the device once; steady-state calls allocate nothing.
+static int ensure_queues(drt_scene::Sub& w, int64_t n, bool fused) {
+    if (n > w.q_cap) {
+        for (int k = 0; k < 3; ++k) {
+            (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]);
+            w.q_idx[k] = nullptr; w.q_ray[k] = nullptr; w.q_face[k] = nullptr;
+        }
+        w.q_cap = 0;
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(hipMalloc(&w.q_idx[k], sizeof(int32_t) * n));
+            HIP_TRY(hipMalloc(&w.q_ray[k], sizeof(float) * 6 * n));
+            HIP_TRY(hipMalloc(&w.q_face[k], sizeof(int32_t) * n));
+        }
+        (void)hipFree(w.redo); w.redo = nullptr;
+        HIP_TRY(hipMalloc(&w.redo, sizeof(int32_t) * n));
+        w.q_cap = n;
+    }
+    if (fused && n > w.fused_cap) {
+        (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2);
+        w.tmp_face1 = w.tmp_face2 = nullptr; w.fused_cap = 0;
+        HIP_TRY(hipMalloc(&w.tmp_face1, sizeof(int32_t) * n));
+        HIP_TRY(hipMalloc(&w.tmp_face2, sizeof(int32_t) * n));
+        w.fused_cap = n;
+    }
+    return DRT_OK;
+}
+
+static Pipe pipe_of(const drt_scene* s, const drt_scene::Sub& w) {
+    return Pipe{RayList{w.q_idx[0], w.q_ray[0], w.q_face[0]}, RayList{w.q_idx[1], w.q_ray[1], w.q_face[1]},
+                RayList{w.q_idx[2], w.q_ray[2], w.q_face[2]}, w.qcount, s->vcount, w.redo};
+}
+
+// How a call of n_rays is cut: `size` rays per sub-batch (a multiple of `unit`), `count` sub-batches, dealt
+// round-robin to `streams` internal streams.  Sub-batches are at most chunk_rays (workspace bound) and, when
+// there is enough work, at least min_sub_rays, so that small calls are not shredded into launch overhead.
+struct Plan { int64_t size; int count; int streams; };
+static Plan plan_call(const drt_scene* s, int64_t n_rays, int tile_w) {
+    int64_t unit = 256;
+    if (tile_w >= 64 && tile_w % 64 == 0) unit = 4 * (int64_t)tile_w;       // whole rows of 64x4 patches per sub-batch
+    int64_t count = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
+    const int64_t by_min = n_rays / s->min_sub_rays;
+    const int64_t most = (int64_t)s->n_sub * s->sub_per_stream;
+    const int64_t want = by_min < most ? by_min : most;
+    if (want > count) count = want;
+    if (count < 1) count = 1;
+    int64_t size = (n_rays + count - 1) / count;
+    size = (size + unit - 1) / unit * unit;
+    count = (n_rays + size - 1) / size;
+    Plan pl;
+    pl.size = size; pl.count = (int)count; pl.streams = count < s->n_sub ? (int)count : s->n_sub;
+    if (s->prof_serial) pl.streams = 1;     // measurement mode: the same sub-batches, one after the other on one stream
+    return pl;
+}
+
+// cull -> trace -> shade1 -> trace -> shade2 -> trace(any) for one sub-batch; the caller appends the last stage.
+extern "C++" {
+template <bool FUSED>
+static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
+                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w) {
+    const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
+    if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
+    { StageTimer t(s, st, kStageCull);
+      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
+    { StageTimer t(s, st, kStageTrace1);
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
+      k_trace_redo<false><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, p.r0.face); }
+    { StageTimer t(s, st, kStageShade1);
+      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
+    { StageTimer t(s, st, kStageTrace2);
+      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
+      k_trace_redo<false><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, p.r1.face); }
+    { StageTimer t(s, st, kStageShade2);
+      k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
+    { StageTimer t(s, st, kStageTrace3);
+      k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
+      k_trace_redo<true><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, p.r2.face); }
+}
+}  // extern "C++"
+
+// Fork: the internal streams wait for everything already enqueued on the caller's stream.
+static int fork_streams(drt_scene* s, hipStream_t st, int streams) {
+    HIP_TRY(hipEventRecord(s->fork_ev, st));
+    for (int k = 0; k < streams; ++k) HIP_TRY(hipStreamWaitEvent(s->sub[k].stream, s->fork_ev, 0));
+    return DRT_OK;
+}
+// Join: the caller's stream waits for every internal stream.
+static int join_streams(drt_scene* s, hipStream_t st, int streams) {
+    for (int k = 0; k < streams; ++k) {
+        HIP_TRY(hipEventRecord(s->sub[k].done, s->sub[k].stream));
+        HIP_TRY(hipStreamWaitEvent(st, s->sub[k].done, 0));
+    }
+    return DRT_OK;
+}
+
+static PathCtx sub_ctx(const drt_scene* s, const drt_scene::Sub& w, const double* d_verts, double ior_int, double ior_ext) {
+    PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    pc.tc.slow_stack = w.slow_stack;     // concurrent kernels must not share overflow stacks
+    return pc;
+}
+int pipeline_blocks_per_cu() {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    return per_cu;
+}
+
+extern "C" {
+
+int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                       double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
+                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rays == 0) {
+        if (d_n_valid) HIP_TRY(hipMemsetAsync(d_n_valid, 0, sizeof(int64_t), st));
+        return DRT_OK;
+    }
+    if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
+    if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
+    const Plan pl = plan_call(s, n_rays, tile_w);
+    for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, false); if (rc) return rc; }
+    HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
+    int rc = fork_streams(s, st, pl.streams);
+    if (rc) return rc;
+    for (int j = 0; j < pl.count; ++j) {
+        drt_scene::Sub& w = s->sub[j % pl.streams];
+        const int64_t b = j * pl.size;
+        const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
+        const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
+        const Pipe p = pipe_of(s, w);
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
+        launch_chunk<false>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                            d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w);
+        { StageTimer t(s, w.stream, kStageFinish);
+          k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 0);
+    }
+    rc = join_streams(s, st, pl.streams);
+    if (rc) return rc;
+    if (d_n_valid) k_store_count<<<1, 64, 0, st>>>(s->vcount, d_n_valid);
+    if (s->prof_on) s->prof_stream = st;
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                        double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                        const int32_t* d_valid_idx, const int64_t* d_n_valid,
+                        const double* d_grad_out_ori, const double* d_grad_out_dir, double* d_grad_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (n_rays == 0 || (!d_grad_out_ori && !d_grad_out_dir)) return DRT_OK;
+    if (!d_verts || !d_origin || !d_dir || !d_face1 || !d_face2 || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
+    hipStream_t st = (hipStream_t)stream;
+    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    if (d_valid_idx) {   // the forward's list of completed paths: no pass over the dense arrays at all
+        StageTimer t(s, st, kStageBackward);
+        k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+                                                   d_valid_idx, nullptr, d_n_valid);
+    } else {             // no list saved: compact face2 >= 0 first (on the caller's stream, workspace of sub-stream 0)
+        drt_scene::Sub& w = s->sub[0];
+        const int64_t chunk = n_rays < s->chunk_rays ? n_rays : s->chunk_rays;
+        int rc = ensure_queues(w, chunk, false);
+        if (rc) return rc;
+        for (int64_t b = 0; b < n_rays; b += chunk) {
+            const int64_t n = n_rays - b < chunk ? n_rays - b : chunk;
+            HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
+            { StageTimer t(s, st, kStageCollect);
+              k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, b, w.q_idx[0], s->vcount); }
+            { StageTimer t(s, st, kStageBackward);
+              k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+                                                         w.q_idx[0], s->vcount, nullptr); }
+            if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->vcount, (unsigned long long)n, s->prof_counts);
+        }
+    }
+    if (s->prof_on) s->prof_stream = st;
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t* d_mask, const double* d_screen_pixel,
+                 const uint8_t* d_valid, int64_t n_rays, double* d_loss, double* d_grad_out_dir,
+                 int32_t* d_list, uint32_t* d_n_list, void* stream) {
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_out_ori || !d_out_dir || !d_mask || !d_screen_pixel || !d_valid || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
+    if ((d_list == nullptr) != (d_n_list == nullptr)) return fail(DRT_E_INVALID, "d_list and d_n_list go together");
+    k_ray_loss<<<grid_for((n_rays + kLossRays - 1) / kLossRays, kPathBlock, 4096), kPathBlock, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays,
+                                                                                          d_loss, d_grad_out_dir, d_list, d_n_list);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list, const double* d_scale, void* stream) {
+    if (!d_x || !d_list || !d_n_list || !d_scale) return fail(DRT_E_INVALID, "null pointer argument");
+    k_scale_rows3<<<1024, 256, 0, (hipStream_t)stream>>>(d_x, d_list, d_n_list, d_scale);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir,
+                              const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays, double ior_int,
+                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, int tile_w, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    const Plan pl = plan_call(s, n_rays, tile_w);
+    for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true); if (rc) return rc; }
+    int rc = fork_streams(s, st, pl.streams);
+    if (rc) return rc;
+    for (int j = 0; j < pl.count; ++j) {
+        drt_scene::Sub& w = s->sub[j % pl.streams];
+        const int64_t b = j * pl.size;
+        const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
+        const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
+        const Pipe p = pipe_of(s, w);
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
+        launch_chunk<true>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w);
+        { StageTimer t(s, w.stream, kStageLossBwdFused);
+          k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
+                                                               d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1);
+    }
+    rc = join_streams(s, st, pl.streams);
+    if (rc) return rc;
+    if (s->prof_on) s->prof_stream = st;
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// drt_scene.h -- what the translation units of libdrt_hip.so share: the scene object behind drt_scene_t, launch
+// constants, error plumbing, the per-stage timer.  (drt_build.hip: LBVH build + checks; drt_trace.hip: B1 queries and
+// closest point; drt_pipeline.hip: the refraction pipeline, its backward and losses; drt_edges.hip: silhouette and
+// smoothness branches; drt_api.hip: create / destroy / profiling.)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared.  Wave size is 64 throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/drt_hip.h"
+#include "drt_common.h"
+#include "drt_closest.h"
+#include "drt_edge.h"
+#include "drt_lbvh.h"
+#include "drt_path.h"
+#include "drt_shade.h"
+#include "drt_traverse.h"
+#include "drt_tri.h"
+
+using namespace drt;
+
+
+// ------------------------------------------------------------------------------------------
+// error plumbing (defined in drt_api.hip)
+// ------------------------------------------------------------------------------------------
+int fail(int code, const char* fmt, ...);
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(DRT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// scene object
+// ------------------------------------------------------------------------------------------
+constexpr int kTraceBlock = 128;       // threads per block in traversal kernels (2 waves)
+#ifndef DRT_STACK_FAST
+#define DRT_STACK_FAST 19
+#endif
+constexpr int kStackFast = DRT_STACK_FAST;         // LDS stack entries per lane (19.5 KB per 256-thread block -> 8 blocks = 32 waves per CU)
+constexpr int kStackSlowDev = 45;      // global overflow entries per thread (LBVH height <= 30 + log2 F <= 64)
+constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
+constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds the list workspace (96 B per ray of the largest pass)
+
+constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
+
+// stage ids of drt_profile_read
+enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kProfStages };
+
+struct BuildParams {   // written by k_bounds, read by the later build kernels
+    float lox, loy, loz;
+    float ix, iy, iz;   // 1 / extent per axis (0 extent -> 0)
+    float pad;
+    int32_t reserved;
+};
+
+struct drt_scene {
+    int device = 0;
+    int64_t n_faces = 0, n_verts = 0;
+    int64_t cap_faces = 0, cap_verts = 0;
+    int32_t* faces = nullptr;      // [F,3] copy
+    float* verts = nullptr;        // [V,3] float32 copy (tracer precision)
+    Node* nodes = nullptr;         // [max(F-1,1)] binary radix tree (build intermediate)
+    Node4Q* wide = nullptr;        // [max(F-1,1)] 4-wide tree (quantised, 64 B/node) read by the traversal, indexed by binary root
+    int32_t *range_lo = nullptr, *range_hi = nullptr;   // sorted-slot range of each binary node
+    TriRec* tris = nullptr;        // [F] Morton order
+    uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
+    uint32_t* hist = nullptr;      // [kRadix * tiles]
+    int32_t *parent_inner = nullptr, *parent_leaf = nullptr;
+    uint32_t* flags = nullptr;
+    BuildParams* params = nullptr;
+    int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev] (B1 queries and edge probes)
+    unsigned long long* scratch = nullptr;  // small counters
+    // wavefront-pipeline workspace, sized for one chunk of rays, allocated on first use
+    // Pipeline workspaces: one per internal stream.  A call is cut into sub-batches that run on
+    // different HIP streams, so that the HBM-bound k_cull of one sub-batch overlaps the latency-bound
+    // k_trace of another and the tail of one kernel is filled by the next sub-batch's work.
+    struct Sub {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        int32_t* q_idx[3] = {nullptr, nullptr, nullptr};     // ray lists R0..R2: index,
+        float* q_ray[3] = {nullptr, nullptr, nullptr};       //   float32 ray [cap,6],
+        int32_t* q_face[3] = {nullptr, nullptr, nullptr};    //   traversal result
+        int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;  // fused path keeps face ids here; backward fallback list
+        unsigned* qcount = nullptr;                          // [8] list sizes + redo counts of the sub-batch in flight
+        int32_t* redo = nullptr;                             // [cap] rays for k_trace_redo
+        int32_t* slow_stack = nullptr;                       // traversal-stack overflow area of this stream's kernels
+        int64_t q_cap = 0, fused_cap = 0;
+    };
+    static constexpr int kMaxSub = 4;
+    Sub sub[kMaxSub];
+    int n_sub = 2;                 // internal streams in use
+    int sub_per_stream = 1;        // sub-batches dealt to each stream (when the call is large enough)
+    int64_t min_sub_rays = 1 << 24;   // do not cut a call into sub-batches smaller than this
+    hipEvent_t fork_ev = nullptr;
+    unsigned* vcount = nullptr;    // [0] valid rays of the whole call, [1] silhouette items of drt_vh_loss_fused
+    uint32_t* vh_list = nullptr;   // (view, edge) items of drt_vh_loss_fused: its own buffer, so that the call may run on
+    int64_t vh_cap = 0;            //   another stream than a pipeline call (which owns the Sub workspaces)
+    // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream
+    bool prof_on = false;
+    bool prof_stats = false;                  // level 2: k_trace also accumulates visit statistics (adds contended atomics)
+    bool prof_serial = false;                 // level 3: sub-batches run on ONE internal stream, so that each kernel is timed alone
+    std::vector<hipEvent_t> prof_ev;          // pool, used pairwise
+    std::vector<int> prof_stage;              // stage id of pair k
+    size_t prof_used = 0;                     // events handed out since the last read
+    unsigned long long* prof_counts = nullptr;  // device [kProfStages]: queue sizes accumulated per stage
+    hipStream_t prof_stream = nullptr;
+    int n_cu = 256;
+    int grid_trace = 2048;         // resident blocks of the pure-traversal kernels
+    int grid_path = 2048;          // resident 256-thread blocks of k_trace
+    int64_t trace_stats[12] = {0};  // per k_trace stage: wave-steps, lane-steps, refills, max wave-steps (last profile read)
+    int refill_min = 16;           // k_trace refills a wave once this many lanes are idle
+    int inner_min = 16;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
+    int64_t chunk_rays = kChunkRays;
+
+    bool built = false;
+};
+
+
+// occupancy of the persistent kernels (defined next to them: drt_trace.hip, drt_pipeline.hip)
+int query_blocks_per_cu();
+int pipeline_blocks_per_cu();
+
+// defined in drt_build.hip
+void scene_free_mesh(drt_scene* s);
+int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts);
+int rebuild(drt_scene* s, hipStream_t st);
+
+inline int grid_for(int64_t n, int block, int cap) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+inline TraceCtx trace_ctx(const drt_scene* s) { return TraceCtx{s->wide, s->tris, (int)s->n_faces, s->slow_stack}; }
+inline PathCtx path_ctx(const drt_scene* s, const double* d_verts, double ior_int, double ior_ext) {
+    return PathCtx{trace_ctx(s), s->faces, d_verts, ior_int, ior_ext};
+}
+
+#define CHECK_SCENE(s)                                                        \
+    do {                                                                      \
+        if (!(s)) return fail(DRT_E_INVALID, "null scene");                   \
+        HIP_TRY(hipSetDevice((s)->device));                                   \
+    } while (0)
+#define CHECK_BUILT(s)                                                                          \
+    do {                                                                                        \
+        CHECK_SCENE(s);                                                                         \
+        if (!(s)->built) return fail(DRT_E_INVALID, "no mesh: call drt_update_mesh first");     \
+    } while (0)
+
+// RAII-ish stage timer: records an event pair around a kernel launch when profiling is on.
+struct StageTimer {
+    drt_scene* s; hipStream_t st; bool on;
+    StageTimer(drt_scene* s_, hipStream_t st_, int stage) : s(s_), st(st_), on(false) {
+        if (!s->prof_on || s->prof_used + 2 > s->prof_ev.size()) return;
+        on = true;
+        s->prof_stage[s->prof_used / 2] = stage;
+        if (!s->prof_stream) s->prof_stream = st;
+        (void)hipEventRecord(s->prof_ev[s->prof_used], st);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord(s->prof_ev[s->prof_used + 1], st);
+        s->prof_used += 2;
+    }
+};

@@ -1,0 +1,108 @@
+// drt_trace.hip -- boundary B1 (closest / any hit per ray, the exhaustive diagnostic) and the closest-point query.
+#include "drt_device.h"
+
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_intersect(TraceCtx c, const float* __restrict__ rays, int64_t n,
+                                                            float* __restrict__ T, int32_t* __restrict__ ID,
+                                                            uint8_t* __restrict__ hitflag) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        const f3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+        const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, o, d, st);
+        if (ANY) {
+            hitflag[i] = h.face >= 0 ? 1 : 0;
+        } else {
+            T[i] = h.t;
+            ID[i] = h.face;
+        }
+    }
+}
+
+// Brute force over every triangle with the same test: the GPU-side checker of the traversal.
+__global__ void __launch_bounds__(256) k_bruteforce(const TriRec* __restrict__ tris, int n_tris, const float* __restrict__ rays,
+                                                    int64_t n, float* __restrict__ T, int32_t* __restrict__ ID) {
+    __shared__ TriRec tile[256];
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    f3 o{0, 0, 0}, d{0, 0, 1};
+    if (live) { o = f3{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}; d = f3{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]}; }
+    float best = INFINITY;
+    int32_t best_face = -1;
+    for (int j0 = 0; j0 < n_tris; j0 += 256) {
+        __syncthreads();
+        if (j0 + (int)threadIdx.x < n_tris) tile[threadIdx.x] = tris[j0 + threadIdx.x];
+        __syncthreads();
+        const int m = min(256, n_tris - j0);
+        for (int j = 0; j < m; ++j) {
+            const TriRec t = tile[j];
+            float tt;
+            if (tri_hit(o, d, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) {
+                if (tt < best || (tt == best && t.face < best_face)) { best = tt; best_face = t.face; }
+            }
+        }
+    }
+    if (live) { T[i] = best_face >= 0 ? best : -1.0f; ID[i] = best_face; }
+}
+
+// ---- closest point on the mesh (the reference's acceptance metric, README.md:11: vertex-to-surface distance)
+__global__ void __launch_bounds__(kTraceBlock) k_closest_point(TraceCtx c, const int32_t* __restrict__ faces, const float* __restrict__ verts,
+                                                                const double* __restrict__ points, int64_t n, double* __restrict__ dist,
+                                                                int32_t* __restrict__ face, double* __restrict__ closest) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        const Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(points, i), st);
+        dist[i] = sqrt(r.dist2);
+        if (face) face[i] = r.face;
+        if (closest) store_d3(closest, i, r.point);
+    }
+}
+
+int query_blocks_per_cu() {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_intersect<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+    return per_cu;
+}
+
+extern "C" {
+
+int drt_intersect(drt_scene_t* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || (n_rays && (!d_rays || !d_T || !d_ID))) return fail(DRT_E_INVALID, "bad ray arguments");
+    if (n_rays == 0) return DRT_OK;
+    k_intersect<false><<<grid_for(n_rays, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, d_T, d_ID, nullptr);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_intersect_any(drt_scene_t* s, const float* d_rays, int64_t n_rays, uint8_t* d_hit, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || (n_rays && (!d_rays || !d_hit))) return fail(DRT_E_INVALID, "bad ray arguments");
+    if (n_rays == 0) return DRT_OK;
+    k_intersect<true><<<grid_for(n_rays, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, nullptr, nullptr, d_hit);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || (n_rays && (!d_rays || !d_T || !d_ID))) return fail(DRT_E_INVALID, "bad ray arguments");
+    if (n_rays == 0) return DRT_OK;
+    k_bruteforce<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(s->tris, (int)s->n_faces, d_rays, n_rays, d_T, d_ID);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double* d_dist, int32_t* d_face, double* d_closest, void* stream) {
+    CHECK_BUILT(s);
+    if (n < 0) return fail(DRT_E_INVALID, "negative point count");
+    if (n == 0) return DRT_OK;
+    if (!d_points || !d_dist) return fail(DRT_E_INVALID, "null pointer argument");
+    k_closest_point<<<grid_for(n, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), s->faces, s->verts, d_points, n, d_dist, d_face, d_closest);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+
+}  // extern "C"

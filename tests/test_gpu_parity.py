@@ -440,8 +440,7 @@ def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
     import sys
     from drt_amd import build
     so = str(tmp_path / "libdrt_hip_stack3.so")
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc] + build.FLAGS + ["-DDRT_STACK_FAST=3", "-o", so, build.SRC, build.SRC_HOST])
+    build.build(force=True, out=so, extra_flags=("-DDRT_STACK_FAST=3",))
     env = dict(os.environ, DRT_HIP_LIB=so)
     sel = "test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or test_silhouette_branch_vs_golden"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
