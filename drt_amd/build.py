@@ -41,7 +41,7 @@ def build(force=False, verbose=False, out=OUT, extra_flags=()):
             return obj
         with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
             objs = list(pool.map(compile_one, UNITS))
-        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", out] + objs
         if verbose:
             print(" ".join(link), flush=True)
         subprocess.check_call(link)
