@@ -16,10 +16,11 @@ What is different, and why:
     ``np.random.seed`` the reference's one-view-per-step SGD trajectory visits the same views
     (tests/golden/view_schedule.npz holds the reference's own sequences); ``rng=`` substitutes a private
     ``np.random.RandomState``;
-  * the HDF5 captures are not distributed with the reference and h5py is not part of this image, so the
-    loader takes the capture's datasets (``cam_proj`` [72,4,4], ``cam_k`` [3,3], ``screen_position``
-    [72,P,3], ``mask`` [72,resy,resx], optional ``ray_origin`` / ``ray_dir`` [72,P,3]) from an ``.npz`` with
-    the same keys, or from the ``.h5`` itself where h5py is importable (tools/h5_to_npz.py converts).
+  * the HDF5 captures are not distributed with the reference and h5py is not part of this image: the loader reads
+    the capture's datasets (``cam_proj`` [72,4,4], ``cam_k`` [3,3], ``screen_position`` [72,P,3], ``mask``
+    [72,resy,resx], optional ``ray_origin`` / ``ray_dir`` [72,P,3]) from the ``.h5`` with h5py where it is
+    importable and otherwise with drt_amd.hdf5_lite (pure Python; plain numeric datasets, contiguous or chunked,
+    optionally deflate-compressed), or from an ``.npz`` with the same keys (tools/h5_to_npz.py converts).
 """
 from __future__ import annotations
 
@@ -85,16 +86,16 @@ class Data:
 
 
 def _open_capture(path):
-    """Mapping of the capture's datasets.  ``.npz`` always; ``.h5`` / ``.hdf5`` needs h5py."""
+    """Mapping of the capture's datasets: ``.npz``, or ``.h5`` / ``.hdf5`` through h5py or drt_amd.hdf5_lite."""
     if not os.path.exists(path):
         raise FileNotFoundError(f"capture {path!r} not found")
     if path.endswith(".npz"):
         return np.load(path)
     try:
         import h5py
-    except ImportError as e:
-        raise RuntimeError(f"{path}: reading HDF5 needs h5py, which this environment lacks; convert the capture once with "
-                           "tools/h5_to_npz.py where h5py exists and pass the .npz") from e
+    except ImportError:
+        from . import hdf5_lite                 # pure-Python reader for plain numeric datasets (what the captures hold)
+        return hdf5_lite.File(path)
     return h5py.File(path, "r")
 
 

@@ -1,0 +1,81 @@
+"""drt_amd.hdf5_lite (the capture reader used where h5py is missing) against HDF5 files written by the HDF5 C
+library and by h5py (tests/golden/hdf5/README.md)."""
+import os
+
+import numpy as np
+import pytest
+
+from drt_amd import captured_data as cd, hdf5_lite as h5
+
+D = os.path.join(os.path.dirname(__file__), "golden", "hdf5")
+
+
+@pytest.mark.parametrize("name,dtype", [("smpl_f64le", "<f8"), ("smpl_i32be", ">i4")])
+def test_contiguous_arrays_of_both_byte_orders(name, dtype):
+    with h5.File(os.path.join(D, name + ".h5")) as f:
+        assert f.keys() == ["TestArray"] and "TestArray" in f and "nope" not in f
+        d = f["TestArray"]
+        assert d.shape == (6, 5) and d.dtype == np.dtype(dtype) and len(d) == 6
+        expect = np.add.outer(np.arange(6), np.arange(5)).astype(dtype)
+        assert np.array_equal(d[...], expect) and np.array_equal(d[:], expect) and np.array_equal(np.asarray(d), expect)
+        assert np.array_equal(d[3], expect[3]) and np.array_equal(d[-1], expect[-1]) and np.array_equal(d[1:3, ::2], expect[1:3, ::2])
+        with pytest.raises(IndexError):
+            d[6]
+        with pytest.raises(KeyError):
+            f["missing"]
+
+
+def test_float_types_in_one_file():
+    f = h5.File(os.path.join(D, "float.h5"))
+    vals = np.add.outer(np.arange(5), np.arange(6))
+    for k in ("float16", "float32", "float64"):
+        assert f[k].shape == (5, 6) and f[k].dtype == np.dtype(k) and np.array_equal(f[k][...], vals.astype(k))
+    with pytest.raises(h5.Hdf5Unsupported):
+        f["longdouble"]                                   # 16-byte floats are refused, not misread
+
+
+def test_chunked_extendible_array_with_unwritten_chunks():
+    d = h5.File(os.path.join(D, "smpl_SDSextendible.h5"))["ExtendibleArray"]
+    expect = np.zeros((10, 5), dtype=">i4")
+    expect[:3, :3] = 1; expect[3:, 0] = 2; expect[:2, 3:] = 3
+    assert d.shape == (10, 5) and d.dtype == np.dtype(">i4") and np.array_equal(d[...], expect)
+    assert np.array_equal(d[4], expect[4])
+
+
+def test_deflate_compressed_chunks_and_nested_groups():
+    f = h5.File(os.path.join(D, "attr-u16.h5"))
+    d = f["wfm_group0/vectors/vector0/data"]
+    assert d.shape == (256, 8) and d.dtype == np.uint8 and d._filters and d._filters[0][0] == 1
+    bits = ((np.arange(256)[:, None] >> np.arange(7, -1, -1)[None, :]) & 1).astype(np.uint8)
+    assert np.array_equal(d[...], bits)
+    assert np.array_equal(f["wfm_group0"]["vectors"]["vector0"]["data"][200], bits[200])
+    assert "wfm_group0" in f and set(f["wfm_group0"].keys()) >= {"axes", "traces", "vectors"}
+
+
+def test_unsupported_content_is_refused_loudly():
+    with pytest.raises(h5.Hdf5Unsupported, match="compound"):
+        h5.File(os.path.join(D, "itemsize.h5"))["Test"]    # written by h5py: the file structure parses, the type is refused
+    f = h5.File(os.path.join(D, "slink.h5"))
+    refused = 0
+    for k in f.keys():
+        try:
+            f[k]
+        except h5.Hdf5Unsupported:
+            refused += 1
+    assert refused >= 1                                       # the soft links
+    with pytest.raises(ValueError):
+        h5.File(__file__)
+
+
+def test_capture_loader_falls_back_to_hdf5_lite(monkeypatch):
+    import builtins
+    real_import = builtins.__import__
+
+    def no_h5py(name, *a, **k):
+        if name == "h5py":
+            raise ImportError("no h5py here")
+        return real_import(name, *a, **k)
+
+    monkeypatch.setattr(builtins, "__import__", no_h5py)
+    cap = cd._open_capture(os.path.join(D, "smpl_f64le.h5"))
+    assert isinstance(cap, h5.File) and np.asarray(cap["TestArray"][2]).tolist() == [2, 3, 4, 5, 6]
