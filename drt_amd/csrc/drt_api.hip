@@ -37,7 +37,7 @@ int drt_create(int device, drt_scene_t** out) {
         e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * 8);
-        if (e == hipSuccess) e = hipMalloc(&w.slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
+        if (e == hipSuccess) e = hipMalloc(&w.slow_stack, sizeof(int32_t) * (size_t)kRedoGrid * kTraceBlock * kStackSlowDev);
     }
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
@@ -106,6 +106,11 @@ int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int6
     for (int k = 0; k < kProfStages; ++k) { ms_out[k] = 0.0; launches_out[k] = 0; items_out[k] = 0; }
     if (s->prof_ev.empty()) return DRT_OK;
     HIP_TRY(hipStreamSynchronize(s->prof_stream));
+    if (s->prof_dropped) {       // the stage times would under-report: say so instead of returning them
+        const size_t lost = s->prof_dropped;
+        s->prof_dropped = 0; s->prof_used = 0;
+        return fail(DRT_E_INVALID, "%zu stage timings were not recorded (event pool exhausted): read the profile more often", lost);
+    }
     for (size_t k = 0; k + 1 < s->prof_used; k += 2) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, s->prof_ev[k], s->prof_ev[k + 1]));

@@ -5,6 +5,8 @@ void scene_free_mesh(drt_scene* s) {
     (void)hipFree(s->faces); (void)hipFree(s->verts); (void)hipFree(s->nodes); (void)hipFree(s->tris);
     (void)hipFree(s->keys[0]); (void)hipFree(s->keys[1]); (void)hipFree(s->idx[0]); (void)hipFree(s->idx[1]);
     (void)hipFree(s->hist); (void)hipFree(s->parent_inner); (void)hipFree(s->parent_leaf); (void)hipFree(s->flags);
+    (void)hipFree(s->wide); (void)hipFree(s->range_lo); (void)hipFree(s->range_hi);
+    s->wide = nullptr; s->range_lo = s->range_hi = nullptr;
     s->faces = nullptr; s->verts = nullptr; s->nodes = nullptr; s->tris = nullptr;
     s->keys[0] = s->keys[1] = s->idx[0] = s->idx[1] = nullptr;
     s->hist = nullptr; s->parent_inner = s->parent_leaf = nullptr; s->flags = nullptr;
@@ -343,7 +345,7 @@ __global__ void k_wide_walk(const Node4Q* __restrict__ wide, const TriRec* __res
             }
         }
     }
-    if (3 * deepest > (unsigned long long)(kStackFast + kStackSlowDev)) ++bad;   // would overflow the spilling traversal stack
+    if (3 * deepest > (unsigned long long)kStackTotal) ++bad;   // would overflow the spilling traversal stack
     out[0] += bad;
     out[2] = deepest;
 }

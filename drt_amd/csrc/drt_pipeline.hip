@@ -80,16 +80,6 @@ __device__ __forceinline__ void stage_push(StageMem& m, bool pred, int32_t i, f3
 }
 
 
-__device__ __forceinline__ Stack make_stack256(int32_t (*lds)[kPathBlock], const TraceCtx& c) {
-    Stack st;
-    st.fast = &lds[0][threadIdx.x];
-    st.stride = kPathBlock;
-    st.depth_fast = kStackFast;
-    st.slow = c.slow_stack + ((int64_t)blockIdx.x * kPathBlock + threadIdx.x) * kStackSlowDev;
-    st.sp = 0;
-    return st;
-}
-
 __device__ __forceinline__ void write_dead(int64_t i, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face2) {
     const d3 z{0.0, 0.0, 0.0};
     store_d3(out_ori, i, z);
@@ -709,17 +699,17 @@ static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const 
       k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
     { StageTimer t(s, st, kStageTrace1);
       k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
-      k_trace_redo<false><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, p.r0.face); }
+      k_trace_redo<false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, p.r0.face); }
     { StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace2);
       k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
-      k_trace_redo<false><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, p.r1.face); }
+      k_trace_redo<false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, p.r1.face); }
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);
       k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
-      k_trace_redo<true><<<64, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, p.r2.face); }
+      k_trace_redo<true><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, p.r2.face); }
 }
 }  // extern "C++"
 

@@ -45,7 +45,13 @@ constexpr int kTraceBlock = 128;       // threads per block in traversal kernels
 #define DRT_STACK_FAST 19
 #endif
 constexpr int kStackFast = DRT_STACK_FAST;         // LDS stack entries per lane (19.5 KB per 256-thread block -> 8 blocks = 32 waves per CU)
-constexpr int kStackSlowDev = 45;      // global overflow entries per thread (LBVH height <= 30 + log2 F <= 64)
+// A traversal postpones at most three children per level of the wide tree; a wide node is rooted at a binary node and its
+// children are strict binary descendants, so wide depth <= binary height, and a Karras tree over (30-bit key, 32-bit index)
+// composites gains at least one prefix bit per level: height <= 64.  3 x 64 entries therefore ALWAYS suffice (drt_traverse.h
+// Stack has no bound check); the part beyond the LDS entries lives in a per-thread global area that is only touched on overflow.
+constexpr int kStackTotal = 192;
+constexpr int kStackSlowDev = kStackTotal - kStackFast;   // global overflow entries per thread
+constexpr int kRedoGrid = 64;          // blocks of k_trace_redo (rays that overflowed the LDS-only stack of k_trace)
 constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
 constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds the list workspace (96 B per ray of the largest pass)
 
@@ -91,7 +97,7 @@ struct drt_scene {
         int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;  // fused path keeps face ids here; backward fallback list
         unsigned* qcount = nullptr;                          // [8] list sizes + redo counts of the sub-batch in flight
         int32_t* redo = nullptr;                             // [cap] rays for k_trace_redo
-        int32_t* slow_stack = nullptr;                       // traversal-stack overflow area of this stream's kernels
+        int32_t* slow_stack = nullptr;                       // [kRedoGrid * kTraceBlock * kStackSlowDev] overflow area of this stream's k_trace_redo
         int64_t q_cap = 0, fused_cap = 0;
     };
     static constexpr int kMaxSub = 4;
@@ -110,6 +116,7 @@ struct drt_scene {
     std::vector<hipEvent_t> prof_ev;          // pool, used pairwise
     std::vector<int> prof_stage;              // stage id of pair k
     size_t prof_used = 0;                     // events handed out since the last read
+    size_t prof_dropped = 0;                  // stage timings lost since the last read (event pool could not grow): drt_profile_read fails
     unsigned long long* prof_counts = nullptr;  // device [kProfStages]: queue sizes accumulated per stage
     hipStream_t prof_stream = nullptr;
     int n_cu = 256;
@@ -160,11 +167,28 @@ inline PathCtx path_ctx(const drt_scene* s, const double* d_verts, double ior_in
 struct StageTimer {
     drt_scene* s; hipStream_t st; bool on;
     StageTimer(drt_scene* s_, hipStream_t st_, int stage) : s(s_), st(st_), on(false) {
-        if (!s->prof_on || s->prof_used + 2 > s->prof_ev.size()) return;
+        if (!s->prof_on) return;
+        if (s->prof_used + 2 > s->prof_ev.size() && !grow()) { ++s->prof_dropped; return; }
         on = true;
         s->prof_stage[s->prof_used / 2] = stage;
         if (!s->prof_stream) s->prof_stream = st;
         (void)hipEventRecord(s->prof_ev[s->prof_used], st);
+    }
+    // the pool grows with the number of launches between two reads (a long --steps run): never silently stops recording
+    bool grow() {
+        constexpr size_t kMaxEvents = (size_t)1 << 22;
+        const size_t want = s->prof_ev.size() ? 2 * s->prof_ev.size() : 8192;
+        if (want > kMaxEvents) return false;
+        const size_t old = s->prof_ev.size();
+        s->prof_ev.resize(want, nullptr);
+        s->prof_stage.resize(want / 2, 0);
+        for (size_t k = old; k < want; ++k)
+            if (hipEventCreate(&s->prof_ev[k]) != hipSuccess) {
+                for (size_t j = old; j < k; ++j) (void)hipEventDestroy(s->prof_ev[j]);
+                s->prof_ev.resize(old); s->prof_stage.resize(old / 2);
+                return false;
+            }
+        return true;
     }
     ~StageTimer() {
         if (!on) return;

@@ -25,8 +25,9 @@ struct Hit {
 };
 
 // Traversal stack: `depth_fast` entries in fast memory with a per-lane stride (LDS on
-// the GPU), the rest in a per-thread overflow area.  LBVH height is bounded by
-// 30 Morton bits + 32 index bits, so 96 entries always suffice.
+// the GPU), the rest in a per-thread overflow area.  At most three children are postponed per level
+// of the wide tree and its depth is bounded by the binary height <= 64 (30 Morton bits + 32 index bits,
+// one prefix bit per level), so depth_fast + overflow area = 192 entries always suffice (drt_scene.h).
 struct Stack {
     int32_t* fast;      // &fast_mem[lane], entry k at fast[k * stride]
     int stride;
@@ -49,7 +50,7 @@ struct Stack {
     }
     DRT_HD bool empty() const { return sp == 0; }
 };
-constexpr int kStackSlow = 72;
+constexpr int kStackSlow = 192;
 
 // Stack of the persistent GPU traversal: fast memory only, no overflow area and therefore no
 // divergent slow path (and no flat loads) in the hot loop.  A push beyond `depth` sets `overflow`;

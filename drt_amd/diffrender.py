@@ -61,6 +61,17 @@ def _tile_hint(n_rays):
     return 0
 
 
+def _flag_bytes(t, name, n):
+    """bool / uint8 [n] flags as a contiguous uint8 view (the kernels read them with 4-byte packed loads)."""
+    if t.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError(f"{name} must be bool or uint8, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor")
+    if t.numel() != n:
+        raise RuntimeError(f"{name} must have {n} elements, got {t.numel()}")
+    return t.contiguous().view(torch.uint8)
+
+
 def _f64c(t, name):
     if t.dtype != torch.float64:
         raise RuntimeError(f"{name} must be float64, got {t.dtype}")
@@ -126,9 +137,9 @@ class _RayLoss(torch.autograd.Function):
         oo = _f64c(out_ori.detach(), "out_ori")
         od = _f64c(out_dir.detach(), "out_dir")
         sp = _f64c(screen_pixel, "screen_pixel")
-        m = mask.contiguous().view(torch.uint8)
-        va = valid.contiguous().view(torch.uint8)
         n = oo.shape[0]
+        m = _flag_bytes(mask, "mask", 3 * n)
+        va = _flag_bytes(valid, "valid", n)
         loss = torch.zeros((), dtype=torch.float64, device=oo.device)
         need = ctx.needs_input_grad[1]
         g = torch.empty_like(od) if need else None
@@ -138,6 +149,7 @@ class _RayLoss(torch.autograd.Function):
             _lib.check(_lib.lib().drt_ray_loss(oo.data_ptr(), od.data_ptr(), m.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
                                                loss.data_ptr(), _lib.ptr(g), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
         ctx.save_for_backward(g, rows, n_rows)
+        ctx.applied = None                       # scale already multiplied into the saved rows (see backward)
         return loss
 
     @staticmethod
@@ -150,6 +162,15 @@ class _RayLoss(torch.autograd.Function):
         # scale only the contributing rows (a few % of the rays) instead of streaming the dense tensor again;
         # out_ori is detached in the reference's loss (optim.py:100): no gradient for it
         sc = g_loss.detach().to(torch.float64).reshape(1).contiguous()
+        new = sc.clone()
+        if ctx.applied is not None:
+            # a second backward over the same graph (retain_graph=True): the saved rows already carry the previous
+            # incoming gradient, so rescale by the ratio.  Rare path: one host sync to refuse an unrecoverable 0.
+            if float(ctx.applied.item()) == 0.0:
+                raise RuntimeError("ray_loss: backward was already run with a zero incoming gradient; the saved rows "
+                                   "cannot be rescaled -- recompute the loss instead of re-using the graph")
+            sc = sc / ctx.applied
+        ctx.applied = new
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().drt_scale_rows3(g.data_ptr(), rows.data_ptr(), n_rows.data_ptr(), sc.data_ptr(), _stream()))
         return None, g, None, None, None
@@ -164,7 +185,7 @@ class _RenderRayLossFused(torch.autograd.Function):
         o = _f64c(origin, "origin")
         d = _f64c(ray_dir, "ray_dir")
         sp = _f64c(screen_pixel, "screen_pixel")
-        va = valid.contiguous().view(torch.uint8)
+        va = _flag_bytes(valid, "valid", o.shape[0])
         loss = torch.zeros((), dtype=torch.float64, device=o.device)
         grad_v = torch.zeros_like(v)
         with torch.cuda.device(o.device):

@@ -180,8 +180,11 @@ class Dataset:
                 raw = np.frombuffer(raw[:n * es], dtype=np.uint8).reshape(es, n).T.tobytes() + raw[n * es:]
         return raw
 
-    def _read_chunked(self):
-        out = np.zeros(self.shape, dtype=self.dtype)
+    def _read_chunked(self, lo=0, hi=None):
+        """Rows [lo, hi) along axis 0 (default: everything).  Only the chunks that overlap the slab are decompressed,
+        so indexing a [72, P, 3] dataset view by view costs one view's chunks per index, not the whole dataset."""
+        hi = (self.shape[0] if self.shape else 1) if hi is None else hi
+        out = np.zeros((hi - lo,) + tuple(self.shape[1:]), dtype=self.dtype) if self.shape else np.zeros((), dtype=self.dtype)
         if self._btree == UNDEF or out.size == 0:
             return out
         r = self._f._r
@@ -203,10 +206,16 @@ class Dataset:
                 if level > 0:
                     walk(child)
                     continue
+                if rank and (offs[0] >= hi or offs[0] + self._chunk[0] <= lo):
+                    continue                                  # chunk outside the requested rows: not even decompressed
                 raw = self._unfilter(bytes(r.b[base + child:base + child + size]), mask)
                 chunk = np.frombuffer(raw, dtype=self.dtype, count=int(np.prod(self._chunk))).reshape(self._chunk)
-                sel_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, self._chunk, self.shape))
-                sel_in = tuple(slice(0, s.stop - s.start) for s in sel_out)
+                if not rank:
+                    out[()] = chunk.reshape(())
+                    continue
+                a0, b0 = max(offs[0], lo), min(offs[0] + self._chunk[0], hi, self.shape[0])
+                sel_out = (slice(a0 - lo, b0 - lo),) + tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs[1:], self._chunk[1:], self.shape[1:]))
+                sel_in = (slice(a0 - offs[0], b0 - offs[0]),) + tuple(slice(0, s.stop - s.start) for s in sel_out[1:])
                 out[sel_out] = chunk[sel_in]
 
         walk(self._btree)
@@ -232,6 +241,16 @@ class Dataset:
             n = int(np.prod(inner)) if inner else 1
             a = self._f._base + self._addr + i * n * self.dtype.itemsize
             return np.frombuffer(self._f._r.b, dtype=self.dtype, count=n, offset=a).reshape(inner).copy()
+        if self._kind == "chunked" and len(self.shape) >= 1:
+            # integer or contiguous slice along axis 0: decode only the overlapping chunks
+            if isinstance(key, (int, np.integer)):
+                i = int(key) + (self.shape[0] if key < 0 else 0)
+                if not 0 <= i < self.shape[0]:
+                    raise IndexError(key)
+                return self._read_chunked(i, i + 1)[0]
+            if isinstance(key, slice) and key.step in (None, 1):
+                lo, hi, _ = key.indices(self.shape[0])
+                return self._read_chunked(lo, max(lo, hi))
         return self.read()[key]
 
     def __len__(self):

@@ -167,7 +167,16 @@ def optimize(scene, data, HyperParams, remesh="isotropic", output=True, fused=Fa
 
 def full_batch_step(scene, local_views, init_vertices, parameter, opt, ray_w, fused=False):
     """One step over ALL views of this rank (BASELINE.json's '72 views forward+backward per iter'):
-    rebuild, per-view ray loss, backward, ONE all-reduce of grad[V,3], limit_hook, SGD step."""
+    rebuild, per-view ray loss, backward, ONE all-reduce of grad[V,3], limit_hook, SGD step.
+
+    ``parameter`` must NOT carry the gradient hook (``setup_opt(..., hook=False)``): the reference clamps the
+    gradient of the whole step (optim.py:155-162), i.e. AFTER the sum over views, so here the clamp follows the
+    all-reduce; a hook would clamp every rank's partial sum first.  A rank without views still takes part in the
+    all-reduce (with zeros) and applies the same update, so parameters stay identical on every rank."""
+    hooks = getattr(parameter, "_backward_hooks", None)
+    if hooks:
+        raise RuntimeError("full_batch_step: `parameter` has a gradient hook; build it with setup_opt(..., hook=False) "
+                           "(limit_hook is applied here, after the all-reduce)")
     opt.zero_grad(set_to_none=True)
     vertices = init_vertices + parameter
     scene.update_verticex(vertices)
@@ -178,8 +187,9 @@ def full_batch_step(scene, local_views, init_vertices, parameter, opt, ray_w, fu
         else:
             out_ori, out_dir, mask = scene.render_transparent(origin, ray_dir)
             loss = loss + Render.ray_loss(out_ori, out_dir, mask, target, valid)
-    (ray_w * loss).backward()
-    g = parameter.grad
+    if loss.requires_grad:
+        (ray_w * loss).backward()
+    g = parameter.grad if parameter.grad is not None else torch.zeros_like(parameter)   # a rank with no views
     ddist.allreduce_sum_(g)                 # the only exchange of the step
     parameter.grad = limit_hook(g)          # clamp after the sum over views, as on one GPU
     opt.step()

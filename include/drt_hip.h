@@ -209,7 +209,9 @@ void drt_mesh_buf_free(drt_mesh_buf_t* b);
  * items (rays in the stage's input queue) since the previous read.  Arrays have DRT_PROFILE_STAGES
  * entries: 0 build, 1 cull, 2 trace1, 3 shade1, 4 trace2, 5 shade2, 6 trace3 (occlusion),
  * 7 finish, 8 collect (backward compaction when no list was saved), 9 backward,
- * 10 fused loss+backward. */
+ * 10 fused loss+backward.  The event pool grows with the number of launches between two reads; if it could not
+ * (allocation failure), drt_profile_read FAILS (DRT_E_INVALID, message with the number of lost timings) instead
+ * of returning under-reported stage times. */
 #define DRT_PROFILE_STAGES 11
 int drt_profile_enable(drt_scene_t* s, int on);
 int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out);

@@ -40,6 +40,20 @@ def test_chunked_extendible_array_with_unwritten_chunks():
     expect[:3, :3] = 1; expect[3:, 0] = 2; expect[:2, 3:] = 3
     assert d.shape == (10, 5) and d.dtype == np.dtype(">i4") and np.array_equal(d[...], expect)
     assert np.array_equal(d[4], expect[4])
+    # row / slab indexing decodes only the overlapping chunks (one view of a capture at a time) -- same values
+    for i in range(-10, 10):
+        assert np.array_equal(d[i], expect[i])
+    for sl in (slice(0, 3), slice(2, 9), slice(7, None), slice(5, 5), slice(-4, -1)):
+        assert np.array_equal(d[sl], expect[sl])
+    calls = []
+    orig = d._unfilter
+    d._unfilter = lambda raw, mask: (calls.append(1), orig(raw, mask))[1]
+    d[0]
+    one_row = len(calls)
+    d[...]
+    assert 0 < one_row < len(calls) - one_row          # a row touches fewer chunks than the whole dataset
+    with pytest.raises(IndexError):
+        d[10]
 
 
 def test_deflate_compressed_chunks_and_nested_groups():
@@ -49,6 +63,7 @@ def test_deflate_compressed_chunks_and_nested_groups():
     bits = ((np.arange(256)[:, None] >> np.arange(7, -1, -1)[None, :]) & 1).astype(np.uint8)
     assert np.array_equal(d[...], bits)
     assert np.array_equal(f["wfm_group0"]["vectors"]["vector0"]["data"][200], bits[200])
+    assert all(np.array_equal(d[i], bits[i]) for i in range(0, 256, 17)) and np.array_equal(d[100:140], bits[100:140])
     assert "wfm_group0" in f and set(f["wfm_group0"].keys()) >= {"axes", "traces", "vectors"}
 
 
