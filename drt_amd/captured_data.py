@@ -185,3 +185,58 @@ class SyntheticData(Data):
         vs = views.make_views(render_gt, hit_gt, center, extent, n_total, resx, resy, device=device, view_ids=ids)
         self.Views = dict(zip(ids, vs))
         self._resident = dict(self.Views)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# writing a capture file (the reference only reads them; its captures are not distributed).  The arrays follow the
+# schema its loaders index (captured_data.py:94-108 PointGrey, 136-149 Redmi): per-view world->camera matrices
+# ``cam_proj`` [n,4,4], intrinsics ``cam_k`` [3,3], background-pattern positions ``screen_position`` ([n,P,3] for the
+# PointGrey camera, [n,resy,resx,3] for the phone -- the Redmi loader reshapes), object masks ``mask`` [n,resy,resx]
+# uint8 in {0,255}, and for the PointGrey camera the calibrated per-pixel rays ``ray_origin`` / ``ray_dir`` [n,P,3].
+# ---------------------------------------------------------------------------------------------------------------
+CAMERAS = {"pointgray": Data_Pointgray, "redmi": Data_Redmi}
+
+
+def synthetic_capture_arrays(scene_gt, center, extent, camera="pointgray", n_views=N_CAPTURE_VIEWS, view_ids=None, device="cuda"):
+    """Trace a ground-truth scene (``drt_amd.diffrender.Scene``) from a turntable of ``n_views`` cameras of the given
+    kind and return the capture's datasets as numpy arrays (``view_ids``: store only these views, in this order)."""
+    cls = CAMERAS[camera]
+    resy, resx = cls.resy, cls.resx
+    cams = views.turntable_cameras(center, extent, n_views, resx, resy)
+    ids = list(range(n_views)) if view_ids is None else list(view_ids)
+    out = {"cam_proj": [], "screen_position": [], "mask": []}
+    if cls.rays_from_file:
+        out["ray_origin"], out["ray_dir"] = [], []
+    for k in ids:
+        R, K, Rinv, Kinv = cams[k]
+        origin, ray_dir = views.generate_ray(resy, resx, Kinv, Rinv, device=device)
+        with torch.no_grad():
+            out_ori, out_dir, m = scene_gt.render_transparent(origin, ray_dir)
+            hit = scene_gt.render_mask(origin, ray_dir) > 0
+        sp = views.screen_targets(out_ori, out_dir, m, cams[k], center, extent).cpu().numpy()
+        out["cam_proj"].append(np.asarray(R, dtype=np.float64))
+        out["screen_position"].append(sp if cls.rays_from_file else sp.reshape(resy, resx, 3))
+        out["mask"].append(hit.view(resy, resx).cpu().numpy().astype(np.uint8) * 255)
+        if cls.rays_from_file:
+            out["ray_origin"].append(origin.cpu().numpy())
+            out["ray_dir"].append(ray_dir.cpu().numpy())
+    arrays = {k: np.stack(v) for k, v in out.items()}
+    arrays["cam_k"] = np.asarray(cams[0][1], dtype=np.float64)
+    return arrays
+
+
+def write_capture(path, arrays):
+    """``<name>.h5`` (h5py where importable, else drt_amd.hdf5_lite.write_simple: same datasets, plain contiguous layout)
+    or ``<name>.npz``."""
+    if path.endswith(".npz"):
+        np.savez(path, **arrays)
+        return path
+    try:
+        import h5py
+    except ImportError:
+        from . import hdf5_lite
+        return hdf5_lite.write_simple(path, arrays)
+    with h5py.File(path, "w") as f:
+        for k, v in arrays.items():
+            f.create_dataset(k, data=v)
+    return path

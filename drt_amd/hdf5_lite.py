@@ -465,3 +465,99 @@ class File(Group):
                     raise Hdf5Unsupported(f"{name}: group with dense link storage (fractal heap)")
             return Group(self, name, dict(self._link_message(m) for m in links))
         return Dataset(self, name, msgs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# writer: the plainest file the format allows (what h5py's default ``create_dataset`` of a numeric array produces in
+# its ``libver='earliest'`` form): superblock 0, one old-style root group (symbol table = v1 B-tree + local heap + one
+# symbol node), version-1 object headers, contiguous little-endian datasets.  Used by tools/make_capture.py to write
+# capture files with the reference's schema (captured_data.py:94-108) where h5py is not installed.
+# ---------------------------------------------------------------------------------------------------------------
+def _dtype_message(dt):
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize in (4, 8):
+        exp_loc, exp_size, man_size, bias = (23, 8, 23, 127) if dt.itemsize == 4 else (52, 11, 52, 1023)
+        head = bytes([0x11, 0x20, 8 * dt.itemsize - 1, 0]) + dt.itemsize.to_bytes(4, "little")
+        return head + (0).to_bytes(2, "little") + (8 * dt.itemsize).to_bytes(2, "little") + bytes([exp_loc, exp_size, 0, man_size]) + bias.to_bytes(4, "little")
+    if dt.kind in "iub" and dt.itemsize in (1, 2, 4, 8):
+        signed = 0x08 if dt.kind == "i" else 0
+        head = bytes([0x10, signed, 0, 0]) + dt.itemsize.to_bytes(4, "little")
+        return head + (0).to_bytes(2, "little") + (8 * dt.itemsize).to_bytes(2, "little")
+    raise Hdf5Unsupported(f"cannot write dtype {dt}")
+
+
+def _v1_message(mtype, body):
+    body = body + bytes(_pad8(len(body)) - len(body))
+    return mtype.to_bytes(2, "little") + len(body).to_bytes(2, "little") + bytes(4) + body
+
+
+def _v1_header(messages):
+    body = b"".join(messages)
+    return bytes([1, 0]) + len(messages).to_bytes(2, "little") + (1).to_bytes(4, "little") + len(body).to_bytes(4, "little") + bytes(4) + body
+
+
+def write_simple(path, arrays):
+    """Write ``{name: array}`` as contiguous datasets at the root of a new HDF5 file (at most 8 datasets: one symbol node)."""
+    names = sorted(arrays)                                # symbol-node entries are ordered by name
+    if not 1 <= len(names) <= 8:
+        raise ValueError("write_simple takes 1..8 datasets")
+    u8 = lambda v: int(v).to_bytes(8, "little")
+    arrs = {k: np.ascontiguousarray(arrays[k]) for k in names}
+    for k in names:
+        if arrs[k].dtype == np.bool_:
+            arrs[k] = arrs[k].astype(np.uint8)
+        arrs[k] = arrs[k].astype(arrs[k].dtype.newbyteorder("<"), copy=False)
+    # local heap data: "" at offset 0, then the names, each NUL-terminated and 8-byte aligned
+    heap_data, name_off = bytearray(8), {}
+    for k in names:
+        name_off[k] = len(heap_data)
+        raw = k.encode("utf-8") + b"\0"
+        heap_data += raw + bytes(_pad8(len(raw)) - len(raw))
+    # layout of the file
+    pos = 96                                              # superblock (56 bytes) + root symbol-table entry (40)
+    root_hdr = pos
+    root_hdr_len = 16 + 8 + 16                            # prefix + one symbol-table message
+    pos = _pad8(pos + root_hdr_len)
+    btree = pos; pos += 24 + 33 * 8 + 32 * 8              # full-size node for internal K = 16
+    snod = pos; pos += 8 + 8 * 40                         # 2 x leaf K = 8 entries
+    heap = pos; pos += 32
+    heap_seg = pos; pos = _pad8(pos + len(heap_data))
+    hdr_at, data_at = {}, {}
+    hdrs = {}
+    for k in names:
+        a = arrs[k]
+        space = bytes([1, a.ndim, 0, 0, 0, 0, 0, 0]) + b"".join(u8(s) for s in a.shape)
+        hdr_at[k] = pos
+        hdrs[k] = (space, _dtype_message(a.dtype))
+        pos = _pad8(pos + 16 + (8 + _pad8(len(space))) + (8 + _pad8(len(hdrs[k][1]))) + (8 + 24))
+    for k in names:
+        data_at[k] = pos
+        pos = _pad8(pos + arrs[k].nbytes)
+    eof = pos
+    with open(path, "wb") as f:
+        sb = b"\x89HDF\r\n\x1a\n" + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + (4).to_bytes(2, "little") + (16).to_bytes(2, "little") + bytes(4)
+        sb += u8(0) + u8(UNDEF) + u8(eof) + u8(UNDEF)
+        sb += u8(0) + u8(root_hdr) + (1).to_bytes(4, "little") + bytes(4) + u8(btree) + u8(heap)     # root symbol-table entry (cached)
+        assert len(sb) == 96
+        f.write(sb)
+        f.write(_v1_header([_v1_message(0x0011, u8(btree) + u8(heap))]))
+        f.seek(btree)
+        f.write(b"TREE" + bytes([0, 0]) + (1).to_bytes(2, "little") + u8(UNDEF) + u8(UNDEF) + u8(0) + u8(snod) + u8(name_off[names[-1]]))
+        f.seek(snod)
+        f.write(b"SNOD" + bytes([1, 0]) + len(names).to_bytes(2, "little"))
+        for k in names:
+            f.write(u8(name_off[k]) + u8(hdr_at[k]) + bytes(4) + bytes(4) + bytes(16))
+        f.seek(heap)
+        f.write(b"HEAP" + bytes(4) + u8(len(heap_data)) + u8(1) + u8(heap_seg))     # free-list head 1 = H5HL_FREE_NULL: no free block
+        f.seek(heap_seg)
+        f.write(bytes(heap_data))
+        for k in names:
+            space, dtm = hdrs[k]
+            layout = bytes([3, 1]) + u8(data_at[k]) + u8(arrs[k].nbytes)
+            f.seek(hdr_at[k])
+            f.write(_v1_header([_v1_message(0x0001, space), _v1_message(0x0003, dtm), _v1_message(0x0008, layout)]))
+        for k in names:
+            f.seek(data_at[k])
+            f.write(arrs[k].tobytes())
+        f.truncate(eof)
+    return path

@@ -301,6 +301,121 @@ def smooth_fixture(DR, optim, scene, mesh, center, extent):
                         param0=steps[0]["param"], param1=steps[1]["param"], loss_str0=steps[0]["loss_str"], loss_str1=steps[1]["loss_str"])
 
 
+def degenerate_fixture(DR, optim, mesh, center, extent):
+    """A closed mesh with the defect SURVEY section 4 notes in monkey_vh.ply / dog_vh.ply: a zero-length edge, i.e. two
+    zero-area faces (monkey_vh: faces with a duplicated vertex position).  Made from the smoothed hand hull by moving
+    one endpoint of edge 100 onto the other (topology untouched, still watertight).  Pins what the reference does
+    with it: a zero-area face is never hit (det = 0), its normal n / |n| is NaN (DiffRender.py:103-104, 149-163), so
+    its edges drop out of the silhouette test, their dihedral cosines and the smoothness loss are NaN, the NaN
+    reaches the vertex gradient and limit_hook (optim.py:155-162) zeroes it before the SGD step."""
+    import tempfile
+    Vs = _smooth(mesh)
+    a, b = (int(x) for x in np.sort(mesh.edges, axis=1)[100])
+    Vs[b] = Vs[a]
+    tri = Vs[mesh.faces]
+    area = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    assert (area == 0).sum() == 2
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "hand_degenerate.ply")
+        mesh_io.write_ply(path, Vs, mesh.faces)
+        scene = DR.Scene(path)
+    res, view_id = 64, 23
+    DR.resx = DR.resy = res
+    cams = views.turntable_cameras(center, extent, 72, res, res)
+    R, K, Rinv, Kinv = cams[view_id]
+    origin, ray_dir = views.generate_ray(res, res, Kinv, Rinv)
+    P = origin.shape[0]
+    V = torch.tensor(Vs, dtype=torch.float64, requires_grad=True)
+    scene.update_verticex(V)
+    rec = dict(vertices=Vs.astype(np.float32), collapsed=np.array([a, b]), zero_area_faces=np.flatnonzero(area == 0),
+               res=res, view_id=view_id, R=R, K=K, Rinv=Rinv, Kinv=Kinv, ior=IOR, mean_len=scene.mean_len)
+    # refraction path of one view (zero-area faces can never be hit)
+    out_ori, out_dir, mask = scene.render_transparent(origin, ray_dir)
+    sp, valid = _targets(P, center, seed=100 + view_id)
+    target = torch.tensor(sp) - out_ori.detach()
+    target = target / target.norm(dim=1, keepdim=True)
+    vm = torch.tensor(valid) * mask[:, 0]
+    ray_loss = (out_dir - target)[vm].pow(2).sum()
+    g_ray, = torch.autograd.grad(ray_loss, V)
+    vi = torch.nonzero(mask[:, 0]).squeeze(1)
+    it1, _ = scene.Dintersect(DR.Ray(origin, ray_dir))
+    rec.update(valid_ind=vi.numpy(), out_dir=out_dir.detach()[vi].numpy(), out_ori=out_ori.detach()[vi].numpy(), ray_loss=ray_loss.item(),
+               grad_ray_loss=g_ray.numpy(), target_seed=100 + view_id, b1_ind=it1.ray.ray_ind.numpy(), b1_face=it1.faces_ind.numpy())
+    # silhouette branch
+    scene.update_verticex(V)
+    camera_M = tuple(torch.tensor(m, dtype=torch.float64) for m in (R, K, Rinv, Kinv))
+    o3 = origin[0]
+    sil = scene.silhouette_edge(o3)
+    index, output = scene.primary_visibility(sil, camera_M, o3, detach_depth=True)
+    hitmask = np.zeros(P, dtype=np.uint8)
+    hitmask[it1.ray.ray_ind.numpy()] = 1
+    soft = torch.tensor(views.process_mask(hitmask.reshape(res, res)), dtype=torch.float64).reshape(-1)
+    vh = (soft.view((res, res))[index[:, 1], index[:, 0]] - output).abs().sum()
+    g_vh, = torch.autograd.grad(vh, V)
+    rec.update(sil_edges=sil.numpy(), vh_index=index.numpy(), vh_output=output.detach().numpy(), vh_loss=vh.item(), grad_vh=g_vh.numpy())
+    # smoothness branch: NaN where a zero-area face is involved
+    scene.update_verticex(V)
+    cosang = scene.dihedral_angle()
+    sm = (-torch.log(1 + cosang)).sum()
+    g_sm, = torch.autograd.grad(sm, V)
+    rec.update(dihedral_cos=cosang.detach().numpy(), sm_loss=sm.item(), grad_sm=g_sm.numpy(), Edges=scene.Edges.numpy())
+    assert np.isnan(rec["dihedral_cos"]).sum() >= 1 and np.isnan(rec["grad_sm"]).any() and np.isnan(sm.item())
+    # one whole iteration: all_loss -> backward -> limit_hook (NaN -> 0, clamp) -> SGD(nesterov)
+    sil_ids = list(range(0, 72, 9))
+
+    class FakeData:
+        resx = resy = res
+
+        def __init__(self):
+            self.cache = {}
+
+        def get_view(self, k):
+            if k not in self.cache:
+                Rk, Kk, Rinvk, Kinvk = cams[k]
+                o, d = views.generate_ray(res, res, Kinvk, Rinvk)
+                spk, validk = _targets(o.shape[0], center, seed=100 + k)
+                _, hit = orc.intersect_ids(orc.Mesh(mesh.faces, torch.tensor(Vs)), o, d)
+                softk = views.process_mask(hit.numpy().reshape(res, res))
+                cam = tuple(torch.tensor(m, dtype=torch.float64) for m in (Rk, Kk, Rinvk, Kinvk))
+                self.cache[k] = (torch.tensor(spk), torch.tensor(validk), torch.tensor(softk, dtype=torch.float64).reshape(-1), o, d, cam)
+            return self.cache[k]
+
+        def ray_view_generator(self):
+            while True:
+                yield view_id
+
+        def silh_view_generator(self):
+            while True:
+                for k in sil_ids:
+                    yield k
+
+    HP = dict(ray_w=40, sm_w=0.08, vh_w=2e-3, momentum=0.95)
+    lc = optim.Loss_calculator(scene, FakeData(), HP)
+    init_vertices = torch.tensor(Vs, dtype=torch.float64)
+    parameter = torch.zeros(init_vertices.shape, dtype=torch.float64, requires_grad=True)
+
+    def limit_hook(grad):        # the reference's closure (optim.py:155-162), same statements
+        grad[torch.isnan(grad)] = 0
+        grad[grad > 1] = 1
+        grad[grad < -1] = -1
+        return grad
+
+    parameter.register_hook(limit_hook)
+    opt = torch.optim.SGD([parameter], lr=0.1, momentum=HP["momentum"], nesterov=True)
+    opt.zero_grad()
+    scene.update_verticex(init_vertices + parameter)
+    loss, loss_str = lc.all_loss()
+    loss.backward()
+    grad0 = parameter.grad.clone().numpy()
+    opt.step()
+    assert np.isnan(loss.item()) and np.isfinite(grad0).all() and np.isfinite(parameter.detach().numpy()).all()
+    rec.update(step_loss_is_nan=True, step_loss_str=loss_str, step_grad=grad0, step_param=parameter.detach().numpy(), sil_views=np.array(sil_ids),
+               lr=0.1, momentum=0.95)
+    np.savez_compressed(os.path.join(OUT, "hand_degenerate.npz"), **rec)
+    print("degenerate: zero-area faces", rec["zero_area_faces"], "NaN cos", int(np.isnan(rec["dihedral_cos"]).sum()),
+          "NaN grad_sm rows", int(np.isnan(rec["grad_sm"]).any(axis=1).sum()), "sil", len(sil), "vh", vh.item(), "valid", len(vi), loss_str)
+
+
 def main():
     torch.manual_seed(0)
     np.random.seed(0)
@@ -309,6 +424,9 @@ def main():
     path = os.path.join(REPO, "data", "hand_vh.ply")
     mesh = mesh_io.read_ply(path)
     center, extent = views.mesh_frame(mesh.vertices)
+    only = set(sys.argv[1:])                 # e.g. `make_golden.py degenerate`: regenerate one family of fixtures
+    if only == {"degenerate"}:
+        return degenerate_fixture(DR, optim, mesh, center, extent)
     scene = DR.Scene(path)
     np.savez_compressed(os.path.join(OUT, "hand_topology.npz"), Edges=scene.Edges.numpy(), E2F=scene.E2F.numpy(),
                         mean_len=scene.mean_len, n_vertices=len(mesh.vertices), n_faces=len(mesh.faces))
@@ -317,6 +435,7 @@ def main():
         for view_id in (5, 23, 41):
             render_fixture(DR, optim, scene, mesh, center, extent, res, view_id, f"hand_r{res}_v{view_id}")
     smooth_fixture(DR, optim, scene, mesh, center, extent)
+    degenerate_fixture(DR, optim, mesh, center, extent)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,359 @@
+"""The HIP path on BASELINE.json's other workloads -- mouse_vh x4 (36 984 triangles, configs[2]) and monkey_vh
+(184 090 triangles with two zero-area faces, configs[4]) -- and on the degenerate-face golden mesh:
+BVH == exhaustive test with bit-exact T / ID at 1024x1024, a 96x96 view against the CPU oracle (mask, face ids exact,
+rays <= 1e-10, gradient <= 1e-5), the size-independent property set at full size, NaN behaviour of zero-area faces
+as the reference has it (DiffRender.py:103-104, optim.py:155-162), and two robustness checks of the library
+(no device-memory growth over topology changes; the stage-timer pool never stops recording silently)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import IOR, data_path, golden
+from drt_amd import mesh_io, views
+from oracle import diffrender_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+_meshes = {}
+
+
+def workload(name):
+    if name not in _meshes:
+        if name == "mouse37k":
+            _meshes[name] = mesh_io.subdivide_midpoint(mesh_io.read_ply(data_path("mouse_vh.ply")))
+        elif name == "monkey184k":
+            _meshes[name] = mesh_io.read_ply(data_path("monkey_vh.ply"))
+        else:
+            raise KeyError(name)
+    return _meshes[name]
+
+
+SIZES = {"mouse37k": 36984, "monkey184k": 184090}
+CONFIGS = list(SIZES)
+
+
+@pytest.fixture(scope="module")
+def Render():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from drt_amd import diffrender
+    diffrender.intIOR = IOR
+    return diffrender
+
+
+def _tracer(mesh):
+    from drt_amd.optix_mesh import optix_mesh
+    t = optix_mesh(0)
+    t.update_mesh(torch.tensor(mesh.faces, dtype=torch.int32, device="cuda"),
+                  torch.tensor(mesh.vertices, dtype=torch.float32, device="cuda"))
+    return t
+
+
+def _camera(mesh, res, view, n_views=72):
+    c, ext = views.mesh_frame(mesh.vertices)
+    return views.turntable_cameras(c, ext, n_views, res, res)[view]
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+def test_full_size_traversal_equals_gpu_bruteforce(name):
+    mesh = workload(name)
+    assert len(mesh.faces) == SIZES[name] and mesh.is_watertight
+    t = _tracer(mesh)
+    bad, height = t.check()
+    assert bad == 0 and 3 * t.wide_depth <= 192, (bad, height, t.wide_depth)
+    print(f"{name}: binary height {height}, wide depth {t.wide_depth}")
+    for view in (3, 40):
+        R, K, Rinv, Kinv = _camera(mesh, 1024, view)
+        o, d = views.generate_ray(1024, 1024, Kinv, Rinv, device="cuda")
+        rays = torch.cat([o.float(), d.float()], 1)
+        T, ID = t.intersect(rays)
+        hit = ID >= 0
+        assert 0.01 < hit.float().mean().item() < 0.6
+        sel = torch.nonzero(hit).squeeze(1)
+        miss = torch.nonzero(~hit).squeeze(1)[:: max(1, int((~hit).sum()) // max(1, len(sel)))]
+        idx = torch.cat([sel, miss])
+        Tb, IDb = t.intersect_bruteforce(rays[idx].contiguous())
+        assert torch.equal(ID[idx], IDb)
+        assert torch.equal(T[idx], Tb)
+        assert torch.equal(t.intersect_any(rays), hit)
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+def test_render_vs_oracle_sample(Render, name):
+    """A 96x96 view through the HIP path and through the oracle (O(rays x faces) on the host)."""
+    mesh = workload(name)
+    scene = Render.Scene(mesh, 0)
+    res = 96
+    Render.resx = Render.resy = res
+    R, K, Rinv, Kinv = _camera(mesh, res, 11)
+    o, d = views.generate_ray(res, res, Kinv, Rinv)
+    V = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    out_ori, out_dir, mask = scene.render_transparent(o.cuda(), d.cuda())
+    Vc = torch.tensor(mesh.vertices, dtype=torch.float64, requires_grad=True)
+    oo, od, mk, aux = orc.render_transparent(orc.Mesh(mesh.faces, Vc), o, d, IOR, return_aux=True)
+    assert torch.equal(mask.cpu(), mk)
+    assert torch.equal(scene.last_face1.cpu().long(), aux["face1"])
+    f2 = aux["face2"].clone(); f2[~mk[:, 0]] = -1
+    assert torch.equal(scene.last_face2.cpu().long(), f2)
+    assert mk[:, 0].sum() > 150
+    torch.testing.assert_close(out_dir.detach().cpu(), od.detach(), rtol=1e-10, atol=1e-11)
+    torch.testing.assert_close(out_ori.detach().cpu(), oo.detach(), rtol=1e-10, atol=1e-9)
+    rng = np.random.default_rng(5)
+    sp = torch.tensor(rng.standard_normal(o.shape) * 40.0 + np.asarray(views.mesh_frame(mesh.vertices)[0]))
+    valid = torch.tensor(rng.random(len(o)) > 0.1)
+    loss = Render.ray_loss(out_ori, out_dir, mask, sp.cuda(), valid.cuda())
+    ref = orc.ray_loss(oo, od, mk, sp, valid)
+    assert loss.item() == pytest.approx(ref.item(), rel=1e-10)
+    w = torch.tensor(rng.standard_normal(o.shape))
+    (loss + (out_dir * w.cuda()).sum() + (out_ori * w.cuda()).sum()).backward()
+    (ref + (od * w).sum() + (oo * w).sum()).backward()
+    err = (V.grad.cpu() - Vc.grad).abs().max().item()
+    assert err <= 1e-5 and err <= 1e-9 * max(1.0, Vc.grad.abs().max().item()), err
+    # the one-pass loss on the same view
+    V2 = V.detach().clone().requires_grad_(True)
+    scene.update_verticex(V2)
+    lf = scene.ray_loss_fused(o.cuda(), d.cuda(), sp.cuda(), valid.cuda())
+    assert lf.item() == pytest.approx(ref.item(), rel=1e-10)
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+def test_properties_at_full_size(Render, name):
+    """Size-independent properties on 1024x1024 rays (one view of the config's capture)."""
+    mesh = workload(name)
+    scene = Render.Scene(mesh, 0)
+    Render.resx = Render.resy = 1024
+    R, K, Rinv, Kinv = _camera(mesh, 1024, 20)
+    o, d = views.generate_ray(1024, 1024, Kinv, Rinv, device="cuda")
+    V = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    out_ori, out_dir, mask = scene.render_transparent(o, d)
+    m = mask[:, 0]
+    f1, f2 = scene.last_face1, scene.last_face2
+    assert 0.005 < m.float().mean().item() < 0.5
+    assert torch.all(f2[m] >= 0) and torch.all(f2[~m] == -1) and torch.all(f1[m] >= 0)
+    assert torch.all(out_ori[~m] == 0) and torch.all(out_dir[~m] == 0)
+    assert (out_dir.detach()[m].norm(dim=1) - 1).abs().max().item() < 1e-12
+    ids, hitted = scene.optix_intersect(Render.Ray(o, d))                # B1 query of the same rays
+    assert torch.equal(hitted, f1 >= 0) and torch.equal(ids[hitted].int(), f1[hitted])
+    _, again = scene.optix_intersect(Render.Ray(out_ori.detach()[m], out_dir.detach()[m]))
+    assert not again.any()                                               # exit rays leave the object
+    o2, d2, m2 = scene.render_transparent(o, d)
+    assert torch.equal(o2, out_ori) and torch.equal(d2, out_dir) and torch.equal(m2, mask)   # deterministic
+    Render.resx, Render.resy = 7, 7                                      # linear ray order instead of tiles: same result
+    o3, d3, m3 = scene.render_transparent(o, d)
+    assert torch.equal(o3, out_ori) and torch.equal(d3, out_dir) and torch.equal(m3, mask)
+    assert torch.equal(scene.last_face1, f1) and torch.equal(scene.last_face2, f2)
+    Render.resx = Render.resy = 1024
+    w = torch.randn(o.shape, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    g1, = torch.autograd.grad((out_dir * w).sum(), V, retain_graph=True)
+    g2, = torch.autograd.grad((out_dir * (2.5 * w)).sum(), V, retain_graph=True)
+    torch.testing.assert_close(g2, 2.5 * g1, rtol=1e-9, atol=1e-9 * g1.abs().max().item())
+    sp = out_ori.detach() + 100.0 * out_dir.detach() + 0.3
+    valid = m.clone()
+    loss = Render.ray_loss(out_ori, out_dir, mask, sp, valid)
+    ga, = torch.autograd.grad(loss, V, retain_graph=True)
+    gb, = torch.autograd.grad(loss, V)               # a second backward over the same graph gives the same gradient
+    assert torch.equal(ga, gb) or torch.allclose(ga, gb, rtol=1e-12, atol=1e-14 * ga.abs().max().item())
+    assert torch.isfinite(ga).all()
+    V2 = V.detach().clone().requires_grad_(True)
+    scene.update_verticex(V2)
+    lf = scene.ray_loss_fused(o, d, sp, valid)
+    lf.backward()
+    assert lf.item() == pytest.approx(loss.item(), rel=1e-10)
+    torch.testing.assert_close(V2.grad, ga, rtol=1e-8, atol=1e-10 * ga.abs().max().item())
+
+
+def test_monkey_zero_area_faces_behave_like_the_reference(Render):
+    """monkey_vh.ply as distributed has a zero-length edge (two zero-area faces).  Reference behaviour (restated by the
+    oracle, pinned on the small golden mesh below): those faces are never hit; the dihedral cosines of their edges are
+    NaN, so sm_loss and the gradient rows of their vertices are NaN; limit_hook turns them into zeros."""
+    from drt_amd import optim as O
+    mesh = workload("monkey184k")
+    tri = mesh.vertices[mesh.faces]
+    zero = np.flatnonzero(np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1) == 0)
+    assert len(zero) == 2
+    scene = Render.Scene(mesh, 0)
+    V = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    Vc = torch.tensor(mesh.vertices, dtype=torch.float64, requires_grad=True)
+    E2F = scene.E2F.cpu()
+    cos_gpu = scene.dihedral_angle()
+    cos_ref = orc.dihedral_cos(Vc, E2F)
+    nan_ref = torch.isnan(cos_ref)
+    assert 1 <= int(nan_ref.sum()) <= 6 and torch.equal(torch.isnan(cos_gpu).cpu(), nan_ref)
+    np.testing.assert_allclose(cos_gpu.detach().cpu().numpy(), cos_ref.detach().numpy(), rtol=1e-10, atol=1e-12, equal_nan=True)
+    sm = (-torch.log(1 + cos_gpu)).sum()
+    g_sm, = torch.autograd.grad(sm, V)
+    g_ref, = torch.autograd.grad(orc.sm_loss(Vc, E2F), Vc)
+    assert torch.equal(torch.isnan(g_sm).cpu(), torch.isnan(g_ref)) and torch.isnan(g_ref).any()
+    fin = ~torch.isnan(g_ref)
+    scale = g_ref[fin].abs().max().item()
+    assert (g_sm.cpu()[fin] - g_ref[fin]).abs().max().item() <= 1e-9 * scale
+    smf = scene.sm_loss_fused()
+    g_f, = torch.autograd.grad(smf, V)
+    assert np.isnan(smf.item()) and torch.equal(torch.isnan(g_f).cpu(), torch.isnan(g_ref))
+    hooked = O.limit_hook(g_sm.clone())
+    assert torch.isfinite(hooked).all() and hooked.abs().max().item() <= 1.0
+    assert torch.equal(hooked.cpu()[~fin], torch.zeros_like(g_ref[~fin]))
+    # silhouette set of one view == oracle (NaN normals never pass the sign test)
+    R, K, Rinv, Kinv = _camera(mesh, 256, 9)
+    origin3 = torch.tensor(Rinv[:3, 3], dtype=torch.float64)
+    sil = scene.silhouette_edge(origin3.cuda())
+    sil_ref = orc.silhouette_edges(Vc.detach(), scene.Edges.cpu(), E2F, origin3)
+    assert torch.equal(sil.cpu(), sil_ref) and len(sil_ref) > 1000
+    # primary rays never report a zero-area face
+    R, K, Rinv, Kinv = _camera(mesh, 512, 30)
+    o, d = views.generate_ray(512, 512, Kinv, Rinv, device="cuda")
+    ids, hitted = scene.optix_intersect(Render.Ray(o, d))
+    assert not np.isin(zero, ids[hitted].cpu().numpy()).any()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_degenerate_golden_mesh(Render, fused):
+    """hand_degenerate.npz (made by the reference's Python on a mesh with a zero-length edge): refraction path,
+    silhouette branch, NaN pattern of the smoothness branch, and one whole iteration ending in finite parameters."""
+    from drt_amd import optim as O
+    g = golden("hand_degenerate")
+    hand = mesh_io.read_ply(data_path("hand_vh.ply"))
+    res = int(g["res"])
+    Render.intIOR = float(g["ior"])
+    Render.resx = Render.resy = res
+    Vs = g["vertices"].astype(np.float64)
+    scene = Render.Scene(mesh_io.TriMesh(Vs, hand.faces), 0)
+    scene.mean_len = float(g["mean_len"])
+    center, extent = views.mesh_frame(hand.vertices)
+    cams = views.turntable_cameras(center, extent, 72, res, res)
+    o, d = views.generate_ray(res, res, g["Kinv"], g["Rinv"])
+    rng = np.random.default_rng(int(g["target_seed"]))
+    sp = torch.tensor(rng.standard_normal((res * res, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0]))
+    valid = torch.tensor(rng.random(res * res) > 0.1)
+    V = torch.tensor(Vs, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    out_ori, out_dir, mask = scene.render_transparent(o.cuda(), d.cuda())
+    vi = torch.nonzero(mask[:, 0]).squeeze(1).cpu().numpy()
+    assert np.array_equal(vi, g["valid_ind"])
+    f1 = np.full(res * res, -1, np.int64); f1[g["b1_ind"]] = g["b1_face"]
+    assert np.array_equal(scene.last_face1.cpu().numpy(), f1)
+    np.testing.assert_allclose(out_dir[vi].detach().cpu().numpy(), g["out_dir"], rtol=1e-10, atol=1e-11)
+    loss = Render.ray_loss(out_ori, out_dir, mask, sp.cuda(), valid.cuda())
+    assert loss.item() == pytest.approx(float(g["ray_loss"]), rel=1e-10)
+    g_ray, = torch.autograd.grad(loss, V)
+    ref = g["grad_ray_loss"]
+    assert np.abs(g_ray.cpu().numpy() - ref).max() <= 1e-5
+    np.testing.assert_allclose(g_ray.cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    origin3 = o[0].cuda()
+    sil = scene.silhouette_edge(origin3)
+    assert np.array_equal(sil.cpu().numpy(), g["sil_edges"])
+    cam = tuple(torch.tensor(g[k], dtype=torch.float64, device="cuda") for k in ("R", "K", "Rinv", "Kinv"))
+    index, output = scene.primary_visibility(sil, cam, origin3, detach_depth=True)
+    assert np.array_equal(index.cpu().numpy(), g["vh_index"])
+    hit = np.zeros(res * res, dtype=np.uint8); hit[g["b1_ind"]] = 1
+    soft = torch.tensor(views.process_mask(hit.reshape(res, res)), dtype=torch.float64, device="cuda").reshape(-1)
+    vh = (soft.view((res, res))[index[:, 1], index[:, 0]] - output).abs().sum()
+    assert vh.item() == pytest.approx(float(g["vh_loss"]), rel=1e-12)
+    g_vh, = torch.autograd.grad(vh, V)
+    np.testing.assert_allclose(g_vh.cpu().numpy(), g["grad_vh"], rtol=1e-8, atol=1e-10 * np.nanmax(np.abs(g["grad_vh"])), equal_nan=True)
+    cosang = scene.dihedral_angle()
+    np.testing.assert_allclose(cosang.detach().cpu().numpy(), g["dihedral_cos"], rtol=1e-10, atol=1e-12, equal_nan=True)
+    sm = (-torch.log(1 + cosang)).sum()
+    g_sm, = torch.autograd.grad(sm, V)
+    ref = g["grad_sm"]
+    assert np.isnan(sm.item()) and np.array_equal(np.isnan(g_sm.cpu().numpy()), np.isnan(ref))
+    np.testing.assert_allclose(g_sm.cpu().numpy(), ref, rtol=1e-8, atol=1e-10 * np.nanmax(np.abs(ref)), equal_nan=True)
+
+    # one whole iteration through drt_amd.optim (drop-in terms or the fused ones)
+    base = orc.Mesh(hand.faces, torch.tensor(Vs))
+
+    class Data:
+        resx = resy = res
+
+        def __init__(self):
+            self.v = {}
+            for k in [int(g["view_id"])] + [int(x) for x in g["sil_views"]]:
+                R, K, Rinv, Kinv = cams[k]
+                ok, dk = views.generate_ray(res, res, Kinv, Rinv)
+                r2 = np.random.default_rng(100 + k)
+                spk = r2.standard_normal((res * res, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0])
+                vk = r2.random(res * res) > 0.1
+                _, hitk = orc.intersect_ids(base, ok, dk)
+                softk = torch.tensor(views.process_mask(hitk.numpy().reshape(res, res)), dtype=torch.float64).reshape(-1)
+                camk = tuple(torch.tensor(a, dtype=torch.float64, device="cuda") for a in (R, K, Rinv, Kinv))
+                self.v[k] = (torch.tensor(spk).cuda(), torch.tensor(vk).cuda(), softk.cuda(), ok.cuda(), dk.cuda(), camk)
+
+        def get_view(self, k):
+            return self.v[k]
+
+        def ray_view_generator(self):
+            while True:
+                yield int(g["view_id"])
+
+        def silh_view_generator(self):
+            while True:
+                for k in g["sil_views"]:
+                    yield int(k)
+
+    hp = dict(O.HyperParams, IOR=float(g["ior"]), momentum=float(g["momentum"]))
+    lc = O.Loss_calculator(scene, Data(), hp, fused=fused)
+    init_vertices, parameter, opt = O.setup_opt(scene, float(g["lr"]), hp)
+    opt.zero_grad()
+    scene.update_verticex(init_vertices + parameter)
+    total, parts = lc.all_loss()
+    total.backward()
+    assert np.isnan(total.item()) and O.loss_string(parts) == str(g["step_loss_str"])
+    assert torch.isfinite(parameter.grad).all()
+    np.testing.assert_allclose(parameter.grad.cpu().numpy(), g["step_grad"], rtol=1e-7, atol=1e-10)
+    opt.step()
+    np.testing.assert_allclose(parameter.detach().cpu().numpy(), g["step_param"], rtol=1e-7, atol=1e-11)
+
+
+def test_topology_changes_do_not_leak_device_memory():
+    """40 update_mesh calls with growing F (every one reallocates the per-mesh buffers): free device memory must not drift."""
+    from drt_amd.optix_mesh import optix_mesh
+    t = optix_mesh(0)
+    base = mesh_io.icosphere(5, radius=50.0)            # 20 480 faces
+    F = torch.tensor(base.faces, dtype=torch.int32, device="cuda")
+    V = torch.tensor(base.vertices, dtype=torch.float32, device="cuda")
+    rays = torch.tensor([[0, 0, 200, 0, 0, -1.0]], dtype=torch.float32, device="cuda")
+
+    def grow(k):                                        # k extra copies of the face list: more faces, same geometry
+        return torch.cat([F] + [F[: 512 * (j + 1)] for j in range(k)]).contiguous()
+
+    for k in range(3):                                  # warm-up: allocator pools, code objects
+        t.update_mesh(grow(k), V)
+        t.intersect(rays)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    worst = 0
+    for k in range(3, 43):
+        Fk = grow(k)
+        t.update_mesh(Fk, V)
+        assert t.intersect(rays)[1].item() >= 0
+        del Fk
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()                        # torch's own cached blocks are not the library's
+        worst = max(worst, free0 - torch.cuda.mem_get_info()[0])
+    per_mesh = 360 * (F.shape[0] + 512 * 43 * 22)       # ~bytes per face of all per-mesh buffers x the largest mesh
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    drift = free0 - torch.cuda.mem_get_info()[0]
+    # the buffers of ONE (the largest) mesh may be live; 40 leaked generations of wide/range arrays would be >> that
+    assert drift < 2 * per_mesh + (64 << 20), (drift, per_mesh)
+    bad, _ = t.check()
+    assert bad == 0
+
+
+def test_stage_timer_pool_grows_instead_of_dropping(Render):
+    """More timed launches between two reads than the initial event pool holds (4096 pairs): every one is recorded."""
+    hand = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(hand, 0)
+    tr = scene.optix_mesh
+    tr.profile_enable(1)
+    tr.profile_read()
+    V = scene.vertices.detach().clone()
+    n = 4300
+    for _ in range(n):
+        tr.update_vert_f64(V)                           # one "build" stage pair per call
+    prof = tr.profile_read()
+    assert prof["build"][1] == n and prof["build"][0] > 0
+    tr.profile_enable(0)

@@ -1,0 +1,76 @@
+"""The multi-GPU step on the HIP path: two ranks (gloo, both on cuda:0 -- the GPU box has one device; on an 8-GPU
+node the same code runs one rank per GPU over RCCL) run drt_amd.optim.full_batch_step -- the function bench.py times --
+for three steps.  Parameters must be bit-identical across ranks and agree with the single-rank run to 1e-12 relative
+(the only difference is the summation order of float64 atomics and of the all-reduce)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import IOR, data_path
+
+pytestmark = pytest.mark.gpu
+
+N_VIEWS, RES, STEPS = 6, 128, 3
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(rank, world, fused):
+    """Three full-batch steps of this rank's share of the views; returns (parameter, per-step global losses)."""
+    from drt_amd import diffrender as Render, dist as ddist, mesh_io, optim as O, views
+    Render.intIOR = IOR
+    Render.resx = Render.resy = RES
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    center, extent = views.mesh_frame(mesh.vertices)
+    scene = Render.Scene(mesh, 0)
+    cams = views.turntable_cameras(center, extent, N_VIEWS, RES, RES)
+    local = []
+    for k in ddist.shard_views(N_VIEWS, rank, world):
+        o, d = views.generate_ray(RES, RES, cams[k][3], cams[k][2], device="cuda")
+        rng = np.random.default_rng(100 + k)
+        sp = torch.tensor(rng.standard_normal((RES * RES, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0]), device="cuda")
+        local.append((sp, torch.tensor(rng.random(RES * RES) > 0.1, device="cuda"), o, d))
+    init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False)
+    ray_w = 40 * 217.5 / RES / RES
+    losses = []
+    for _ in range(STEPS):
+        loss = O.full_batch_step(scene, local, init_vertices, parameter, opt, ray_w, fused=fused).detach().clone()
+        ddist.allreduce_sum_(loss)
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    return parameter.detach().cpu().numpy(), np.array(losses)
+
+
+def _worker(rank, world, port, out_dir, fused):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),
+                      DRT_DIST_BACKEND="gloo")
+    from drt_amd import dist as ddist
+    torch.cuda.set_device(0)
+    r, _, w = ddist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    param, losses = _run(rank, world, fused)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), param=param, losses=losses)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_ranks_on_the_hip_path_equal_one_rank(tmp_path, fused):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fused), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
+    assert np.array_equal(r0["param"], r1["param"]) and np.array_equal(r0["losses"], r1["losses"])   # bit-identical ranks
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    param, losses = _run(0, 1, fused)
+    assert np.abs(param).max() > 1e-3 and np.isfinite(param).all()
+    scale = np.abs(param).max()
+    assert np.abs(r0["param"] - param).max() <= 1e-12 * scale, np.abs(r0["param"] - param).max() / scale
+    np.testing.assert_allclose(r0["losses"], losses, rtol=1e-12)

@@ -94,3 +94,62 @@ def test_capture_loader_falls_back_to_hdf5_lite(monkeypatch):
     monkeypatch.setattr(builtins, "__import__", no_h5py)
     cap = cd._open_capture(os.path.join(D, "smpl_f64le.h5"))
     assert isinstance(cap, h5.File) and np.asarray(cap["TestArray"][2]).tolist() == [2, 3, 4, 5, 6]
+
+
+def _capture_like(n=5, resy=12, resx=16, seed=0):
+    rng = np.random.default_rng(seed)
+    P = resy * resx
+    return {"cam_proj": rng.standard_normal((n, 4, 4)), "cam_k": rng.standard_normal((3, 3)),
+            "screen_position": rng.standard_normal((n, P, 3)) * (rng.random((n, P, 1)) > 0.7),
+            "mask": ((rng.random((n, resy, resx)) > 0.5) * 255).astype(np.uint8),
+            "ray_origin": rng.standard_normal((n, P, 3)).astype(np.float32), "ray_dir": rng.standard_normal((n, P, 3))}
+
+
+def test_writer_is_read_back_by_the_reader_and_by_libhdf5(tmp_path):
+    """hdf5_lite.write_simple (what tools/make_capture.py uses without h5py): our reader returns the arrays, and so does
+    the HDF5 C library itself where the image has one."""
+    arrays = _capture_like()
+    arrays["idx"] = np.arange(-5, 5, dtype=np.int64)
+    arrays["flag"] = np.array([True, False, True])
+    path = str(tmp_path / "cap.h5")
+    h5.write_simple(path, arrays)
+    with h5.File(path) as f:
+        assert sorted(f.keys()) == sorted(arrays)
+        for k, v in arrays.items():
+            want = v.astype(np.uint8) if v.dtype == np.bool_ else v
+            assert f[k].shape == want.shape and f[k].dtype == want.dtype and np.array_equal(f[k][...], want)
+            if want.ndim > 1:
+                assert np.array_equal(f[k][1], want[1])
+    with pytest.raises(ValueError):
+        h5.write_simple(path, {str(k): np.zeros(1) for k in range(9)})
+    with pytest.raises(h5.Hdf5Unsupported):
+        h5.write_simple(path, {"c": np.zeros(2, dtype=np.complex128)})
+    import h5lib
+    if h5lib.lib() is None:
+        pytest.skip("no libhdf5 in this image: the writer is checked by the reader only")
+    h5.write_simple(path, arrays)
+    for k, v in arrays.items():
+        want = v.astype(np.uint8) if v.dtype == np.bool_ else v
+        assert np.array_equal(h5lib.read(path, k, want.dtype), want)
+
+
+@pytest.mark.parametrize("deflate,shuffle", [(0, False), (4, False), (6, True)])
+def test_capture_layout_written_by_libhdf5(tmp_path, deflate, shuffle):
+    """A file with the capture's layout ([n,P,3] / [n,resy,resx] datasets, chunked one view per chunk as a writer
+    of multi-GB captures would, optionally deflate + shuffle) written by the HDF5 C library, read view by view."""
+    import h5lib
+    if h5lib.lib() is None:
+        pytest.skip("no libhdf5 in this image")
+    arrays = _capture_like(n=6, seed=3)
+    P = arrays["screen_position"].shape[1]
+    chunks = {"screen_position": (1, P, 3), "ray_dir": (2, P // 2, 3), "mask": (1, 12, 16), "ray_origin": (4, P, 1)}
+    path = str(tmp_path / "lib.h5")
+    h5lib.write(path, arrays, chunks=chunks, deflate=deflate, shuffle=shuffle)
+    with h5.File(path) as f:
+        for k, v in arrays.items():
+            d = f[k]
+            assert d.shape == v.shape and d.dtype == v.dtype
+            assert (d._kind == "chunked") == (k in chunks)
+            for i in range(len(v)):
+                assert np.array_equal(d[i], v[i]), (k, i)
+            assert np.array_equal(d[...], v) and np.array_equal(d[1:4], v[1:4])

@@ -274,3 +274,51 @@ def test_closest_point_matches_bruteforce(hostsim):
     assert dist[600:700].max() < 1e-12                        # a vertex is on the surface
     assert dist[700:800].max() < 1e-4                         # face centroids (float32 vertices, float64 mean)
     hostsim.hs_destroy(h)
+
+
+def test_degenerate_faces_vs_golden(hostsim, hand):
+    """The device math on the mesh with a zero-length edge (golden from the reference): never hits a zero-area face,
+    same silhouette set, NaN dihedral cosines / smoothness gradient in the same places (limit_hook zeroes them later)."""
+    g = golden("hand_degenerate")
+    topo = golden("hand_topology")
+    res = int(g["res"])
+    V = np.ascontiguousarray(g["vertices"].astype(np.float64))
+    s = HostScene(hostsim, hand.faces, V)
+    assert hostsim.hs_check(s.h) == 0
+    o, d = views.generate_ray(res, res, g["Kinv"], g["Rinv"])
+    T, ID, _ = s.intersect(_rays32(o, d))
+    f1 = np.full(res * res, -1, np.int32); f1[g["b1_ind"]] = g["b1_face"]
+    assert np.array_equal(ID, f1)
+    r = s.render(o.numpy(), d.numpy(), float(g["ior"]))
+    assert np.array_equal(np.flatnonzero(r["mask"][:, 0]), g["valid_ind"])
+    np.testing.assert_allclose(r["out_dir"][g["valid_ind"]], g["out_dir"], rtol=1e-10, atol=1e-11)
+    E2F = np.ascontiguousarray(topo["E2F"]); Edges = topo["Edges"]
+    origin3 = o[0].numpy().copy()
+    flags = np.zeros(len(E2F), np.uint8)
+    hostsim.hs_silhouette_flags(s.v64.ctypes.data, E2F.ctypes.data, len(E2F), origin3.ctypes.data, flags.ctypes.data)
+    sil = np.ascontiguousarray(Edges[flags.astype(bool)])
+    assert np.array_equal(sil, g["sil_edges"])
+    cam = _cam50(g)
+    index = np.zeros((len(sil), 2), np.int64); f = np.zeros(len(sil), np.float32)
+    hostsim.hs_edge_sample_forward(s.h, s.v64.ctypes.data, sil.ctypes.data, len(sil), cam.ctypes.data, origin3.ctypes.data,
+                                   index.ctypes.data, f.ctypes.data)
+    valid_edge = np.abs(f) > 1e-5
+    idx = index[valid_edge]
+    keep = (idx[:, 0] < res - 1) & (idx[:, 1] < res - 1) & (idx[:, 0] >= 0) & (idx[:, 1] >= 0)
+    assert np.array_equal(idx[keep], g["vh_index"])
+    hit = np.zeros(res * res, dtype=np.uint8); hit[g["b1_ind"]] = 1
+    soft = views.process_mask(hit.reshape(res, res))
+    diff = soft[idx[:, 1].clip(0, res - 1), idx[:, 0].clip(0, res - 1)] - 0.5
+    coef = np.zeros(len(sil))
+    coef[np.flatnonzero(valid_edge)[keep]] = -np.sign(diff[keep])
+    gv = np.zeros_like(s.v64)
+    hostsim.hs_edge_sample_backward(s.v64.ctypes.data, sil.ctypes.data, len(sil), cam.ctypes.data, f.ctypes.data, coef.ctypes.data, 1, gv.ctypes.data)
+    ref = g["grad_vh"]
+    np.testing.assert_allclose(gv, ref, rtol=1e-8, atol=1e-10 * np.nanmax(np.abs(ref)), equal_nan=True)
+    cosv = np.zeros(len(E2F)); loss = np.zeros(1); gsm = np.zeros_like(V)
+    hostsim.hs_dihedral(V.ctypes.data, E2F.ctypes.data, len(E2F), 2, cosv.ctypes.data, None, loss.ctypes.data, gsm.ctypes.data)
+    np.testing.assert_allclose(cosv, g["dihedral_cos"], rtol=1e-10, atol=1e-12, equal_nan=True)
+    assert np.isnan(loss[0])
+    ref = g["grad_sm"]
+    assert np.array_equal(np.isnan(gsm), np.isnan(ref))
+    np.testing.assert_allclose(gsm, ref, rtol=1e-8, atol=1e-10 * np.nanmax(np.abs(ref)), equal_nan=True)

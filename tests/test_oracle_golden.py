@@ -245,3 +245,78 @@ def test_oracle_bvh_tracer_equals_bruteforce(hand):
     assert (I0[len(cam):] >= 0).mean() > 0.1
     Te, Ie = orc.trace_closest(np.zeros((0, 3), np.int32), v32, rays[:5], bvh=True)
     assert (Ie == -1).all() and (Te == -1).all()
+
+
+def test_degenerate_faces_follow_the_reference(hand):
+    """hand_degenerate.npz (a zero-length edge = two zero-area faces, the defect of monkey_vh.ply / dog_vh.ply): a zero-area
+    face is never hit, its normal is NaN (reference DiffRender.py:103-104, 149-163), NaN reaches the smoothness loss and
+    the vertex gradient, and limit_hook (optim.py:155-162) zeroes it before the SGD step."""
+    g = golden("hand_degenerate")
+    topo = golden("hand_topology")
+    res = int(g["res"])
+    Vs = torch.tensor(g["vertices"].astype(np.float64))
+    Edges, E2F = torch.tensor(topo["Edges"]), torch.tensor(topo["E2F"])
+    assert np.array_equal(g["Edges"], topo["Edges"])
+    tri = Vs[torch.tensor(hand.faces)]
+    area = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).norm(dim=1)
+    assert np.array_equal(np.flatnonzero(area.numpy() == 0), g["zero_area_faces"])
+    center, extent = views.mesh_frame(hand.vertices)
+    cams = views.turntable_cameras(center, extent, 72, res, res)
+    o, d = views.generate_ray(res, res, g["Kinv"], g["Rinv"])
+    rng = np.random.default_rng(int(g["target_seed"]))
+    sp = torch.tensor(rng.standard_normal((res * res, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0]))
+    valid = torch.tensor(rng.random(res * res) > 0.1)
+    V = Vs.clone().requires_grad_(True)
+    mesh = orc.Mesh(hand.faces, V)
+    oo, od, mk, aux = orc.render_transparent(mesh, o, d, float(g["ior"]), return_aux=True)
+    assert np.array_equal(torch.nonzero(mk[:, 0]).squeeze(1).numpy(), g["valid_ind"])
+    f1 = np.full(res * res, -1, np.int64); f1[g["b1_ind"]] = g["b1_face"]
+    assert np.array_equal(aux["face1"].numpy(), f1) and not np.isin(g["zero_area_faces"], f1).any()
+    close(od[mk[:, 0]], g["out_dir"]); close(oo[mk[:, 0]], g["out_ori"], atol=1e-9)
+    ray = orc.ray_loss(oo, od, mk, sp, valid)
+    assert ray.item() == pytest.approx(float(g["ray_loss"]), rel=1e-11)
+    g_ray, = torch.autograd.grad(ray, V)
+    close(g_ray, g["grad_ray_loss"], rtol=1e-8, atol=1e-11 * np.abs(g["grad_ray_loss"]).max())
+    cam = tuple(torch.tensor(g[k]) for k in ("R", "K", "Rinv", "Kinv"))
+    sil = orc.silhouette_edges(V, Edges, E2F, o[0])
+    assert np.array_equal(sil.numpy(), g["sil_edges"])
+    index, output = orc.primary_visibility(mesh, sil, cam, o[0], res, res, detach_depth=True)
+    assert np.array_equal(index.numpy(), g["vh_index"])
+    hit = np.zeros(res * res, dtype=np.uint8); hit[g["b1_ind"]] = 1
+    soft = torch.tensor(views.process_mask(hit.reshape(res, res)), dtype=torch.float64).reshape(-1)
+    vh = orc.vh_loss_view(mesh, Edges, E2F, cam, o[0], soft, res, res)
+    assert vh.item() == pytest.approx(float(g["vh_loss"]), rel=1e-12)
+    g_vh, = torch.autograd.grad(vh, V)
+    np.testing.assert_allclose(g_vh.numpy(), g["grad_vh"], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(g["grad_vh"])), equal_nan=True)
+    cosang = orc.dihedral_cos(V, E2F)
+    assert np.isnan(g["dihedral_cos"]).sum() == 5
+    np.testing.assert_allclose(cosang.detach().numpy(), g["dihedral_cos"], rtol=RTOL, atol=1e-11, equal_nan=True)
+    sm = orc.sm_loss(V, E2F)
+    assert np.isnan(sm.item()) and np.isnan(float(g["sm_loss"]))
+    g_sm, = torch.autograd.grad(sm, V)
+    assert np.array_equal(np.isnan(g_sm.numpy()), np.isnan(g["grad_sm"]))
+    np.testing.assert_allclose(g_sm.numpy(), g["grad_sm"], rtol=1e-8, atol=1e-10 * np.nanmax(np.abs(g["grad_sm"])), equal_nan=True)
+    # the whole iteration: NaN loss, finite clamped gradient, finite parameters
+    base = orc.Mesh(hand.faces, Vs)
+    p = torch.zeros_like(Vs).requires_grad_(True)
+    Vp = Vs + p
+    mesh = orc.Mesh(hand.faces, Vp)
+    oo, od, mk = orc.render_transparent(mesh, o, d, float(g["ior"]))
+    ray = orc.ray_loss(oo, od, mk, sp, valid)
+    vh = 0
+    for k in g["sil_views"]:
+        R, K, Rinv, Kinv = cams[int(k)]
+        ok, dk = views.generate_ray(res, res, Kinv, Rinv)
+        _, hitk = orc.intersect_ids(base, ok, dk)
+        softk = torch.tensor(views.process_mask(hitk.numpy().reshape(res, res)), dtype=torch.float64).reshape(-1)
+        camk = tuple(torch.tensor(a, dtype=torch.float64) for a in (R, K, Rinv, Kinv))
+        vh = vh + orc.vh_loss_view(mesh, Edges, E2F, camk, ok[0], softk, res, res)
+    sm = orc.sm_loss(Vp, E2F)
+    loss = orc.total_loss(ray, vh, sm, res, float(g["mean_len"]))
+    assert np.isnan(loss.item()) and f"ray={ray:g} vh={vh:g} sm={sm:g}" == str(g["step_loss_str"])
+    grad, = torch.autograd.grad(loss, p)
+    grad = orc.limit_grad(grad)
+    assert torch.isfinite(grad).all()
+    close(grad, g["step_grad"], rtol=1e-8, atol=1e-12)
+    param, _ = orc.sgd_nesterov_step(torch.zeros_like(Vs), grad, None, float(g["lr"]), float(g["momentum"]))
+    close(param, g["step_param"], rtol=1e-8, atol=1e-13)
