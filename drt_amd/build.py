@@ -48,5 +48,41 @@ def build(force=False, verbose=False, out=OUT, extra_flags=()):
     return out
 
 
+OPTIX_SRC = os.path.join(CSRC, "optix_hip.cpp")
+OPTIX_OUT = os.path.join(HERE, "optix.so")
+
+
+def optix_ext_flags():
+    """(include dirs, compile flags, link flags) of the pybind11 tracer class -- the same ones the reference-style
+    ``torch.utils.cpp_extension.load(name="optix", sources=[optix_hip.cpp], extra_include_paths=..., extra_cflags=...,
+    extra_ldflags=...)`` call takes."""
+    inc = [os.path.join(os.path.dirname(HERE), "include"), "/opt/rocm/include"]
+    cflags = ["-D__HIP_PLATFORM_AMD__=1"]
+    ldflags = ["-L" + HERE, "-ldrt_hip", "-Wl,-rpath," + HERE, "-lc10_hip"]
+    return inc, cflags, ldflags
+
+
+def build_optix_ext(force=False, verbose=False):
+    """g++ the torch extension in-tree (drt_amd/optix.so: ``import drt_amd.optix``); host-only C++ over the C ABI."""
+    deps = [OPTIX_SRC, OUT, os.path.join(os.path.dirname(HERE), "include", "drt_hip.h")]
+    if not force and os.path.exists(OPTIX_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OPTIX_OUT) for d in deps):
+        return OPTIX_OUT
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    inc, cflags, ldflags = optix_ext_flags()
+    inc = inc + ce.include_paths() + [sysconfig.get_paths()["include"]]
+    tlib = ce.library_paths()[0]
+    cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=optix", "-DTORCH_API_INCLUDE_EXTENSION_H",
+            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] + cflags + ["-isystem" + i for i in inc] +
+           ["-o", OPTIX_OUT, OPTIX_SRC, "-L" + tlib, "-Wl,-rpath," + tlib, "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python"] +
+           [f for f in ldflags if not f.startswith("-Wl,-rpath")] + ["-Wl,-rpath,$ORIGIN"])      # in-tree: libdrt_hip.so sits next to it
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OPTIX_OUT
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_optix_ext(force=True, verbose=True)

@@ -70,6 +70,7 @@ void drt_destroy(drt_scene_t* s) {
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
     (void)hipFree(s->scratch);
+    (void)hipFree(s->b1_list); (void)hipFree(s->b1_redo); (void)hipFree(s->b1_count);
     for (int j = 0; j < drt_scene::kMaxSub; ++j) {
         drt_scene::Sub& w = s->sub[j];
         for (int k = 0; k < 3; ++k) { (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]); }

@@ -33,6 +33,34 @@ __device__ __forceinline__ int block_push(bool pred, unsigned* counter, unsigned
     return slot;
 }
 
+// Conservative "can this ray touch the mesh at all": two levels of the wide tree (the root's
+// children, then the children of every inner child the ray enters).  k_cull is HBM-bound, so these
+// <= 20 slab tests are free, and every ray they reject is one the traversal stages never see.
+__device__ __forceinline__ unsigned hit_mask4(const Node4Q* __restrict__ node, f3 inv, f3 oi) {
+    const F4* np = reinterpret_cast<const F4*>(node);
+    const int32_t* ch = node->child;
+    float t[4];
+    bool h[4];
+    slab_node4q(np[0], np[1], np[2], inv, oi, INFINITY, t, h);
+    return (unsigned)(h[0] & (ch[0] != kEmptyChild)) | ((unsigned)(h[1] & (ch[1] != kEmptyChild)) << 1) |
+           ((unsigned)(h[2] & (ch[2] != kEmptyChild)) << 2) | ((unsigned)(h[3] & (ch[3] != kEmptyChild)) << 3);
+}
+
+__device__ __forceinline__ bool hits_top_boxes(const Node4Q* __restrict__ nodes, f3 o, f3 d) {
+    const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
+    const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
+    const unsigned m = hit_mask4(nodes, inv, oi);
+    if (m == 0) return false;
+    bool any = false;
+    for (int k = 0; k < 4; ++k) {
+        if (!((m >> k) & 1u)) continue;
+        const int32_t c = nodes[0].child[k];
+        if (c < 0) { any = true; continue; }            // a leaf directly under the root
+        any |= hit_mask4(nodes + c, inv, oi) != 0;
+    }
+    return any;
+}
+
 struct AtomicAdd3 {
     double* g;
     __device__ __forceinline__ void operator()(int32_t v, d3 a) const {

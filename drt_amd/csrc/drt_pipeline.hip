@@ -1,5 +1,6 @@
 // drt_pipeline.hip -- the two-bounce refraction path (render_transparent), its backward, ray_loss and the fused loss.
 #include "drt_device.h"
+#include "drt_trace_kernel.h"
 
 // ---- the two-bounce refraction path as a compacted wavefront pipeline ---------------------
 //
@@ -93,34 +94,6 @@ __device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
     e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z;
 }
 
-// Conservative "can this ray touch the mesh at all": two levels of the wide tree (the root's
-// children, then the children of every inner child the ray enters).  k_cull is HBM-bound, so these
-// <= 20 slab tests are free, and every ray they reject is one the traversal stages never see.
-__device__ __forceinline__ unsigned hit_mask4(const Node4Q* __restrict__ node, f3 inv, f3 oi) {
-    const F4* np = reinterpret_cast<const F4*>(node);
-    const int32_t* ch = node->child;
-    float t[4];
-    bool h[4];
-    slab_node4q(np[0], np[1], np[2], inv, oi, INFINITY, t, h);
-    return (unsigned)(h[0] & (ch[0] != kEmptyChild)) | ((unsigned)(h[1] & (ch[1] != kEmptyChild)) << 1) |
-           ((unsigned)(h[2] & (ch[2] != kEmptyChild)) << 2) | ((unsigned)(h[3] & (ch[3] != kEmptyChild)) << 3);
-}
-
-__device__ __forceinline__ bool hits_top_boxes(const Node4Q* __restrict__ nodes, f3 o, f3 d) {
-    const f3 inv{safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)};
-    const f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
-    const unsigned m = hit_mask4(nodes, inv, oi);
-    if (m == 0) return false;
-    bool any = false;
-    for (int k = 0; k < 4; ++k) {
-        if (!((m >> k) & 1u)) continue;
-        const int32_t c = nodes[0].child[k];
-        if (c < 0) { any = true; continue; }            // a leaf directly under the root
-        any |= hit_mask4(nodes + c, inv, oi) != 0;
-    }
-    return any;
-}
-
 // `tile_w` > 0: the rays are rows of an image `tile_w` pixels wide (any number of images of a
 // multiple-of-4 height, concatenated).  A block then takes a 64x4 pixel patch per iteration and
 // appends its candidates in 16x4-tile order, so that the 64 rays a traversal wave picks up come from
@@ -173,110 +146,6 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
             slot = block_push(cand, &p.count[0], s_tmp);
         }
         if (slot >= 0) { p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d); }
-    }
-}
-
-// Persistent traversal over a ray list.  Each wave owns a contiguous segment of the list; a lane
-// whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
-template <bool ANY>
-__global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
-                                                       int32_t* __restrict__ out_face, int32_t* __restrict__ redo_list, unsigned* redo_count,
-                                                       int refill_min, int inner_min, unsigned long long* stats) {
-    __shared__ int32_t lds[kStackFast + 1][kPathBlock];     // + the dump slot of FastStack: 20 x 1 KB x 8 blocks = the CU's 160 KB
-    FastStack st;
-    st.fast = &lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast; st.sp = 0; st.overflow = false;
-    const unsigned n = *n_ptr;
-    const int lane = threadIdx.x & 63;
-    // Work assignment without atomics, XCD-aware: workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
-    // b % 8), and every XCD has its own L2.  The list -- in tile order, so neighbouring entries walk the same part of the
-    // tree -- is therefore cut into 8 contiguous parts, one per XCD, and only WITHIN its part are the groups of 64
-    // consecutive rays interleaved over that XCD's waves (wave w owns groups w, w + W, w + 2W, ... of the part: coherent
-    // within a group, statistically balanced across waves).  `taken` counts the rays this wave has started.
-    constexpr unsigned kXcd = 8;
-    const unsigned n_groups = (n + 63u) >> 6;
-    const bool split = gridDim.x % kXcd == 0 && n_groups >= 64u * kXcd;
-    const unsigned xcd = split ? blockIdx.x % kXcd : 0u, parts = split ? kXcd : 1u;
-    const unsigned wave = (split ? blockIdx.x / kXcd : blockIdx.x) * kPathWaves + (threadIdx.x >> 6);
-    const unsigned n_waves = (split ? gridDim.x / kXcd : gridDim.x) * kPathWaves;
-    const unsigned part_lo = (unsigned)((unsigned long long)n_groups * xcd / parts), part_hi = (unsigned)((unsigned long long)n_groups * (xcd + 1) / parts);
-    const unsigned part_groups = part_hi - part_lo;
-    const unsigned my_groups = wave < part_groups ? (part_groups - wave + n_waves - 1) / n_waves : 0u;
-    const unsigned my_rays = my_groups << 6;      // upper bound; indices >= n are skipped
-    unsigned taken = 0;
-    int32_t slot = -1;
-    TravState s;
-    unsigned long long wave_steps = 0, lane_steps = 0, refills = 0;   // wave-uniform diagnostics (scalar registers)
-    for (;;) {
-        const unsigned long long idle = __ballot(slot < 0);
-        if (idle != 0 && taken < my_rays && (__popcll(idle) >= refill_min || idle == ~0ull)) {
-            if (slot < 0) {
-                const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-                const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
-                if (j < my_rays && k < n) {
-                    const float* e = rays + 6 * (int64_t)k;
-                    trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
-                    st.overflow = false;
-                    slot = (int32_t)k;
-                }
-            }
-            taken += (unsigned)__popcll(idle);
-            ++refills;
-        }
-        const unsigned long long busy = __ballot(slot >= 0);
-        if (busy == 0) break;
-        // inner phase ("while-while"): lanes at inner nodes keep descending; lanes that reached a leaf
-        // wait, so that the (longer) triangle code runs once for many lanes instead of on every step
-        for (;;) {
-            const bool at_inner = slot >= 0 && s.cur >= 0;
-            const unsigned long long mi = __ballot(at_inner);
-            if (mi == 0) break;
-            if (__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
-            ++wave_steps;
-            lane_steps += (unsigned long long)__popcll(mi);
-            if (at_inner) {
-                const bool done = trav_inner(c.nodes, s, st);
-                if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to k_trace_redo
-                    redo_list[atomicAdd(redo_count, 1u)] = slot;
-                    slot = -1;
-                } else if (done) {
-                    out_face[slot] = s.best_face;
-                    slot = -1;
-                }
-            }
-        }
-        // leaf phase
-        const bool at_leaf = slot >= 0 && s.cur < 0;
-        const unsigned long long ml = __ballot(at_leaf);
-        if (ml != 0) {
-            ++wave_steps;
-            lane_steps += (unsigned long long)__popcll(ml);
-            if (at_leaf && trav_leaf<ANY>(c.tris, s, st)) {
-                out_face[slot] = s.best_face;
-                slot = -1;
-            }
-        }
-    }
-    if (stats && lane == 0 && wave_steps) {
-        atomicAdd(stats + 0, wave_steps);
-        atomicAdd(stats + 1, lane_steps);
-        atomicAdd(stats + 2, refills);
-        atomicMax(stats + 3, wave_steps);
-    }
-}
-
-// Second pass for the rays whose traversal overflowed the LDS-only stack of k_trace: one thread per
-// ray, spilling stack.  Normally the list is empty and the kernel returns at once.
-template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock) k_trace_redo(TraceCtx c, const float* __restrict__ rays, const int32_t* __restrict__ redo_list,
-                                                             const unsigned* __restrict__ redo_count, int32_t* __restrict__ out_face) {
-    __shared__ int32_t lds[kStackFast][kTraceBlock];
-    const unsigned n = *redo_count;
-    if (n == 0) return;
-    Stack st = make_stack(lds, c);
-    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
-        const int32_t slot = redo_list[k];
-        const float* e = rays + 6 * (int64_t)slot;
-        out_face[slot] = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st).face;
     }
 }
 
@@ -698,18 +567,18 @@ static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const 
     { StageTimer t(s, st, kStageCull);
       k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
     { StageTimer t(s, st, kStageTrace1);
-      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, p.r0.face, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
-      k_trace_redo<false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, p.r0.face); }
+      k_trace<false, false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
+      k_trace_redo<false, false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, TraceOut{p.r0.face, nullptr, nullptr, nullptr}); }
     { StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace2);
-      k_trace<false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, p.r1.face, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
-      k_trace_redo<false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, p.r1.face); }
+      k_trace<false, false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
+      k_trace_redo<false, false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, TraceOut{p.r1.face, nullptr, nullptr, nullptr}); }
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);
-      k_trace<true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, p.r2.face, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
-      k_trace_redo<true><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, p.r2.face); }
+      k_trace<true, false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
+      k_trace_redo<true, false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, TraceOut{p.r2.face, nullptr, nullptr, nullptr}); }
 }
 }  // extern "C++"
 
@@ -735,7 +604,7 @@ static PathCtx sub_ctx(const drt_scene* s, const drt_scene::Sub& w, const double
 }
 int pipeline_blocks_per_cu() {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu;
 }
 

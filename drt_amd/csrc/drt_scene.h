@@ -84,6 +84,9 @@ struct drt_scene {
     BuildParams* params = nullptr;
     int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev] (B1 queries and edge probes)
     unsigned long long* scratch = nullptr;  // small counters
+    int32_t *b1_list = nullptr, *b1_redo = nullptr;   // B1 queries (drt_intersect*): candidate ray numbers, redo list
+    unsigned* b1_count = nullptr;           // [0] candidates, [1] redo entries
+    int64_t b1_cap = 0;
     // wavefront-pipeline workspace, sized for one chunk of rays, allocated on first use
     // Pipeline workspaces: one per internal stream.  A call is cut into sub-batches that run on
     // different HIP streams, so that the HBM-bound k_cull of one sub-batch overlaps the latency-bound

@@ -1,21 +1,28 @@
 // drt_trace.hip -- boundary B1 (closest / any hit per ray, the exhaustive diagnostic) and the closest-point query.
 #include "drt_device.h"
+#include "drt_trace_kernel.h"
 
+// B1 prefilter: one thread per ray.  A ray that misses the top two levels of the wide tree is answered here (most
+// camera rays of a view miss the object); the others go, as ray numbers, to the persistent traversal kernel the
+// refraction pipeline uses (drt_trace_kernel.h).  HBM-bound: 24 B read + 8 B (closest) or 1 B (any) written per ray.
 template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock) k_intersect(TraceCtx c, const float* __restrict__ rays, int64_t n,
-                                                            float* __restrict__ T, int32_t* __restrict__ ID,
-                                                            uint8_t* __restrict__ hitflag) {
-    __shared__ int32_t lds[kStackFast][kTraceBlock];
-    Stack st = make_stack(lds, c);
-    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
-        const f3 o{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, d{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
-        const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, o, d, st);
-        if (ANY) {
-            hitflag[i] = h.face >= 0 ? 1 : 0;
-        } else {
-            T[i] = h.t;
-            ID[i] = h.face;
+__global__ void __launch_bounds__(kPathBlock) k_b1_cull(const Node4Q* __restrict__ nodes, int n_tris, const float* __restrict__ rays, int64_t n,
+                                                         float* __restrict__ T, int32_t* __restrict__ ID, uint8_t* __restrict__ hitflag,
+                                                         int32_t* __restrict__ list, unsigned* count) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
+        const int64_t i = base + threadIdx.x;
+        bool cand = false;
+        if (i < n) {
+            const float* e = rays + 6 * i;
+            cand = n_tris > 0 && hits_top_boxes(nodes, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+            if (!cand) {
+                if (ANY) hitflag[i] = 0; else { T[i] = -1.0f; ID[i] = -1; }
+            }
         }
+        if (!__syncthreads_or(cand ? 1 : 0)) continue;
+        const int slot = block_push(cand, count, s_tmp);
+        if (slot >= 0) list[slot] = (int32_t)i;
     }
 }
 
@@ -61,8 +68,31 @@ __global__ void __launch_bounds__(kTraceBlock) k_closest_point(TraceCtx c, const
 
 int query_blocks_per_cu() {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_intersect<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_closest_point, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 8;
     return per_cu;
+}
+
+// prefilter -> persistent traversal -> redo, all on the caller's stream; workspace grown on demand (a scene serves one
+// B1 call at a time, like the reference's optix_mesh)
+template <bool ANY>
+static int b1_query(drt_scene* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, uint8_t* d_hit, hipStream_t st) {
+    if (n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (n_rays > s->b1_cap) {
+        (void)hipFree(s->b1_list); (void)hipFree(s->b1_redo);
+        s->b1_list = s->b1_redo = nullptr; s->b1_cap = 0;
+        HIP_TRY(hipMalloc(&s->b1_list, sizeof(int32_t) * n_rays));
+        HIP_TRY(hipMalloc(&s->b1_redo, sizeof(int32_t) * n_rays));
+        s->b1_cap = n_rays;
+    }
+    if (!s->b1_count) HIP_TRY(hipMalloc(&s->b1_count, sizeof(unsigned) * 2));
+    HIP_TRY(hipMemsetAsync(s->b1_count, 0, sizeof(unsigned) * 2, st));
+    const TraceCtx tc = trace_ctx(s);
+    const TraceOut out{d_ID, d_T, d_hit, s->b1_list};
+    k_b1_cull<ANY><<<grid_for(n_rays, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(tc.nodes, tc.n_tris, d_rays, n_rays, d_T, d_ID, d_hit, s->b1_list, s->b1_count);
+    k_trace<ANY, true><<<s->grid_path, kPathBlock, 0, st>>>(tc, d_rays, s->b1_count, out, s->b1_redo, s->b1_count + 1, s->refill_min, s->inner_min, nullptr);
+    k_trace_redo<ANY, true><<<kRedoGrid, kTraceBlock, 0, st>>>(tc, d_rays, s->b1_redo, s->b1_count + 1, out);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
 }
 
 extern "C" {
@@ -71,18 +101,14 @@ int drt_intersect(drt_scene_t* s, const float* d_rays, int64_t n_rays, float* d_
     CHECK_BUILT(s);
     if (n_rays < 0 || (n_rays && (!d_rays || !d_T || !d_ID))) return fail(DRT_E_INVALID, "bad ray arguments");
     if (n_rays == 0) return DRT_OK;
-    k_intersect<false><<<grid_for(n_rays, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, d_T, d_ID, nullptr);
-    HIP_TRY(hipGetLastError());
-    return DRT_OK;
+    return b1_query<false>(s, d_rays, n_rays, d_T, d_ID, nullptr, (hipStream_t)stream);
 }
 
 int drt_intersect_any(drt_scene_t* s, const float* d_rays, int64_t n_rays, uint8_t* d_hit, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || (n_rays && (!d_rays || !d_hit))) return fail(DRT_E_INVALID, "bad ray arguments");
     if (n_rays == 0) return DRT_OK;
-    k_intersect<true><<<grid_for(n_rays, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), d_rays, n_rays, nullptr, nullptr, d_hit);
-    HIP_TRY(hipGetLastError());
-    return DRT_OK;
+    return b1_query<true>(s, d_rays, n_rays, nullptr, nullptr, d_hit, (hipStream_t)stream);
 }
 
 int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, void* stream) {

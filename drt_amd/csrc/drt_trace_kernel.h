@@ -1,0 +1,132 @@
+// drt_trace_kernel.h -- the persistent BVH traversal kernel, shared by the refraction pipeline (drt_pipeline.hip:
+// compact ray lists R0..R2 -> face per list slot) and by boundary B1 (drt_trace.hip: optix_mesh::intersect of
+// reference optix_extend.cpp:29-57 -> T, ID per ray; the any-hit form -> hit flag per ray).
+#pragma once
+#include "drt_device.h"
+
+// Where a finished ray's result goes.  Pipeline: out.face[list slot].  B1 (`idx` non-null): the list holds ray numbers;
+// the float32 ray is read from rays[idx[slot]] and T / ID (closest) or the hit flag (any) are written at that ray number.
+struct TraceOut {
+    int32_t* face;          // pipeline: [list size];  B1 closest: ID [N]
+    float* t;               // B1 closest: T [N] (miss = -1, like the brute force of oracle/tracer.c)
+    uint8_t* flag;          // B1 any-hit: [N]
+    const int32_t* idx;     // B1: list slot -> ray number
+};
+
+template <bool ANY, bool B1>
+__device__ __forceinline__ void trace_emit(const TraceOut& out, int32_t slot, float best_t, int32_t best_face) {
+    if (!B1) { out.face[slot] = best_face; return; }
+    const int32_t i = out.idx[slot];
+    if (ANY) { out.flag[i] = best_face >= 0 ? 1 : 0; return; }
+    out.t[i] = best_face >= 0 ? best_t : -1.0f;
+    out.face[i] = best_face;
+}
+template <bool B1>
+__device__ __forceinline__ const float* trace_ray(const float* __restrict__ rays, const TraceOut& out, unsigned slot) {
+    return rays + 6 * (int64_t)(B1 ? out.idx[slot] : (int32_t)slot);
+}
+
+// Persistent traversal over a ray list.  Each wave owns a contiguous segment of the list; a lane
+// whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
+template <bool ANY, bool B1>
+__global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
+                                                       TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count,
+                                                       int refill_min, int inner_min, unsigned long long* stats) {
+    __shared__ int32_t lds[kStackFast + 1][kPathBlock];     // + the dump slot of FastStack: 20 x 1 KB x 8 blocks = the CU's 160 KB
+    FastStack st;
+    st.fast = &lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast; st.sp = 0; st.overflow = false;
+    const unsigned n = *n_ptr;
+    const int lane = threadIdx.x & 63;
+    // Work assignment without atomics, XCD-aware: workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
+    // b % 8), and every XCD has its own L2.  The list -- in tile order, so neighbouring entries walk the same part of the
+    // tree -- is therefore cut into 8 contiguous parts, one per XCD, and only WITHIN its part are the groups of 64
+    // consecutive rays interleaved over that XCD's waves (wave w owns groups w, w + W, w + 2W, ... of the part: coherent
+    // within a group, statistically balanced across waves).  `taken` counts the rays this wave has started.
+    constexpr unsigned kXcd = 8;
+    const unsigned n_groups = (n + 63u) >> 6;
+    const bool split = gridDim.x % kXcd == 0 && n_groups >= 64u * kXcd;
+    const unsigned xcd = split ? blockIdx.x % kXcd : 0u, parts = split ? kXcd : 1u;
+    const unsigned wave = (split ? blockIdx.x / kXcd : blockIdx.x) * kPathWaves + (threadIdx.x >> 6);
+    const unsigned n_waves = (split ? gridDim.x / kXcd : gridDim.x) * kPathWaves;
+    const unsigned part_lo = (unsigned)((unsigned long long)n_groups * xcd / parts), part_hi = (unsigned)((unsigned long long)n_groups * (xcd + 1) / parts);
+    const unsigned part_groups = part_hi - part_lo;
+    const unsigned my_groups = wave < part_groups ? (part_groups - wave + n_waves - 1) / n_waves : 0u;
+    const unsigned my_rays = my_groups << 6;      // upper bound; indices >= n are skipped
+    unsigned taken = 0;
+    int32_t slot = -1;
+    TravState s;
+    unsigned long long wave_steps = 0, lane_steps = 0, refills = 0;   // wave-uniform diagnostics (scalar registers)
+    for (;;) {
+        const unsigned long long idle = __ballot(slot < 0);
+        if (idle != 0 && taken < my_rays && (__popcll(idle) >= refill_min || idle == ~0ull)) {
+            if (slot < 0) {
+                const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
+                if (j < my_rays && k < n) {
+                    const float* e = trace_ray<B1>(rays, out, k);
+                    trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+                    st.overflow = false;
+                    slot = (int32_t)k;
+                }
+            }
+            taken += (unsigned)__popcll(idle);
+            ++refills;
+        }
+        const unsigned long long busy = __ballot(slot >= 0);
+        if (busy == 0) break;
+        // inner phase ("while-while"): lanes at inner nodes keep descending; lanes that reached a leaf
+        // wait, so that the (longer) triangle code runs once for many lanes instead of on every step
+        for (;;) {
+            const bool at_inner = slot >= 0 && s.cur >= 0;
+            const unsigned long long mi = __ballot(at_inner);
+            if (mi == 0) break;
+            if (__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(mi);
+            if (at_inner) {
+                const bool done = trav_inner(c.nodes, s, st);
+                if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to k_trace_redo
+                    redo_list[atomicAdd(redo_count, 1u)] = slot;
+                    slot = -1;
+                } else if (done) {
+                    trace_emit<ANY, B1>(out, slot, s.best_t, s.best_face);
+                    slot = -1;
+                }
+            }
+        }
+        // leaf phase
+        const bool at_leaf = slot >= 0 && s.cur < 0;
+        const unsigned long long ml = __ballot(at_leaf);
+        if (ml != 0) {
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(ml);
+            if (at_leaf && trav_leaf<ANY>(c.tris, s, st)) {
+                trace_emit<ANY, B1>(out, slot, s.best_t, s.best_face);
+                slot = -1;
+            }
+        }
+    }
+    if (stats && lane == 0 && wave_steps) {
+        atomicAdd(stats + 0, wave_steps);
+        atomicAdd(stats + 1, lane_steps);
+        atomicAdd(stats + 2, refills);
+        atomicMax(stats + 3, wave_steps);
+    }
+}
+
+// Second pass for the rays whose traversal overflowed the LDS-only stack of k_trace: one thread per
+// ray, spilling stack.  Normally the list is empty and the kernel returns at once.
+template <bool ANY, bool B1>
+__global__ void __launch_bounds__(kTraceBlock) k_trace_redo(TraceCtx c, const float* __restrict__ rays, const int32_t* __restrict__ redo_list,
+                                                             const unsigned* __restrict__ redo_count, TraceOut out) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    const unsigned n = *redo_count;
+    if (n == 0) return;
+    Stack st = make_stack(lds, c);
+    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
+        const int32_t slot = redo_list[k];
+        const float* e = trace_ray<B1>(rays, out, (unsigned)slot);
+        const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st);
+        trace_emit<ANY, B1>(out, slot, h.t, h.face);
+    }
+}

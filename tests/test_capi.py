@@ -53,3 +53,24 @@ def test_null_arguments_are_rejected():
     assert lib.drt_intersect(None, None, 0, None, None, None) != 0
     assert lib.drt_ray_loss(None, None, None, None, None, 5, None, None, None, None, None) != 0
     lib.drt_destroy(None)   # no-op
+
+
+def test_optix_extension_loads_with_the_reference_call(tmp_path):
+    """Boundary B1 as the reference binds it (DiffRender.py:3-6): torch.utils.cpp_extension.load(name="optix", sources=[...])
+    of drt_amd/csrc/optix_hip.cpp gives a module with the pybind11 class of optix_extend.cpp:77-83; and the in-tree build
+    (drt_amd/optix.so) is the same class.  Host-only C++, so it builds and imports without a GPU; constructing a tracer
+    without one raises."""
+    from torch.utils.cpp_extension import load
+    build.build()
+    inc, cflags, ldflags = build.optix_ext_flags()
+    optix = load(name="optix", sources=[build.OPTIX_SRC], extra_include_paths=inc, extra_cflags=cflags, extra_ldflags=ldflags,
+                 build_directory=str(tmp_path))
+    members = {m for m in dir(optix.optix_mesh) if not m.startswith("_")}
+    assert members == {"update_mesh", "update_vert", "intersect"}
+    build.build_optix_ext()
+    import drt_amd.optix as intree
+    assert {m for m in dir(intree.optix_mesh) if not m.startswith("_")} == members
+    if not torch.cuda.is_available():
+        for mod in (optix, intree):
+            with pytest.raises(RuntimeError, match="libdrt_hip error"):
+                mod.optix_mesh(0)

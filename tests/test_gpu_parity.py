@@ -678,3 +678,49 @@ def test_silhouette_loss_edge_cases(Render, hand):
     assert scene.vh_loss_fused_views([]).item() == 0.0
     dist, face, closest = scene.optix_mesh.closest_point(torch.zeros((0, 3), dtype=torch.float64, device="cuda"), want_point=True)
     assert dist.shape == (0,) and face.shape == (0,) and closest.shape == (0, 3)
+
+
+def test_b1_torch_extension_used_like_the_reference(hand, horse50k):
+    """drt_amd/optix.so (csrc/optix_hip.cpp, the pybind11 class of optix_extend.cpp:77-83) driven the way
+    DiffRender.py does: optix.optix_mesh(device), update_mesh(F int32, V float32), update_vert(V), intersect(Ray [N,6])
+    -> [T, ID]; Scene.optix_intersect's `T > 0` (DiffRender.py:386-392).  On torch's current (non-default) stream."""
+    import drt_amd.optix as optix
+    mesh = optix.optix_mesh(0)
+    with pytest.raises(RuntimeError):
+        mesh.intersect(torch.zeros((1, 6), device="cuda"))               # update_mesh first
+    F = torch.tensor(hand.faces, dtype=torch.int32, device="cuda")
+    V = torch.tensor(hand.vertices, dtype=torch.float32, device="cuda")
+    mesh.update_mesh(F, V)
+    rays = _camera_rays(hand, 128, 5)
+    To, IDo = orc.trace_closest(hand.faces.astype(np.int32), hand.vertices.astype(np.float32), rays.numpy())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        T, ID = mesh.intersect(rays.cuda())
+    side.synchronize()
+    assert T.dtype == torch.float32 and ID.dtype == torch.int32 and T.is_contiguous() and ID.is_contiguous()
+    assert np.array_equal(ID.cpu().numpy(), IDo) and np.array_equal(T.cpu().numpy(), To)
+    hitted = T > 0
+    assert torch.equal(hitted, ID >= 0)
+    # update_vert: same topology, moved vertices -> same answer as a fresh update_mesh
+    V2 = V * 1.25 + 3.0
+    mesh.update_vert(V2)
+    T2, ID2 = mesh.intersect(rays.cuda())
+    To2, IDo2 = orc.trace_closest(hand.faces.astype(np.int32), V2.cpu().numpy(), rays.numpy())
+    assert np.array_equal(ID2.cpu().numpy(), IDo2) and np.array_equal(T2.cpu().numpy(), To2)
+    # validation instead of the reference's silent misreads
+    with pytest.raises(RuntimeError):
+        mesh.intersect(rays.cuda().double())
+    with pytest.raises(RuntimeError):
+        mesh.intersect(rays)                                               # CPU tensor
+    with pytest.raises(RuntimeError):
+        mesh.update_vert(V[:7])
+    wide = torch.zeros((len(rays), 12), dtype=torch.float32, device="cuda"); wide[:, ::2] = rays.cuda()
+    assert torch.equal(mesh.intersect(wide[:, ::2])[1], ID2)               # non-contiguous input
+    T0, ID0 = mesh.intersect(torch.zeros((0, 6), dtype=torch.float32, device="cuda"))
+    assert T0.shape == (0,) and ID0.shape == (0,)
+    # the 50k workload through the same class == the ctypes class
+    mesh.update_mesh(torch.tensor(horse50k.faces, dtype=torch.int32, device="cuda"), torch.tensor(horse50k.vertices, dtype=torch.float32, device="cuda"))
+    big = _camera_rays(horse50k, 512, 7).cuda()
+    Ta, IDa = mesh.intersect(big)
+    Tb, IDb = _tracer(horse50k).intersect(big)
+    assert torch.equal(IDa, IDb) and torch.equal(Ta, Tb) and 0.01 < (IDa >= 0).float().mean().item() < 0.6
