@@ -105,32 +105,50 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world):
                     "cache-resident BVH (see node_visits_per_ray, lane_utilisation); k_cull is the HBM-streaming stage."}
 
 
-def cpu_baseline(mesh, center, extent, res_sample=768):
-    """The oracle (a port of the reference's CPU path: brute-force float32 tracer + float64
-    PyTorch autograd) on one res_sample^2 slice of view 0 of the same workload, fwd + bwd."""
+def cpu_baseline(mesh, center, extent):
+    """the oracle (port of the reference's CPU path: brute-force float32 tracer + float64 PyTorch
+    autograd, `BASELINE.json:configs[0]`) on the GPU box's host cores, forward + backward, median of 3:
+      (i)  config 1 in full: hand_vh.ply, one view, 256x256;
+      (ii) the timed workload's mesh on a one-view 256x256 slice (cost is O(rays x faces): rays/s carries over to 72 x 1024^2).
+    `value` is (ii).  For context also a 768x768 slice and the same path with a BVH tracer instead of the brute force."""
+    import statistics
     from oracle import diffrender_oracle as orc
     cores = os.cpu_count() or 1
     orc.TRACER_THREADS = cores                       # the C tracers use every core ...
     orc.TORCH_THREADS = min(32, cores)               # ... PyTorch's float64 ops do not scale past a few dozen threads (they collapse at 256)
     torch.set_num_threads(orc.TORCH_THREADS)
-    R, K, Rinv, Kinv = views.turntable_cameras(center, extent, 72, res_sample, res_sample)[0]
-    o, d = views.generate_ray(res_sample, res_sample, Kinv, Rinv)
     rng = np.random.default_rng(0)
-    sp = torch.tensor(rng.standard_normal((res_sample ** 2, 3)) * 40.0 + center)
-    valid = torch.ones(res_sample ** 2, dtype=torch.bool)
-    times = []
-    for _ in range(2):
-        V = torch.tensor(mesh.vertices, dtype=torch.float64, requires_grad=True)
-        t0 = time.perf_counter()
-        om = orc.Mesh(mesh.faces, V)
-        oo, od, mk = orc.render_transparent(om, o, d, IOR)
-        loss = orc.ray_loss(oo, od, mk, sp, valid)
-        loss.backward()
-        times.append(time.perf_counter() - t0)
-    t = min(times)
-    out = {"value": round(res_sample ** 2 / t / 1e6, 6), "unit": "M camera-rays/s", "cores": cores, "kind": "port",
-           "sample": f"oracle (brute-force f32 tracer on {cores} threads + f64 autograd on {orc.TORCH_THREADS}), 1 view "
-                     f"{res_sample}x{res_sample} of the same {len(mesh.faces)}-triangle mesh, forward+backward, best of 2 ({t:.2f} s)"}
+
+    def run(m, c, ext, res, repeats):
+        R, K, Rinv, Kinv = views.turntable_cameras(c, ext, 72, res, res)[0]
+        o, d = views.generate_ray(res, res, Kinv, Rinv)
+        sp = torch.tensor(rng.standard_normal((res * res, 3)) * 40.0 + c)
+        valid = torch.ones(res * res, dtype=torch.bool)
+        times = []
+        for _ in range(repeats):
+            V = torch.tensor(m.vertices, dtype=torch.float64, requires_grad=True)
+            t0 = time.perf_counter()
+            om = orc.Mesh(m.faces, V)
+            oo, od, mk = orc.render_transparent(om, o, d, IOR)
+            loss = orc.ray_loss(oo, od, mk, sp, valid)
+            if loss.requires_grad:
+                loss.backward()
+            times.append(time.perf_counter() - t0)
+        return statistics.median(times), times
+
+    threads = f"brute-force f32 tracer on {cores} threads + f64 autograd on {orc.TORCH_THREADS}"
+    hand = mesh_io.read_ply(os.path.join(ROOT, "data", "hand_vh.ply"))
+    hc, hext = views.mesh_frame(hand.vertices)
+    run(hand, hc, hext, 64, 1)                       # thread pools, first-touch
+    t1, _ = run(hand, hc, hext, 256, 3)
+    t2, _ = run(mesh, center, extent, 256, 3)
+    t3, _ = run(mesh, center, extent, 768, 1)
+    out = {"value": round(256 ** 2 / t2 / 1e6, 6), "unit": "M camera-rays/s", "cores": cores, "kind": "port",
+           "sample": f"oracle ({threads}), 1 view 256x256 of the same {len(mesh.faces)}-triangle mesh, forward+backward, median of 3 ({t2:.3f} s)",
+           "config1": {"value": round(256 ** 2 / t1 / 1e6, 6), "unit": "M camera-rays/s",
+                       "sample": f"hand_vh.ply ({len(hand.faces)} triangles), 1 view 256x256 in full, forward+backward, median of 3 ({t1:.3f} s)"},
+           "slice_768": {"value": round(768 ** 2 / t3 / 1e6, 6), "unit": "M camera-rays/s",
+                         "sample": f"same mesh, 1 view 768x768, one run ({t3:.2f} s): the fixed costs of the 256x256 slice amortised"}}
     # context: the same CPU path with a reasonable tracer (oracle/bvh_tracer.c: same contract, median-split BVH instead of the
     # loop over every face, bit-identical hits) on a larger slice -- what a CPU implementation that is not brute force does
     res_b, n_b = 1024, 8
@@ -178,6 +196,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras after the timed region (fused-mode comparison, traversal statistics); "
                          "used under rocprofv3 so that the trace ends with the timed steps")
+    ap.add_argument("--displaced-targets", action="store_true", help="targets from a noise-displaced hull even when data/<mesh>_scan.ply exists")
     ap.add_argument("--random-targets", action="store_true",
                     help="skip the ground-truth render of the setup (targets = random points); used for PMC passes so that every "
                          "traced kernel dispatch belongs to a step")
@@ -206,7 +225,13 @@ def main():
 
     # ---- synthetic capture (untimed): targets from a displaced ground-truth mesh through the same path
     scene = Render.Scene(mesh, local_rank)
-    gt = views.displaced_ground_truth(mesh, sigma=0.3, seed=0)
+    # targets: the scanned object traced through the same path; meshes without a scan in data/ use a
+    # noise-displaced copy of the hull
+    scan_path = os.path.join(ROOT, "data", f"{args.mesh}_scan.ply")
+    if os.path.exists(scan_path) and not args.displaced_targets:
+        gt, target_src = mesh_io.read_ply(scan_path), f"{args.mesh}_scan.ply"
+    else:
+        gt, target_src = views.displaced_ground_truth(mesh, sigma=0.3, seed=0), "hull displaced along vertex normals, sigma 0.3"
     gt_scene = Render.Scene(gt, local_rank)
     my_views = ddist.shard_views(args.views, rank, world)
     cams = views.turntable_cameras(center, extent, args.views, res, res)
@@ -230,33 +255,16 @@ def main():
     data = [tuple(torch.cat([v[j] for v in data[i:i + bv]]).contiguous() for j in range(4)) for i in range(0, len(data), bv)]
     torch.cuda.empty_cache()
 
-    init_vertices = scene.vertices.clone()
-    parameter = torch.zeros_like(init_vertices, requires_grad=True)
-
-    def limit_hook(grad):                      # reference optim.py:155-162
-        grad = torch.nan_to_num(grad, nan=0.0, posinf=None, neginf=None)
-        return grad.clamp_(-1.0, 1.0)
-
-    opt = torch.optim.SGD([parameter], lr=0.1, momentum=0.95, nesterov=True, foreach=False)   # see drt_amd.optim.setup_opt
-    w_ray = 40 * 217.5 / res / res             # reference optim.py:127 with config.py defaults
+    from drt_amd import optim as O
+    init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False)    # reference optim.py:164-171
+    limit_hook = O.limit_hook
+    w_ray = O.loss_weights(O.HyperParams, res, scene.mean_len)[0]     # 40 * 217.5 / res^2 (reference optim.py:127, config.py defaults)
+    local_views = [(sp, valid, o, d) for sp, valid, o, d in data]
 
     def step(record):
-        opt.zero_grad(set_to_none=True)
-        vertices = init_vertices + parameter
-        scene.update_verticex(vertices)
-        loss = torch.zeros((), dtype=torch.float64, device=dev)
-        for sp, valid, o, d in data:
-            if args.mode == "fused":
-                loss = loss + scene.ray_loss_fused(o, d, sp, valid)
-            else:
-                out_ori, out_dir, mask = scene.render_transparent(o, d)
-                loss = loss + Render.ray_loss(out_ori, out_dir, mask, sp, valid)
-        (w_ray * loss).backward()
-        g = parameter.grad
-        ddist.allreduce_sum_(g)                # one RCCL all-reduce of grad[V,3] per step
-        parameter.grad = limit_hook(g)         # clamp AFTER the sum over views, like the single-GPU reference
-        opt.step()
-        return loss
+        """drt_amd.optim.full_batch_step: rebuild, every local view's render_transparent + ray_loss, backward, ONE
+        all-reduce of grad[V,3], limit_hook, SGD(nesterov) -- the same function the 2-rank tests run."""
+        return O.full_batch_step(scene, local_views, init_vertices, parameter, opt, w_ray, fused=args.mode == "fused")
 
     graph = None
     if args.graph:
@@ -301,7 +309,7 @@ def main():
         "vs_baseline": None, "dtype": "f32 traversal + f64 shading/gradients", "data": "synthetic",
         "config": {"workload": f"{mesh_src} = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD",
-                   "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
+                   "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
                    "final_loss": float(loss.item())},
     }
     prof_timed = scene.optix_mesh.profile_read() if live_profile else None
@@ -310,15 +318,7 @@ def main():
         # same K steps through the one-pass API (Scene.ray_loss_fused: no dense out_ori/out_dir/mask, rays of
         # pixels without a target dropped before tracing) -- reported next to the headline, never as `value`
         def fused_step():
-            opt.zero_grad(set_to_none=True)
-            scene.update_verticex(init_vertices + parameter)
-            fl = torch.zeros((), dtype=torch.float64, device=dev)
-            for sp, valid, o, d in data:
-                fl = fl + scene.ray_loss_fused(o, d, sp, valid)
-            (w_ray * fl).backward()
-            ddist.allreduce_sum_(parameter.grad)
-            parameter.grad = limit_hook(parameter.grad)
-            opt.step()
+            O.full_batch_step(scene, local_views, init_vertices, parameter, opt, w_ray, fused=True)
         scene.optix_mesh.profile_enable(0)
         fused_step()
         ddist.barrier(); torch.cuda.synchronize()
