@@ -78,6 +78,8 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world):
         "backward": (4 + 48 + 8 + 24) * v + 144 * v,
         "loss_bwd_fused": (8 + 48 + 8 + 24) * s2 + 144 * s2,
         "build": per_view_mesh_bytes(V, F) * args.steps,
+        # projected primary visibility: every image reads the triangle records once; per written key a 24-byte ray and a 16-byte atomic
+        "raster": 48 * F * n_local_views * args.steps + 40 * c,
     }
     stages = {}
     for k, (ms, launches, items) in prof.items():

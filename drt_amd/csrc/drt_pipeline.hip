@@ -98,15 +98,28 @@ __device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
 // multiple-of-4 height, concatenated).  A block then takes a 64x4 pixel patch per iteration and
 // appends its candidates in 16x4-tile order, so that the 64 rays a traversal wave picks up come from
 // a compact screen region (same BVH nodes, same depth) instead of a 64x1 strip.
+// Raster mode (`rz.views` non-null; needs tile_w > 0): the primary hit of a ray that verifies as a ray of its image's
+// pinhole grid was decided by k_raster (drt_raster.h) -- its key is read here, consumed (reset to empty) and the ray
+// goes to R0 with its face already known; only rays that do not verify take the top-box test and are listed in
+// `gen_list` for the traversal kernel, exactly as every candidate was before.
+struct RasterIn {
+    const ViewModel* views;          // null: BVH path for every ray
+    unsigned long long* zbuf;
+    uint32_t* zmask;
+    int32_t* gen_list;               // R0 slots that still need k_trace (count in p.count[3])
+    int img_w, img_h;
+};
+
 template <bool FUSED>
 __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
                                                       const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
                                                       double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w) {
+                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz) {
     __shared__ unsigned s_tmp[kPathWaves + 1];
     __shared__ uint8_t s_flag[kPathBlock];
     __shared__ int s_slot[kPathBlock];
     const int tid = threadIdx.x;
+    const bool raster = rz.views != nullptr;
     // (`nodes` is a __restrict__ parameter of its own, not the TraceCtx struct, so that the compiler can prove the root
     // node is never clobbered: it is then fetched once, through the scalar cache, instead of by four vector loads per ray)
     // patch = 64 pixels wide x 4 rows (every wave reads one full 1536-byte row segment); tiles of 16x4 pixels
@@ -114,18 +127,43 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
     const int64_t patches_per_row = tile_w > 0 ? tile_w / 64 : 1;
     for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
         int64_t i = base + tid;
+        int64_t y = 0, x = 0;
         if (tile_w > 0) {
             const int64_t patch = base / kPathBlock;
-            const int64_t y = 4 * (patch / patches_per_row) + (tid >> 6), x = 64 * (patch % patches_per_row) + (tid & 63);
+            y = 4 * (patch / patches_per_row) + (tid >> 6); x = 64 * (patch % patches_per_row) + (tid & 63);
             i = y * tile_w + x;
         }
-        bool cand = false;
+        bool cand = false, generic = false;
+        int32_t face = -1;
         f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f};
         if (i < n) {
+            unsigned long long key = kRasterEmpty;
+            if (raster) {
+                // the 64 rays of a wave are one 64-aligned run: one group bit decides whether any key was written here
+                const unsigned word = rz.zmask[i >> 11], bit = 1u << ((i >> 6) & 31);
+                if (word & bit) {
+                    key = rz.zbuf[i];
+                    if (key != kRasterEmpty) rz.zbuf[i] = kRasterEmpty;          // consumed: the buffer is empty again for the next call
+                    if ((tid & 63) == 0) atomicAnd(&rz.zmask[i >> 11], ~bit);
+                }
+            }
             // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
             if (!FUSED || valid[i]) {
-                o = to_f32(load_d3(origin, i)); d = to_f32(load_d3(dir, i));
-                cand = n_tris > 0 && hits_top_boxes(nodes, o, d);
+                const d3 o64 = load_d3(origin, i), d64 = load_d3(dir, i);
+                o = to_f32(o64); d = to_f32(d64);
+                bool verified = false;
+                if (raster) {
+                    const int64_t view = y / rz.img_h;
+                    const ViewModel& vm = rz.views[view];
+                    verified = vm.ok && view_verify(vm, o64, d64, (double)x, (double)(y - view * rz.img_h));
+                }
+                if (verified) {
+                    cand = key != kRasterEmpty;
+                    face = (int32_t)(uint32_t)key;
+                } else {
+                    cand = n_tris > 0 && hits_top_boxes(nodes, o, d);
+                    generic = cand;
+                }
             }
             if (!cand) {
                 face1[i] = -1;
@@ -145,7 +183,14 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
         } else {
             slot = block_push(cand, &p.count[0], s_tmp);
         }
-        if (slot >= 0) { p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d); }
+        if (slot >= 0) {
+            p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d);
+            if (raster) p.r0.face[slot] = face;
+        }
+        if (raster && __syncthreads_or(generic ? 1 : 0)) {       // rare: rays outside the grid model
+            const int g = block_push(generic, &p.count[3], s_tmp);
+            if (g >= 0) rz.gen_list[g] = slot;
+        }
     }
 }
 
@@ -487,11 +532,12 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
 }
 
 
-__global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused) {
+__global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused, int raster) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // sub-batches on different streams may report concurrently: atomics
     atomicAdd(&tot[kStageCull], n_rays);
-    atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
+    if (raster) atomicAdd(&tot[kStageRaster], n_rays);
+    atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
     atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
     atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[2]);
     atomicAdd(&tot[fused ? kStageLossBwdFused : kStageFinish], (unsigned long long)qcount[2]);
@@ -518,6 +564,8 @@ static int ensure_queues(drt_scene::Sub& w, int64_t n, bool fused) {
         }
         (void)hipFree(w.redo); w.redo = nullptr;
         HIP_TRY(hipMalloc(&w.redo, sizeof(int32_t) * n));
+        (void)hipFree(w.gen_list); w.gen_list = nullptr;
+        HIP_TRY(hipMalloc(&w.gen_list, sizeof(int32_t) * n));
         w.q_cap = n;
     }
     if (fused && n > w.fused_cap) {
@@ -539,9 +587,10 @@ static Pipe pipe_of(const drt_scene* s, const drt_scene::Sub& w) {
 // round-robin to `streams` internal streams.  Sub-batches are at most chunk_rays (workspace bound) and, when
 // there is enough work, at least min_sub_rays, so that small calls are not shredded into launch overhead.
 struct Plan { int64_t size; int count; int streams; };
-static Plan plan_call(const drt_scene* s, int64_t n_rays, int tile_w) {
+static Plan plan_call(const drt_scene* s, int64_t n_rays, int tile_w, int tile_h) {
     int64_t unit = 256;
     if (tile_w >= 64 && tile_w % 64 == 0) unit = 4 * (int64_t)tile_w;       // whole rows of 64x4 patches per sub-batch
+    if (unit > 256 && tile_h >= 4 && tile_h % 4 == 0 && n_rays % ((int64_t)tile_w * tile_h) == 0) unit = (int64_t)tile_w * tile_h;   // whole images (projected primary visibility)
     int64_t count = (n_rays + s->chunk_rays - 1) / s->chunk_rays;
     const int64_t by_min = n_rays / s->min_sub_rays;
     const int64_t most = (int64_t)s->n_sub * s->sub_per_stream;
@@ -557,28 +606,55 @@ static Plan plan_call(const drt_scene* s, int64_t n_rays, int tile_w) {
     return pl;
 }
 
+// Whole images of a multiple-of-64 width and multiple-of-4 height: the sub-batch can use the projected primary visibility.
+static bool raster_on(const drt_scene* s, int64_t n, int tile_w, int tile_h) {
+    if (!s->use_raster || s->n_faces <= 0 || tile_w < 64 || tile_w % 64 != 0 || tile_h < 4 || tile_h % 4 != 0) return false;
+    const int64_t image = (int64_t)tile_w * tile_h;
+    return n > 0 && n % image == 0 && n / image <= 65535;
+}
+
 // cull -> trace -> shade1 -> trace -> shade2 -> trace(any) for one sub-batch; the caller appends the last stage.
+// `w` non-null and whole images (tile_w x tile_h) of a multiple-of-64 width: primary visibility by projection
+// (drt_raster.h), k_trace #1 then only sees the rays that are not grid rays (normally none).
 extern "C++" {
 template <bool FUSED>
-static void launch_chunk(drt_scene* s, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
-                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w) {
+static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
+                        int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h) {
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
+    RasterIn rz{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const int64_t image = (int64_t)tile_w * tile_h;
+    if (raster_on(s, n, tile_w, tile_h)) {
+        const int n_views = (int)(n / image);
+        int rc = ensure_raster(s, w, n, n_views, st);
+        if (rc) return rc;
+        StageTimer t(s, st, kStageRaster);
+        rc = launch_raster(s, w, st, o, d, n_views, tile_w, tile_h);
+        if (rc) return rc;
+        rz = RasterIn{w.vmodel, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h};
+    }
     { StageTimer t(s, st, kStageCull);
-      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w); }
+      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz); }
     { StageTimer t(s, st, kStageTrace1);
-      k_trace<false, false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
-      k_trace_redo<false, false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, TraceOut{p.r0.face, nullptr, nullptr, nullptr}); }
+      if (rz.views) {       // only the R0 slots listed by k_cull (rays that are not grid rays)
+          const TraceOut out{p.r0.face, nullptr, nullptr, w.gen_list};
+          k_trace<false, 2><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 3, out, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
+          k_trace_redo<false, 2><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, out);
+      } else {
+          k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
+          k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, TraceOut{p.r0.face, nullptr, nullptr, nullptr});
+      } }
     { StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace2);
-      k_trace<false, false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
-      k_trace_redo<false, false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, TraceOut{p.r1.face, nullptr, nullptr, nullptr}); }
+      k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
+      k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, TraceOut{p.r1.face, nullptr, nullptr, nullptr}); }
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);
-      k_trace<true, false><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
-      k_trace_redo<true, false><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, TraceOut{p.r2.face, nullptr, nullptr, nullptr}); }
+      k_trace<true, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
+      k_trace_redo<true, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, TraceOut{p.r2.face, nullptr, nullptr, nullptr}); }
+    return DRT_OK;
 }
 }  // extern "C++"
 
@@ -604,7 +680,7 @@ static PathCtx sub_ctx(const drt_scene* s, const drt_scene::Sub& w, const double
 }
 int pipeline_blocks_per_cu() {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, 0>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu;
 }
 
@@ -612,7 +688,7 @@ extern "C" {
 
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
-                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, void* stream) {
+                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -622,7 +698,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     }
     if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
-    const Plan pl = plan_call(s, n_rays, tile_w);
+    const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, false); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
     int rc = fork_streams(s, st, pl.streams);
@@ -634,11 +710,12 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
         HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
-        launch_chunk<false>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                            d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w);
+        rc = launch_chunk<false>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
+                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h);
+        if (rc) return rc;
         { StageTimer t(s, w.stream, kStageFinish);
           k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
-        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 0);
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 0, raster_on(s, n, tile_w, tile_h));
     }
     rc = join_streams(s, st, pl.streams);
     if (rc) return rc;
@@ -706,13 +783,13 @@ int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list
 
 int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir,
                               const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays, double ior_int,
-                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, int tile_w, void* stream) {
+                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, int tile_w, int tile_h, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    const Plan pl = plan_call(s, n_rays, tile_w);
+    const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true); if (rc) return rc; }
     int rc = fork_streams(s, st, pl.streams);
     if (rc) return rc;
@@ -723,11 +800,12 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
         HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
-        launch_chunk<true>(s, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w);
+        rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h);
+        if (rc) return rc;
         { StageTimer t(s, w.stream, kStageLossBwdFused);
           k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
                                                                d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
-        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1);
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1, raster_on(s, n, tile_w, tile_h));
     }
     rc = join_streams(s, st, pl.streams);
     if (rc) return rc;

@@ -1,0 +1,103 @@
+// drt_raster.h -- primary visibility of pinhole ray grids by projection instead of BVH traversal.
+//
+// The first traversal of Scene.render_transparent (reference DiffRender.py:537-540: `Dintersect` of the camera rays)
+// answers, for every pixel of a view, "closest triangle along this ray".  When the rays of an image ARE a pinhole grid
+// -- generate_ray, reference captured_data.py:23-40: origin = R^-1[:3,3] for every pixel, direction ~ M (x, y, 1)^T with
+// M = R^-1[:3,:3] K^-1 -- the set of pixels whose ray can hit a triangle is the projection of that triangle, so each
+// triangle is tested only against the handful of pixels of its projected bounding box, with the SAME float32
+// ray/triangle test (drt_tri.h) on the SAME float32 ray the traversal would use, and the closest hit per pixel is kept
+// by a 64-bit atomic minimum of (t bits, face id) -- i.e. the contract of oracle/tracer.c (minimum t, ties -> lowest
+// face id) without walking a tree: ~3 tests per (view, triangle) instead of ~14 node visits per candidate ray.
+//
+// Nothing is assumed about the caller's rays: the model (origin, M^-1) of every image is FITTED on the device from four
+// of its rays, every single ray is then VERIFIED against it in k_cull (origin bit-equal, pixel position within
+// kRasterVerifyTol), and a ray that does not verify -- calibrated per-pixel rays of a real capture, arbitrary ray
+// lists -- takes the BVH path as before.  Conservative by construction: the box is grown by kRasterPad pixels, two
+// orders above what the float32 test's rounding, the float32 cast of the ray and the verification tolerance add up to
+// (the BVH's own leaf padding, 2^-13 of the scene extent, is ~0.06 px in the benchmark geometry).
+#pragma once
+#include "drt_common.h"
+
+namespace drt {
+
+struct ViewModel {
+    double o[3];        // common origin of the image's rays
+    double minv[9];     // (x, y, 1) ~ minv * direction, row-major
+    int32_t ok;         // 1: pinhole grid; 0: take the BVH path for every ray of this image
+    int32_t pad;
+};
+
+constexpr double kRasterPad = 0.25;          // pixels added on every side of a projected triangle's bounding box
+constexpr double kRasterVerifyTol = 1e-3;    // a ray belongs to the grid if its direction projects within this of its pixel
+constexpr int kRasterMaxPerLane = 48;        // larger boxes are handed to k_raster_big (one block per triangle)
+
+// Solve the model from the rays of the four image corners (unit or not, only their directions matter):
+// d(x, y) ~ x m0 + y m1 + m2.  Returns false when the corner directions are degenerate.
+DRT_HD bool fit_view_model(d3 o, d3 d00, d3 dW0, d3 d0H, d3 dWH, double wm1, double hm1, ViewModel& vm) {
+    // beta dW0 + gamma d0H - eps dWH = d00   (from (W-1) m0 = beta dW0 - d00, (H-1) m1 = gamma d0H - d00, m2 = d00)
+    const d3 c0 = dW0, c1 = d0H, c2 = -dWH;
+    const double det = dot(c0, cross(c1, c2));
+    vm.ok = 0; vm.pad = 0;
+    vm.o[0] = o.x; vm.o[1] = o.y; vm.o[2] = o.z;
+    for (int k = 0; k < 9; ++k) vm.minv[k] = 0.0;
+    if (!(fabs(det) > 1e-300) || !(wm1 > 0.0) || !(hm1 > 0.0)) return false;
+    const double beta = dot(d00, cross(c1, c2)) / det, gamma = dot(c0, cross(d00, c2)) / det;
+    const d3 m0 = (beta * dW0 - d00) / wm1, m1 = (gamma * d0H - d00) / hm1, m2 = d00;
+    // inverse of M = [m0 m1 m2] (columns): rows of M^-1 are cross products / det(M)
+    const double dm = dot(m0, cross(m1, m2));
+    if (!(fabs(dm) > 1e-300)) return false;
+    const d3 r0 = cross(m1, m2) / dm, r1 = cross(m2, m0) / dm, r2 = cross(m0, m1) / dm;
+    vm.minv[0] = r0.x; vm.minv[1] = r0.y; vm.minv[2] = r0.z;
+    vm.minv[3] = r1.x; vm.minv[4] = r1.y; vm.minv[5] = r1.z;
+    vm.minv[6] = r2.x; vm.minv[7] = r2.y; vm.minv[8] = r2.z;
+    bool fin = true;
+    for (int k = 0; k < 9; ++k) fin = fin && (fabs(vm.minv[k]) < 1e300);
+    return fin;
+}
+
+// (px, py, pz) = minv * v: the pixel position is (px / pz, py / pz), pz > 0 in front of the camera.
+DRT_HD d3 view_project(const ViewModel& vm, d3 v) {
+    return d3{(vm.minv[0] * v.x + vm.minv[1] * v.y) + vm.minv[2] * v.z,
+              (vm.minv[3] * v.x + vm.minv[4] * v.y) + vm.minv[5] * v.z,
+              (vm.minv[6] * v.x + vm.minv[7] * v.y) + vm.minv[8] * v.z};
+}
+
+// Is (o, d) the ray of pixel (x, y) of this image?
+DRT_HD bool view_verify(const ViewModel& vm, d3 o, d3 d, double x, double y) {
+    if (!(o.x == vm.o[0] && o.y == vm.o[1] && o.z == vm.o[2])) return false;
+    const d3 p = view_project(vm, d);
+    if (!(p.z > 0.0)) return false;
+    return fabs(p.x - x * p.z) <= kRasterVerifyTol * p.z && fabs(p.y - y * p.z) <= kRasterVerifyTol * p.z;
+}
+
+struct PixelBox {
+    int x0, x1, y0, y1;     // inclusive; empty when x0 > x1 or y0 > y1
+    bool unsafe;            // a vertex at or behind the camera plane (or a non-finite projection): no projection bound
+};
+
+// Padded pixel bounding box of the triangle (a, a + e1, a + e2) given relative to the ray origin.
+DRT_HD PixelBox project_tri_box(const ViewModel& vm, d3 a, d3 b, d3 c, int w, int h) {
+    PixelBox r{0, -1, 0, -1, false};
+    const d3 pa = view_project(vm, a), pb = view_project(vm, b), pc = view_project(vm, c);
+    const double zmin = fmin(pa.z, fmin(pb.z, pc.z));
+    if (!(zmin > 1e-30)) { r.unsafe = true; return r; }
+    const double ax = pa.x / pa.z, ay = pa.y / pa.z, bx = pb.x / pb.z, by = pb.y / pb.z, cx = pc.x / pc.z, cy = pc.y / pc.z;
+    const double lox = fmin(ax, fmin(bx, cx)) - kRasterPad, hix = fmax(ax, fmax(bx, cx)) + kRasterPad;
+    const double loy = fmin(ay, fmin(by, cy)) - kRasterPad, hiy = fmax(ay, fmax(by, cy)) + kRasterPad;
+    if (!(fabs(lox) < 1e15 && fabs(hix) < 1e15 && fabs(loy) < 1e15 && fabs(hiy) < 1e15)) { r.unsafe = true; return r; }
+    const double fx0 = fmax(ceil(lox), 0.0), fx1 = fmin(floor(hix), (double)(w - 1));
+    const double fy0 = fmax(ceil(loy), 0.0), fy1 = fmin(floor(hiy), (double)(h - 1));
+    if (fx0 > fx1 || fy0 > fy1) return r;
+    r.x0 = (int)fx0; r.x1 = (int)fx1; r.y0 = (int)fy0; r.y1 = (int)fy1;
+    return r;
+}
+
+// 64-bit key of a hit: t > 0, so its bit pattern orders like an unsigned integer; equal t -> lowest face id wins.
+DRT_HD unsigned long long raster_key(float t, int32_t face) {
+    uint32_t tb;
+    memcpy(&tb, &t, 4);
+    return ((unsigned long long)tb << 32) | (unsigned long long)(uint32_t)face;
+}
+constexpr unsigned long long kRasterEmpty = ~0ull;
+
+}  // namespace drt

@@ -1,0 +1,144 @@
+// drt_raster.hip -- kernels of the projected primary-visibility pass (drt_raster.h) and their launcher.
+#include "drt_device.h"
+
+// One block per image: lane 0 fits the pinhole model from the four corner rays, then 64 lanes check an 8x8 lattice of
+// the image's rays against it; an image that is not a pinhole grid keeps ok = 0 and takes the BVH path entirely
+// (k_raster skips it; k_cull verifies every ray once more anyway).
+__global__ void __launch_bounds__(64) k_fit_views(const double* __restrict__ origin, const double* __restrict__ dir, int w, int h,
+                                                  ViewModel* __restrict__ views) {
+    __shared__ ViewModel vm;
+    const int64_t base = (int64_t)blockIdx.x * w * h;
+    if (threadIdx.x == 0) {
+        const int64_t i00 = base, iW0 = base + (w - 1), i0H = base + (int64_t)(h - 1) * w, iWH = i0H + (w - 1);
+        if (fit_view_model(load_d3(origin, i00), load_d3(dir, i00), load_d3(dir, iW0), load_d3(dir, i0H), load_d3(dir, iWH),
+                           (double)(w - 1), (double)(h - 1), vm))
+            vm.ok = 1;
+    }
+    __syncthreads();
+    bool good = vm.ok != 0;
+    if (good) {
+        const int sx = (int)(threadIdx.x & 7), sy = (int)(threadIdx.x >> 3);
+        const int x = (int)(((int64_t)(w - 1) * sx) / 7), y = (int)(((int64_t)(h - 1) * sy) / 7);
+        const int64_t i = base + (int64_t)y * w + x;
+        good = view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)y);
+    }
+    const bool all_good = __ballot(good) == ~0ull;
+    if (threadIdx.x == 0) {
+        vm.ok = all_good ? 1 : 0;
+        views[blockIdx.x] = vm;
+    }
+}
+
+// Test one (triangle, pixel) pair and fold a hit into the pixel's key.  The plain read of the current key may be stale
+// (the L1 is not coherent with the atomics at L2) but keys only ever decrease, so a stale value is >= the true one:
+// skipping when the new key is not smaller than what was read can never drop a winner.
+__device__ __forceinline__ void raster_test(const TriRec& t, f3 o32, const double* __restrict__ dir, int64_t i,
+                                            unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask) {
+    const f3 d32 = to_f32(load_d3(dir, i));
+    float tt;
+    if (!tri_hit(o32, d32, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) return;
+    const unsigned long long key = raster_key(tt, t.face);
+    if (key >= zbuf[i]) return;
+    atomicMin(&zbuf[i], key);
+    atomicOr(&zmask[i >> 11], 1u << ((i >> 6) & 31));      // one bit per 64 consecutive rays: k_cull reads keys only there
+}
+
+struct BigItem { int32_t view, tri, x0, y0, nx, ny; };
+
+// grid (ceil(F / 256), n_views): one thread per (image, triangle in Morton order).
+__global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris, int n_tris, ViewModel* views,
+                                                const double* __restrict__ dir, int w, int h,
+                                                unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask,
+                                                BigItem* __restrict__ big, unsigned* big_count, unsigned big_cap) {
+    const int view = blockIdx.y;
+    const ViewModel vm = views[view];
+    if (!vm.ok) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_tris) return;
+    const TriRec t = tris[k];
+    const d3 o{vm.o[0], vm.o[1], vm.o[2]};
+    const f3 o32 = to_f32(o);
+    const d3 a = d3{(double)t.v0x, (double)t.v0y, (double)t.v0z} - o;
+    const d3 b = a + d3{(double)t.e1x, (double)t.e1y, (double)t.e1z}, c = a + d3{(double)t.e2x, (double)t.e2y, (double)t.e2z};
+    const PixelBox box = project_tri_box(vm, a, b, c, w, h);
+    if (box.unsafe) {              // the camera plane cuts (or touches) this triangle: no projection bound for this image
+        __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (box.x0 > box.x1 || box.y0 > box.y1) return;
+    const int nx = box.x1 - box.x0 + 1, ny = box.y1 - box.y0 + 1;
+    const int64_t base = (int64_t)view * w * h;
+    if ((int64_t)nx * ny > kRasterMaxPerLane) {
+        const unsigned slot = atomicAdd(big_count, 1u);
+        if (slot < big_cap) big[slot] = BigItem{view, k, box.x0, box.y0, nx, ny};
+        else __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // list full: BVH path for this image
+        return;
+    }
+    for (int y = box.y0; y <= box.y1; ++y)
+        for (int x = box.x0; x <= box.x1; ++x)
+            raster_test(t, o32, dir, base + (int64_t)y * w + x, zbuf, zmask);
+}
+
+// Triangles whose box holds more pixels than one lane should loop over: one block per list entry.
+__global__ void __launch_bounds__(256) k_raster_big(const TriRec* __restrict__ tris, const ViewModel* __restrict__ views,
+                                                    const double* __restrict__ dir, int w, int h,
+                                                    unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask,
+                                                    const BigItem* __restrict__ big, const unsigned* __restrict__ big_count, unsigned big_cap) {
+    const unsigned n = min(*big_count, big_cap);
+    for (unsigned e = blockIdx.x; e < n; e += gridDim.x) {
+        const BigItem it = big[e];
+        const ViewModel& vm = views[it.view];
+        const TriRec t = tris[it.tri];
+        const f3 o32 = to_f32(d3{vm.o[0], vm.o[1], vm.o[2]});
+        const int64_t base = (int64_t)it.view * w * h;
+        const int64_t cnt = (int64_t)it.nx * it.ny;
+        for (int64_t p = threadIdx.x; p < cnt; p += 256) {
+            const int y = it.y0 + (int)(p / it.nx), x = it.x0 + (int)(p % it.nx);
+            raster_test(t, o32, dir, base + (int64_t)y * w + x, zbuf, zmask);
+        }
+    }
+}
+
+__global__ void k_fill_u64(unsigned long long* __restrict__ p, int64_t n, unsigned long long v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// Workspace of the raster pass of one internal stream: keys [cap] (kept all-empty between calls: k_cull resets every
+// key it consumes), group bits, image models, the big-triangle list.
+int ensure_raster(drt_scene* s, drt_scene::Sub& w, int64_t n_rays, int n_views, hipStream_t st) {
+    if (n_rays > w.z_cap) {
+        (void)hipFree(w.zbuf); (void)hipFree(w.zmask);
+        w.zbuf = nullptr; w.zmask = nullptr; w.z_cap = 0;
+        const int64_t words = (n_rays + 2047) / 2048 + 1;
+        HIP_TRY(hipMalloc(&w.zbuf, sizeof(unsigned long long) * n_rays));
+        HIP_TRY(hipMalloc(&w.zmask, sizeof(uint32_t) * words));
+        k_fill_u64<<<4 * s->n_cu, 256, 0, st>>>(w.zbuf, n_rays, kRasterEmpty);
+        HIP_TRY(hipMemsetAsync(w.zmask, 0, sizeof(uint32_t) * words, st));
+        w.z_cap = n_rays;
+    }
+    if (n_views > w.vm_cap) {
+        (void)hipFree(w.vmodel); w.vmodel = nullptr; w.vm_cap = 0;
+        HIP_TRY(hipMalloc(&w.vmodel, sizeof(ViewModel) * n_views));
+        w.vm_cap = n_views;
+    }
+    if (!w.big) {
+        HIP_TRY(hipMalloc(&w.big, sizeof(BigItem) * drt_scene::kBigCap));
+        HIP_TRY(hipMalloc(&w.big_count, sizeof(unsigned)));
+    }
+    return DRT_OK;
+}
+
+// Fit the image models and rasterise every triangle into the key buffer of `w` (rays [0, n_views * w * h) of the sub-batch).
+int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih) {
+    const int n = (int)s->n_faces;
+    HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
+    k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
+    if (n > 0) {
+        k_raster<<<dim3((n + 255) / 256, n_views), 256, 0, st>>>(s->tris, n, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+                                                                  reinterpret_cast<BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
+        k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+                                                   reinterpret_cast<const BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
+    }
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}

@@ -20,6 +20,7 @@
 #include "drt_edge.h"
 #include "drt_lbvh.h"
 #include "drt_path.h"
+#include "drt_raster.h"
 #include "drt_shade.h"
 #include "drt_traverse.h"
 #include "drt_tri.h"
@@ -58,7 +59,7 @@ constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds th
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
 
 // stage ids of drt_profile_read
-enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kProfStages };
+enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kStageRaster, kProfStages };
 
 struct BuildParams {   // written by k_bounds, read by the later build kernels
     float lox, loy, loz;
@@ -102,7 +103,18 @@ struct drt_scene {
         int32_t* redo = nullptr;                             // [cap] rays for k_trace_redo
         int32_t* slow_stack = nullptr;                       // [kRedoGrid * kTraceBlock * kStackSlowDev] overflow area of this stream's k_trace_redo
         int64_t q_cap = 0, fused_cap = 0;
+        // projected primary visibility (drt_raster.h): per-ray keys (all-empty between calls), one bit per 64 rays that
+        // says "some key here was written", the fitted image models, triangles too large for one lane
+        unsigned long long* zbuf = nullptr;
+        uint32_t* zmask = nullptr;
+        int64_t z_cap = 0;
+        ViewModel* vmodel = nullptr;
+        int vm_cap = 0;
+        void* big = nullptr;
+        unsigned* big_count = nullptr;
+        int32_t* gen_list = nullptr;                         // [q_cap] R0 slots whose ray did not verify as a grid ray: traced like before
     };
+    static constexpr unsigned kBigCap = 1u << 20;
     static constexpr int kMaxSub = 4;
     Sub sub[kMaxSub];
     int n_sub = 2;                 // internal streams in use
@@ -130,6 +142,7 @@ struct drt_scene {
     int inner_min = 16;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
     int64_t chunk_rays = kChunkRays;
 
+    bool use_raster = true;        // DRT_RASTER=0: every primary ray takes the BVH path (A/B measurement)
     bool built = false;
 };
 
@@ -137,6 +150,10 @@ struct drt_scene {
 // occupancy of the persistent kernels (defined next to them: drt_trace.hip, drt_pipeline.hip)
 int query_blocks_per_cu();
 int pipeline_blocks_per_cu();
+
+// defined in drt_raster.hip
+int ensure_raster(drt_scene* s, drt_scene::Sub& w, int64_t n_rays, int n_views, hipStream_t st);
+int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih);
 
 // defined in drt_build.hip
 void scene_free_mesh(drt_scene* s);

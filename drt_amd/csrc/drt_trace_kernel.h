@@ -13,22 +13,25 @@ struct TraceOut {
     const int32_t* idx;     // B1: list slot -> ray number
 };
 
-template <bool ANY, bool B1>
+// MODE 0: pipeline list (face per list slot); 1: B1 (T / ID or hit flag per ray number); 2: pipeline, but only the R0
+// slots listed in `idx` (the rays the projected primary-visibility pass did not answer): face per R0 slot.
+template <bool ANY, int MODE>
 __device__ __forceinline__ void trace_emit(const TraceOut& out, int32_t slot, float best_t, int32_t best_face) {
-    if (!B1) { out.face[slot] = best_face; return; }
+    if (MODE == 0) { out.face[slot] = best_face; return; }
     const int32_t i = out.idx[slot];
+    if (MODE == 2) { out.face[i] = best_face; return; }
     if (ANY) { out.flag[i] = best_face >= 0 ? 1 : 0; return; }
     out.t[i] = best_face >= 0 ? best_t : -1.0f;
     out.face[i] = best_face;
 }
-template <bool B1>
+template <int MODE>
 __device__ __forceinline__ const float* trace_ray(const float* __restrict__ rays, const TraceOut& out, unsigned slot) {
-    return rays + 6 * (int64_t)(B1 ? out.idx[slot] : (int32_t)slot);
+    return rays + 6 * (int64_t)(MODE != 0 ? out.idx[slot] : (int32_t)slot);
 }
 
 // Persistent traversal over a ray list.  Each wave owns a contiguous segment of the list; a lane
 // whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
-template <bool ANY, bool B1>
+template <bool ANY, int MODE>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
                                                        TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count,
                                                        int refill_min, int inner_min, unsigned long long* stats) {
@@ -63,7 +66,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                 const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
                 const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
                 if (j < my_rays && k < n) {
-                    const float* e = trace_ray<B1>(rays, out, k);
+                    const float* e = trace_ray<MODE>(rays, out, k);
                     trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
                     st.overflow = false;
                     slot = (int32_t)k;
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                     redo_list[atomicAdd(redo_count, 1u)] = slot;
                     slot = -1;
                 } else if (done) {
-                    trace_emit<ANY, B1>(out, slot, s.best_t, s.best_face);
+                    trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
                     slot = -1;
                 }
             }
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             ++wave_steps;
             lane_steps += (unsigned long long)__popcll(ml);
             if (at_leaf && trav_leaf<ANY>(c.tris, s, st)) {
-                trace_emit<ANY, B1>(out, slot, s.best_t, s.best_face);
+                trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
                 slot = -1;
             }
         }
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
 
 // Second pass for the rays whose traversal overflowed the LDS-only stack of k_trace: one thread per
 // ray, spilling stack.  Normally the list is empty and the kernel returns at once.
-template <bool ANY, bool B1>
+template <bool ANY, int MODE>
 __global__ void __launch_bounds__(kTraceBlock) k_trace_redo(TraceCtx c, const float* __restrict__ rays, const int32_t* __restrict__ redo_list,
                                                              const unsigned* __restrict__ redo_count, TraceOut out) {
     __shared__ int32_t lds[kStackFast][kTraceBlock];
@@ -125,8 +128,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_redo(TraceCtx c, const fl
     Stack st = make_stack(lds, c);
     for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
         const int32_t slot = redo_list[k];
-        const float* e = trace_ray<B1>(rays, out, (unsigned)slot);
+        const float* e = trace_ray<MODE>(rays, out, (unsigned)slot);
         const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st);
-        trace_emit<ANY, B1>(out, slot, h.t, h.face);
+        trace_emit<ANY, MODE>(out, slot, h.t, h.face);
     }
 }

@@ -54,11 +54,13 @@ class Ray:
 
 
 def _tile_hint(n_rays):
-    """Image width for the pipeline's 16x4-pixel tile ray grouping when the ray list is whole images of the module's
-    resx x resy (as produced by generate_ray, reference captured_data.py:23-40); 0 = no assumption."""
+    """(image width, image height) for the pipeline when the ray list is whole images of the module's resx x resy (as
+    produced by generate_ray, reference captured_data.py:23-40; the module globals are what optim.py:180-181 sets):
+    16x4-pixel tile ray grouping and projected primary visibility.  A hint only -- the library checks every ray against
+    the grid it fits and falls back to the tree; (0, 0) = no assumption."""
     if resx >= 64 and resx % 64 == 0 and resy % 4 == 0 and n_rays % (resx * resy) == 0:
-        return int(resx)
-    return 0
+        return int(resx), int(resy)
+    return 0, 0
 
 
 def _flag_bytes(t, name, n):
@@ -101,7 +103,7 @@ class _RenderTransparent(torch.autograd.Function):
             _lib.check(_lib.lib().drt_render_forward(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
                 out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
-                _lib.ptr(valid_idx), _lib.ptr(n_valid), _tile_hint(n), _stream()))
+                _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), _stream()))
         ctx.scene = scene
         ctx.ior = (float(ior_int), float(ior_ext))
         ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)
@@ -191,7 +193,7 @@ class _RenderRayLossFused(torch.autograd.Function):
         with torch.cuda.device(o.device):
             _lib.check(_lib.lib().drt_render_ray_loss_fused(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), o.shape[0],
-                float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, _tile_hint(o.shape[0]), _stream()))
+                float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, *_tile_hint(o.shape[0]), _stream()))
         ctx.save_for_backward(grad_v)
         return loss
 

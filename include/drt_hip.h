@@ -81,14 +81,17 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
  *      a primary miss.  Optional (both or neither): d_valid_idx int32 [N] receives the indices of
  *      the rays with mask = 1 (unordered), *d_n_valid (int64, device) their number -- handing
  *      them to drt_render_backward spares it a pass over the dense arrays.
- *      tile_w: 0, or the width in pixels of the image(s) whose rows the rays are (multiple of 64, whole
- *      images of a multiple-of-4 height concatenated): a pure ordering hint that lets the pipeline
- *      group rays by 16x4-pixel screen tiles; results do not depend on it. */
+ *      tile_w, tile_h: 0, or the width / height in pixels of the image(s) whose rows the rays are (width a multiple
+ *      of 64, height a multiple of 4, whole images concatenated): a HINT that lets the pipeline group rays by
+ *      16x4-pixel screen tiles and, when every image verifies as a pinhole ray grid (generate_ray, reference
+ *      captured_data.py:23-40), decide the primary hits by projecting the triangles instead of traversing the
+ *      tree (csrc/drt_raster.h).  Every ray is checked against the fitted grid on the device and takes the
+ *      tree otherwise: results do not depend on the hint. */
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                        double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
                        int32_t* d_face1, int32_t* d_face2,
-                       int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, void* stream);
+                       int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h, void* stream);
 /* Adjoint of drt_render_forward w.r.t. the vertices: d_grad_verts float64 [V,3] += ...
  * (atomic accumulation; zero it first).  Either incoming gradient may be NULL (= zeros). */
 int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin,
@@ -121,7 +124,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
                               const double* d_dir, const double* d_screen_pixel,
                               const uint8_t* d_valid, int64_t n_rays, double ior_int,
                               double ior_ext, double* d_loss, double* d_grad_verts,
-                              int64_t* d_n_valid, int tile_w, void* stream);
+                              int64_t* d_n_valid, int tile_w, int tile_h, void* stream);
 
 /* ---- smoothness branch: Scene.dihedral_angle (DiffRender.py:440-443, edge_face_norm :149-163)
  * and Loss_calculator.sm_loss (optim.py:82-89) ---------------------------------------------------
@@ -209,10 +212,10 @@ void drt_mesh_buf_free(drt_mesh_buf_t* b);
  * items (rays in the stage's input queue) since the previous read.  Arrays have DRT_PROFILE_STAGES
  * entries: 0 build, 1 cull, 2 trace1, 3 shade1, 4 trace2, 5 shade2, 6 trace3 (occlusion),
  * 7 finish, 8 collect (backward compaction when no list was saved), 9 backward,
- * 10 fused loss+backward.  The event pool grows with the number of launches between two reads; if it could not
+ * 10 fused loss+backward, 11 projected primary visibility (fit + raster kernels).  The event pool grows with the number of launches between two reads; if it could not
  * (allocation failure), drt_profile_read FAILS (DRT_E_INVALID, message with the number of lost timings) instead
  * of returning under-reported stage times. */
-#define DRT_PROFILE_STAGES 11
+#define DRT_PROFILE_STAGES 12
 int drt_profile_enable(drt_scene_t* s, int on);
 int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out);
 /* Traversal diagnostics of the last drt_profile_read interval, 4 values for each of the three

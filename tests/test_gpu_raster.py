@@ -1,0 +1,153 @@
+"""Projected primary visibility (drt_amd/csrc/drt_raster.h): the primary face ids of render_transparent must equal the
+exhaustive float32 test (the tracer contract, oracle/tracer.c) whether the rays are a pinhole grid (decided by projecting
+the triangles), a perturbed grid (every ray falls back to the tree), a mix, a camera inside the object (no projection
+bound: whole image falls back) or a low-polygon close-up (triangles that cover thousands of pixels)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import IOR, data_path
+from drt_amd import mesh_io, views
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Render():
+    from drt_amd import diffrender
+    diffrender.intIOR = IOR
+    return diffrender
+
+
+def _primary_reference(scene, o, d):
+    rays = torch.cat([o.float(), d.float()], 1).contiguous()
+    T, ID = scene.optix_mesh.intersect_bruteforce(rays)
+    return ID
+
+
+def _check(Render, scene, o, d, res_x, res_y, expect_stage_items=None):
+    Render.resx, Render.resy = res_x, res_y
+    tr = scene.optix_mesh
+    tr.profile_enable(1)
+    tr.profile_read()
+    with torch.no_grad():
+        oo, od, mk = scene.render_transparent(o, d)
+    prof = tr.profile_read()
+    tr.profile_enable(0)
+    f1 = scene.last_face1.clone()
+    assert torch.equal(f1, _primary_reference(scene, o, d))
+    # and the whole path equals the run without the hint (linear order, tree for every ray)
+    Render.resx, Render.resy = 7, 7
+    with torch.no_grad():
+        oo2, od2, mk2 = scene.render_transparent(o, d)
+    assert torch.equal(oo, oo2) and torch.equal(od, od2) and torch.equal(mk, mk2)
+    assert torch.equal(scene.last_face1, f1)
+    return prof, f1
+
+
+def test_grid_rays_are_decided_by_projection_and_equal_bruteforce(Render):
+    mesh = mesh_io.subdivide_midpoint(mesh_io.read_ply(data_path("horse_vh.ply")))
+    scene = Render.Scene(mesh, 0)
+    c, ext = views.mesh_frame(mesh.vertices)
+    res = 512
+    cams = views.turntable_cameras(c, ext, 72, res, res)
+    rays = [views.generate_ray(res, res, cams[k][3], cams[k][2], device="cuda") for k in (0, 13, 29, 50)]
+    o = torch.cat([r[0] for r in rays]).contiguous(); d = torch.cat([r[1] for r in rays]).contiguous()
+    prof, f1 = _check(Render, scene, o, d, res, res)
+    assert prof["raster"][1] >= 1 and prof["raster"][2] == len(o)      # the projection pass ran over all four images
+    assert prof["trace1"][2] == 0                                       # and no ray needed the tree
+    assert 0.01 < (f1 >= 0).float().mean().item() < 0.6
+    # a non-square image (the captures are 960x1280 and 1080x1920) and 144 rows of padding-free rectangles
+    cams = views.turntable_cameras(c, ext, 72, 320, 192)
+    o2, d2 = views.generate_ray(192, 320, cams[7][3], cams[7][2], device="cuda")
+    prof, _ = _check(Render, scene, o2, d2, 320, 192)
+    assert prof["raster"][2] == len(o2) and prof["trace1"][2] == 0
+
+
+def test_rays_outside_the_grid_fall_back_to_the_tree(Render):
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(mesh, 0)
+    c, ext = views.mesh_frame(mesh.vertices)
+    res = 256
+    cam = views.turntable_cameras(c, ext, 72, res, res)[31]
+    o, d = views.generate_ray(res, res, cam[3], cam[2], device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    # (a) a calibrated-camera-like perturbation of every direction (2 pixels of smooth distortion): the four corner rays
+    #     still fit a model, the lattice check refuses it, every ray takes the tree
+    yy, xx = torch.meshgrid(torch.arange(res, device="cuda", dtype=torch.float64), torch.arange(res, device="cuda", dtype=torch.float64), indexing="ij")
+    r2 = ((xx - res / 2) ** 2 + (yy - res / 2) ** 2).reshape(-1, 1) / (res * res)
+    d_dist = d + 0.01 * r2 * (1 - 4 * r2) * torch.linalg.cross(d, torch.tensor([[0.0, 1.0, 0.0]], device="cuda", dtype=torch.float64).expand_as(d))
+    d_dist = d_dist / d_dist.norm(dim=1, keepdim=True)
+    prof, f1 = _check(Render, scene, o, d_dist.contiguous(), res, res)
+    assert prof["trace1"][2] > 0 and (f1 >= 0).any()
+    # (b) a grid in which a sprinkling of rays is replaced (other origin / other direction): those rays, and only
+    #     those, take the tree
+    o_mix, d_mix = o.clone(), d.clone()
+    pick = torch.rand(len(o), device="cuda", generator=g) < 0.03
+    d_mix[pick] = d[torch.randperm(len(o), device="cuda", generator=g)][pick]
+    pick2 = torch.rand(len(o), device="cuda", generator=g) < 0.01
+    o_mix[pick2] = o_mix[pick2] + 3.0
+    prof, f1 = _check(Render, scene, o_mix, d_mix, res, res)
+    assert 0 < prof["trace1"][2] < 0.08 * len(o)
+    # (c) rays that are no image at all (random order): the model of the "image" does not fit
+    perm = torch.randperm(len(o), device="cuda", generator=g)
+    prof, _ = _check(Render, scene, o[perm].contiguous(), d[perm].contiguous(), res, res)
+    assert prof["trace1"][2] > 0
+    # (d) a wrong hint (width x height swapped on a non-square image) is harmless
+    cam = views.turntable_cameras(c, ext, 72, 128, 64)[5]
+    o3, d3 = views.generate_ray(64, 128, cam[3], cam[2], device="cuda")
+    _check(Render, scene, o3, d3, 64, 128)
+
+
+def test_camera_inside_the_object_and_huge_triangles(Render):
+    # camera inside a coarse sphere: triangles behind / through the camera plane have no projection bound
+    sphere = mesh_io.icosphere(1, radius=50.0)
+    scene = Render.Scene(sphere, 0)
+    res = 128
+    K = np.array([[0.6 * res, 0, res / 2], [0, 0.6 * res, res / 2], [0, 0, 1.0]])
+    Rinv = np.eye(4); Rinv[:3, 3] = [3.0, -2.0, 5.0]
+    o, d = views.generate_ray(res, res, np.linalg.inv(K), Rinv, device="cuda")
+    prof, f1 = _check(Render, scene, o, d, res, res)
+    assert (f1 >= 0).all() and prof["trace1"][2] > 0                   # every ray hits from inside; all took the tree
+    # low-polygon close-up from outside: 80 triangles, each covering thousands of pixels (the one-block-per-triangle kernel)
+    c, ext = views.mesh_frame(sphere.vertices)
+    cam = views.turntable_cameras(c, ext, 72, 256, 256, distance_factor=1.2)[3]
+    o, d = views.generate_ray(256, 256, cam[3], cam[2], device="cuda")
+    prof, f1 = _check(Render, scene, o, d, 256, 256)
+    assert prof["trace1"][2] == 0 and (f1 >= 0).float().mean().item() > 0.3
+    # a mesh of two triangles, one of them degenerate, and an empty mesh
+    flat = mesh_io.TriMesh(np.array([[-30.0, -30, 0], [30, -30, 0], [0, 40, 0]]), np.array([[0, 1, 2], [0, 0, 0]]))
+    from drt_amd.optix_mesh import optix_mesh
+    t = optix_mesh(0)
+    t.update_mesh(torch.tensor(flat.faces, dtype=torch.int32, device="cuda"), torch.tensor(flat.vertices, dtype=torch.float32, device="cuda"))
+    T, ID = t.intersect(torch.cat([o.float(), d.float()], 1))
+    assert torch.equal(ID, t.intersect_bruteforce(torch.cat([o.float(), d.float()], 1))[1])
+
+
+def test_key_buffer_is_clean_after_every_call(Render):
+    """The per-ray key buffer is reset by the kernel that consumes it: alternating meshes and views on one scene must
+    never see a stale key of an earlier call."""
+    hand = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(hand, 0)
+    c, ext = views.mesh_frame(hand.vertices)
+    res = 256
+    cams = views.turntable_cameras(c, ext, 72, res, res)
+    V0 = scene.vertices.detach().clone()
+    for it in range(6):
+        scene.update_verticex(V0 * (1.0 + 0.07 * (it % 3)) + (it % 2) * 9.0)
+        o, d = views.generate_ray(res, res, cams[11 * it][3], cams[11 * it][2], device="cuda")
+        Render.resx = Render.resy = res
+        with torch.no_grad():
+            if it % 2:
+                sp = torch.randn(o.shape, dtype=torch.float64, device="cuda")
+                valid = torch.rand(len(o), device="cuda") < 0.5
+                scene.ray_loss_fused(o, d, sp, valid)               # the fused pass consumes the keys of untargeted pixels too
+            else:
+                scene.render_transparent(o, d)
+                assert torch.equal(scene.last_face1, _primary_reference(scene, o, d))
+    scene.update_verticex(V0)
+    o, d = views.generate_ray(res, res, cams[40][3], cams[40][2], device="cuda")
+    Render.resx = Render.resy = res
+    with torch.no_grad():
+        scene.render_transparent(o, d)
+    assert torch.equal(scene.last_face1, _primary_reference(scene, o, d))
