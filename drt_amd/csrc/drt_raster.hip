@@ -40,43 +40,105 @@ __device__ __forceinline__ void raster_test(const TriRec& t, f3 o32, const doubl
     const unsigned long long key = raster_key(tt, t.face);
     if (key >= zbuf[i]) return;
     atomicMin(&zbuf[i], key);
-    atomicOr(&zmask[i >> 11], 1u << ((i >> 6) & 31));      // one bit per 64 consecutive rays: k_cull reads keys only there
+    // one bit per 64 consecutive rays: k_cull reads keys only there.  Thousands of hits share a word, and atomics on ONE
+    // address are served one at a time: set the bit only when a (possibly stale) read does not show it yet
+    const uint32_t bit = 1u << ((i >> 6) & 31);
+    if (!(zmask[i >> 11] & bit)) atomicOr(&zmask[i >> 11], bit);
 }
 
 struct BigItem { int32_t view, tri, x0, y0, nx, ny; };
 
-// grid (ceil(F / 256), n_views): one thread per (image, triangle in Morton order).
+// grid (ceil(F / 256), n_views): one thread per (image, triangle in Morton order) projects its triangle (float32 is
+// ample: the box is padded by a quarter of a pixel) and counts the pixel centres inside the padded box -- 0 for most
+// sub-pixel triangles, a handful typically, dozens for a few.  The (triangle, pixel) tests of a wave are then dealt to its
+// lanes 64 at a time (wave prefix sum of the counts, owner found by bisection in LDS), so that one fat triangle does not
+// hold 63 idle lanes.
+struct RasterLane {            // what a lane publishes for the wave: its triangle and its box
+    TriRec tri;
+    int32_t x0, y0, nx, end;   // `end` = inclusive prefix sum of the counts (first work item NOT of this lane)
+};
+
 __global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris, int n_tris, ViewModel* views,
                                                 const double* __restrict__ dir, int w, int h,
                                                 unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask,
                                                 BigItem* __restrict__ big, unsigned* big_count, unsigned big_cap) {
+    __shared__ RasterLane s_lane[256];
     const int view = blockIdx.y;
     const ViewModel vm = views[view];
-    if (!vm.ok) return;
+    if (!vm.ok) return;                                   // block-uniform
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_tris) return;
-    const TriRec t = tris[k];
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
     const d3 o{vm.o[0], vm.o[1], vm.o[2]};
     const f3 o32 = to_f32(o);
-    const d3 a = d3{(double)t.v0x, (double)t.v0y, (double)t.v0z} - o;
-    const d3 b = a + d3{(double)t.e1x, (double)t.e1y, (double)t.e1z}, c = a + d3{(double)t.e2x, (double)t.e2y, (double)t.e2z};
-    const PixelBox box = project_tri_box(vm, a, b, c, w, h);
-    if (box.unsafe) {              // the camera plane cuts (or touches) this triangle: no projection bound for this image
-        __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+    int count = 0;
+    RasterLane me;
+    me.x0 = me.y0 = 0; me.nx = 1;
+    if (k < n_tris) {
+        me.tri = tris[k];
+        const TriRec& t = me.tri;
+        // relative to the origin, in float32 (|error| ~1e-4 px at these magnitudes, the pad is 0.25 px)
+        const f3 a{t.v0x - o32.x, t.v0y - o32.y, t.v0z - o32.z};
+        const f3 b{a.x + t.e1x, a.y + t.e1y, a.z + t.e1z}, c{a.x + t.e2x, a.y + t.e2y, a.z + t.e2z};
+        const float m0 = (float)vm.minv[0], m1 = (float)vm.minv[1], m2 = (float)vm.minv[2], m3 = (float)vm.minv[3], m4 = (float)vm.minv[4],
+                    m5 = (float)vm.minv[5], m6 = (float)vm.minv[6], m7 = (float)vm.minv[7], m8 = (float)vm.minv[8];
+        const float az = fmaf(m6, a.x, fmaf(m7, a.y, m8 * a.z)), bz = fmaf(m6, b.x, fmaf(m7, b.y, m8 * b.z)), cz = fmaf(m6, c.x, fmaf(m7, c.y, m8 * c.z));
+        const float zmin = fminf(az, fminf(bz, cz));
+        if (!(zmin > 1e-20f)) {        // the camera plane cuts (or touches) this triangle: no projection bound for this image
+            __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const float ra = 1.0f / az, rb = 1.0f / bz, rc = 1.0f / cz;
+            const float ax = fmaf(m0, a.x, fmaf(m1, a.y, m2 * a.z)) * ra, ay = fmaf(m3, a.x, fmaf(m4, a.y, m5 * a.z)) * ra;
+            const float bx = fmaf(m0, b.x, fmaf(m1, b.y, m2 * b.z)) * rb, by = fmaf(m3, b.x, fmaf(m4, b.y, m5 * b.z)) * rb;
+            const float cx = fmaf(m0, c.x, fmaf(m1, c.y, m2 * c.z)) * rc, cy = fmaf(m3, c.x, fmaf(m4, c.y, m5 * c.z)) * rc;
+            const float pad = (float)kRasterPad;
+            const float lox = fminf(ax, fminf(bx, cx)) - pad, hix = fmaxf(ax, fmaxf(bx, cx)) + pad;
+            const float loy = fminf(ay, fminf(by, cy)) - pad, hiy = fmaxf(ay, fmaxf(by, cy)) + pad;
+            if (!(fabsf(lox) < 1e9f && fabsf(hix) < 1e9f && fabsf(loy) < 1e9f && fabsf(hiy) < 1e9f)) {
+                __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const float fx0 = fmaxf(ceilf(lox), 0.0f), fx1 = fminf(floorf(hix), (float)(w - 1));
+                const float fy0 = fmaxf(ceilf(loy), 0.0f), fy1 = fminf(floorf(hiy), (float)(h - 1));
+                if (fx0 <= fx1 && fy0 <= fy1) {
+                    me.x0 = (int)fx0; me.y0 = (int)fy0; me.nx = (int)fx1 - me.x0 + 1;
+                    const int ny = (int)fy1 - me.y0 + 1;
+                    const int64_t cnt = (int64_t)me.nx * ny;
+                    if (cnt > kRasterMaxPerLane) {
+                        const unsigned slot = atomicAdd(big_count, 1u);
+                        if (slot < big_cap) big[slot] = BigItem{view, k, me.x0, me.y0, me.nx, ny};
+                        else __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // list full: BVH path for this image
+                    } else {
+                        count = (int)cnt;
+                    }
+                }
+            }
+        }
     }
-    if (box.x0 > box.x1 || box.y0 > box.y1) return;
-    const int nx = box.x1 - box.x0 + 1, ny = box.y1 - box.y0 + 1;
+    // inclusive prefix sum of the counts over the wave
+    int end = count;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(end, off);
+        if (lane >= off) end += v;
+    }
+    const int total = __shfl(end, 63);
+    if (total == 0) return;                                // wave-uniform: most waves of a view see nothing but background
+    me.end = end;
+    s_lane[threadIdx.x] = me;                              // read back by the lanes of this wave only: no block barrier needed
+    __builtin_amdgcn_wave_barrier();
     const int64_t base = (int64_t)view * w * h;
-    if ((int64_t)nx * ny > kRasterMaxPerLane) {
-        const unsigned slot = atomicAdd(big_count, 1u);
-        if (slot < big_cap) big[slot] = BigItem{view, k, box.x0, box.y0, nx, ny};
-        else __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // list full: BVH path for this image
-        return;
+    for (int item0 = 0; item0 < total; item0 += 64) {
+        const int item = item0 + lane;
+        if (item >= total) break;
+        int lo = 0, hi = 63;                               // first lane whose `end` exceeds item
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_lane[wbase + mid].end > item) hi = mid; else lo = mid + 1;
+        }
+        const RasterLane& ow = s_lane[wbase + lo];
+        const int local = item - (lo == 0 ? 0 : s_lane[wbase + lo - 1].end);
+        const int row = (int)(((float)local + 0.5f) / (float)ow.nx);     // exact for these small integers
+        const int x = ow.x0 + (local - row * ow.nx), y = ow.y0 + row;
+        raster_test(ow.tri, o32, dir, base + (int64_t)y * w + x, zbuf, zmask);
     }
-    for (int y = box.y0; y <= box.y1; ++y)
-        for (int x = box.x0; x <= box.x1; ++x)
-            raster_test(t, o32, dir, base + (int64_t)y * w + x, zbuf, zmask);
 }
 
 // Triangles whose box holds more pixels than one lane should loop over: one block per list entry.

@@ -83,12 +83,20 @@ def test_rays_outside_the_grid_fall_back_to_the_tree(Render):
     # (b) a grid in which a sprinkling of rays is replaced (other origin / other direction): those rays, and only
     #     those, take the tree
     o_mix, d_mix = o.clone(), d.clone()
-    pick = torch.rand(len(o), device="cuda", generator=g) < 0.03
+    lattice = torch.zeros(res, res, dtype=torch.bool, device="cuda")      # the 8x8 sample rays of the model check stay grid rays
+    ls = ((res - 1) * torch.arange(8, device="cuda")) // 7
+    lattice[ls[:, None], ls[None, :]] = True
+    free = ~lattice.reshape(-1)
+    pick = (torch.rand(len(o), device="cuda", generator=g) < 0.03) & free
     d_mix[pick] = d[torch.randperm(len(o), device="cuda", generator=g)][pick]
-    pick2 = torch.rand(len(o), device="cuda", generator=g) < 0.01
+    pick2 = (torch.rand(len(o), device="cuda", generator=g) < 0.01) & free
     o_mix[pick2] = o_mix[pick2] + 3.0
     prof, f1 = _check(Render, scene, o_mix, d_mix, res, res)
-    assert 0 < prof["trace1"][2] < 0.08 * len(o)
+    assert 0 < prof["trace1"][2] <= int((pick | pick2).sum())
+    # ... and when one of the sampled rays is off, the whole image takes the tree
+    d_mix[0] = d[777]
+    prof, f1 = _check(Render, scene, o_mix, d_mix, res, res)
+    assert prof["trace1"][2] > int((pick | pick2).sum())
     # (c) rays that are no image at all (random order): the model of the "image" does not fit
     perm = torch.randperm(len(o), device="cuda", generator=g)
     prof, _ = _check(Render, scene, o[perm].contiguous(), d[perm].contiguous(), res, res)

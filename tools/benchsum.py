@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Print the numbers of a bench.py JSON line that are looked at while tuning: step, per-stage (overlapped / isolated)."""
+import json
+import sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(f"{d['value']:.0f} Mrays/s  {d['ms_per_step']} ms/step   fused: {d.get('fused_mode', {}).get('ms_per_step')}")
+st = d["roofline"]["stages"]
+iso = d["roofline"].get("isolated", {}).get("stages_avg_launch_ms", {})
+for k, v in st.items():
+    extra = " ".join(f"{a}={v[a]}" for a in ("node_visits_per_ray", "lane_utilisation", "longest_wave_visits") if a in v)
+    print(f"  {k:15s} {v['ms_per_step']:7.3f} ms/step  {v['launches']:3d} launches  {v['avg_launch_ms']:7.4f} ms/launch  alone {iso.get(k, float('nan')):7.4f}  items/launch {v['items_per_launch']:9d}  {v['alg_GBps']:7.1f} GB/s {extra}")
