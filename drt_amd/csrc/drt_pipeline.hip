@@ -532,6 +532,45 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
 }
 
 
+// Backward of render_transparent + ray_loss for the rows ray_loss reported as contributing (drt_ray_loss's list):
+// the loss gradient d loss / d out_dir = 2 (out_dir - target) * scale is recomputed from the path (bit-identical to the
+// stored outputs: same code) instead of being read from a dense [N,3] tensor that is zero almost everywhere.
+__global__ void __launch_bounds__(256) k_render_bwd_rows(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                         const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
+                                                         const int32_t* __restrict__ face2, const int32_t* __restrict__ rows,
+                                                         const unsigned* __restrict__ n_rows, const double* __restrict__ scale, double* grad_verts) {
+    __shared__ int32_t hkeys[kHashSize];
+    __shared__ double hsums[3 * kHashSize];
+    const unsigned n = *n_rows;
+    const double sc = *scale;
+    const HashAdd3 add{hkeys, hsums, grad_verts};
+    for (unsigned base = blockIdx.x * kBwdBatch; base < n; base += gridDim.x * kBwdBatch) {
+        hash_clear(hkeys, hsums);
+        const unsigned end = base + kBwdBatch < n ? base + kBwdBatch : n;
+        for (unsigned k = base + threadIdx.x; k < end; k += blockDim.x) {
+            const int64_t i = rows[k];
+            d3 v0, v1, v2;
+            int32_t vid1[3], vid2[3];
+            Bounce b1, b2;
+            load_tri64(c, face1[i], v0, v1, v2, vid1);
+            bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b1);
+            load_tri64(c, face2[i], v0, v1, v2, vid2);
+            bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
+            d3 g_dir;
+            (void)ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
+            g_dir = sc * g_dir;
+            const d3 z{0.0, 0.0, 0.0};
+            d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
+            bounce_backward(b2, z, g_dir, ga, gb, gc, g_o, g_d);
+            add(vid2[0], ga); add(vid2[1], gb); add(vid2[2], gc);
+            ga = z; gb = z; gc = z;
+            bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
+            add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
+        }
+        hash_flush(hkeys, hsums, grad_verts);
+    }
+}
+
 __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused, int raster) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // sub-batches on different streams may report concurrently: atomics
@@ -756,6 +795,24 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
             if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->vcount, (unsigned long long)n, s->prof_counts);
         }
     }
+    if (s->prof_on) s->prof_stream = st;
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_render_backward_ray_loss(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                                 double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                                 const int32_t* d_rows, const uint32_t* d_n_rows, const double* d_screen_pixel, const double* d_scale,
+                                 double* d_grad_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_verts || !d_origin || !d_dir || !d_face1 || !d_face2 || !d_rows || !d_n_rows || !d_screen_pixel || !d_scale || !d_grad_verts)
+        return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    { StageTimer t(s, st, kStageBackward);
+      k_render_bwd_rows<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_face1, d_face2, d_rows, d_n_rows, d_scale, d_grad_verts); }
     if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;

@@ -82,11 +82,37 @@ def _f64c(t, name):
     return t.contiguous()
 
 
+# ray_loss's gradient w.r.t. out_dir is zero in all but a few per cent of the rows.  When the out_dir handed to
+# ``ray_loss`` is the very tensor ``render_transparent`` returned, the two autograd nodes exchange that gradient as a ROW
+# LIST instead of a dense float64 [N,3] tensor (1.8 GB per 72 x 1024^2 step, written once and read once): ray_loss's
+# backward queues (rows, targets, scale) on the link and returns a stride-0 zero tensor; render_transparent's backward
+# adds the queued rows (drt_render_backward_ray_loss) to whatever dense gradient other consumers of out_dir produced.
+# The values are identical.  What it cannot serve is a caller who asks autograd for d loss / d out_dir ITSELF
+# (torch.autograd.grad(loss, out_dir), out_dir.retain_grad()): set SPARSE_LOSS_GRAD = False for that.
+SPARSE_LOSS_GRAD = True
+
+
+class _GradLink:
+    def __init__(self):
+        self.pending = []
+        self._token = None
+
+    def token(self, n, device):
+        if self._token is None or self._token.shape[0] != n:
+            self._token = torch.zeros((1, 3), dtype=torch.float64, device=device).expand(n, 3)
+        return self._token
+
+    def is_token(self, g):
+        t = self._token
+        return t is not None and g.data_ptr() == t.data_ptr() and g.stride() == t.stride() and g.shape == t.shape
+
+
 class _RenderTransparent(torch.autograd.Function):
     """render_transparent as a function of the vertices (the reference's implicit input)."""
 
     @staticmethod
-    def forward(ctx, vertices, origin, ray_dir, scene, ior_int, ior_ext):
+    def forward(ctx, vertices, origin, ray_dir, scene, ior_int, ior_ext, link):
+        ctx.link = link
         v = _f64c(vertices.detach(), "vertices")
         o = _f64c(origin.detach(), "origin")
         d = _f64c(ray_dir.detach(), "ray_dir")
@@ -119,23 +145,31 @@ class _RenderTransparent(torch.autograd.Function):
     def backward(ctx, g_ori, g_dir, g_mask):
         v, o, d, face1, face2, valid_idx, n_valid = ctx.saved_tensors
         grad_v = torch.zeros_like(v)
-        if g_ori is None and g_dir is None:
-            return grad_v, None, None, None, None, None
-        g_ori = None if g_ori is None else _f64c(g_ori, "grad_out_ori")
-        g_dir = None if g_dir is None else _f64c(g_dir, "grad_out_dir")
+        link = ctx.link
+        pending, link.pending = link.pending, []
+        if g_dir is not None and link.is_token(g_dir):
+            g_dir = None                        # ray_loss's placeholder: its gradient is in `pending`
+        h = ctx.scene.optix_mesh._h
         with torch.cuda.device(o.device):
-            _lib.check(_lib.lib().drt_render_backward(
-                ctx.scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1],
-                face1.data_ptr(), face2.data_ptr(), _lib.ptr(valid_idx), _lib.ptr(n_valid),
-                _lib.ptr(g_ori), _lib.ptr(g_dir), grad_v.data_ptr(), _stream()))
-        return grad_v, None, None, None, None, None
+            if g_ori is not None or g_dir is not None:
+                g_ori = None if g_ori is None else _f64c(g_ori, "grad_out_ori")
+                g_dir = None if g_dir is None else _f64c(g_dir, "grad_out_dir")
+                _lib.check(_lib.lib().drt_render_backward(
+                    h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1],
+                    face1.data_ptr(), face2.data_ptr(), _lib.ptr(valid_idx), _lib.ptr(n_valid),
+                    _lib.ptr(g_ori), _lib.ptr(g_dir), grad_v.data_ptr(), _stream()))
+            for rows, n_rows, sp, scale in pending:
+                _lib.check(_lib.lib().drt_render_backward_ray_loss(
+                    h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1], face1.data_ptr(), face2.data_ptr(),
+                    rows.data_ptr(), n_rows.data_ptr(), sp.data_ptr(), scale.data_ptr(), grad_v.data_ptr(), _stream()))
+        return grad_v, None, None, None, None, None, None
 
 
 class _RayLoss(torch.autograd.Function):
     """Loss_calculator.ray_loss (reference optim.py:100-106) in one pass over the rays."""
 
     @staticmethod
-    def forward(ctx, out_ori, out_dir, mask, screen_pixel, valid):
+    def forward(ctx, out_ori, out_dir, mask, screen_pixel, valid, link):
         oo = _f64c(out_ori.detach(), "out_ori")
         od = _f64c(out_dir.detach(), "out_dir")
         sp = _f64c(screen_pixel, "screen_pixel")
@@ -144,23 +178,30 @@ class _RayLoss(torch.autograd.Function):
         va = _flag_bytes(valid, "valid", n)
         loss = torch.zeros((), dtype=torch.float64, device=oo.device)
         need = ctx.needs_input_grad[1]
-        g = torch.empty_like(od) if need else None
+        ctx.link = link if need else None
+        g = torch.empty_like(od) if need and link is None else None      # dense d loss / d out_dir only without a link
         rows = torch.empty(n, dtype=torch.int32, device=oo.device) if need else None
         n_rows = torch.zeros(1, dtype=torch.int32, device=oo.device) if need else None
         with torch.cuda.device(oo.device):
             _lib.check(_lib.lib().drt_ray_loss(oo.data_ptr(), od.data_ptr(), m.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
                                                loss.data_ptr(), _lib.ptr(g), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
-        ctx.save_for_backward(g, rows, n_rows)
+        ctx.save_for_backward(g, rows, n_rows, sp if (need and link is not None) else None)
         ctx.applied = None                       # scale already multiplied into the saved rows (see backward)
+        ctx.n_rays = n
         return loss
 
     @staticmethod
     def backward(ctx, g_loss):
-        g, rows, n_rows = ctx.saved_tensors
+        g, rows, n_rows, sp = ctx.saved_tensors
+        if ctx.link is not None:                 # row-list hand-off to render_transparent's backward (see _GradLink)
+            if ctx.n_rays == 0:
+                return None, None, None, None, None, None
+            ctx.link.pending.append((rows, n_rows, sp, g_loss.detach().to(torch.float64).reshape(1).contiguous()))
+            return None, ctx.link.token(ctx.n_rays, rows.device), None, None, None, None
         if g is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if g.numel() == 0:                       # no rays: an empty tensor has no storage to pass down
-            return None, g, None, None, None
+            return None, g, None, None, None, None
         # scale only the contributing rows (a few % of the rays) instead of streaming the dense tensor again;
         # out_ori is detached in the reference's loss (optim.py:100): no gradient for it
         sc = g_loss.detach().to(torch.float64).reshape(1).contiguous()
@@ -175,7 +216,7 @@ class _RayLoss(torch.autograd.Function):
         ctx.applied = new
         with torch.cuda.device(g.device):
             _lib.check(_lib.lib().drt_scale_rows3(g.data_ptr(), rows.data_ptr(), n_rows.data_ptr(), sc.data_ptr(), _stream()))
-        return None, g, None, None, None
+        return None, g, None, None, None, None
 
 
 class _RenderRayLossFused(torch.autograd.Function):
@@ -205,7 +246,10 @@ class _RenderRayLossFused(torch.autograd.Function):
 
 def ray_loss(out_ori, out_dir, mask, screen_pixel, valid):
     """sum over valid & mask rays of |out_dir - normalize(screen_pixel - out_ori.detach())|^2."""
-    return _RayLoss.apply(out_ori, out_dir, mask, screen_pixel, valid)
+    link = getattr(out_dir, "_drt_link", None) if SPARSE_LOSS_GRAD else None
+    if link is not None and not (out_dir.requires_grad and isinstance(out_dir.grad_fn, _RenderTransparent._backward_cls)):
+        link = None
+    return _RayLoss.apply(out_ori, out_dir, mask, screen_pixel, valid, link)
 
 
 def edge_tables(F, V):
@@ -285,7 +329,10 @@ class Scene(StepwiseMixin):
 
     # ------------------------------------------------------------------ refraction path
     def render_transparent(self, origin: torch.Tensor, ray_dir: torch.Tensor):
-        return _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR)
+        link = _GradLink()
+        out_ori, out_dir, mask = _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR, link)
+        out_dir._drt_link = link            # lets ray_loss hand its gradient over as a row list (see _GradLink)
+        return out_ori, out_dir, mask
 
     def ray_loss_fused(self, origin, ray_dir, screen_pixel, valid):
         """ray_loss of this view without materialising out_ori/out_dir/mask."""

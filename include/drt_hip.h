@@ -117,6 +117,17 @@ int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t
 int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list,
                     const double* d_scale, void* stream);
 
+/* Adjoint of drt_render_forward followed by drt_ray_loss, for the rays drt_ray_loss listed (d_rows / *d_n_rows):
+ * grad_verts [V,3] += *d_scale * d ray_loss / d vertices.  Equivalent to drt_scale_rows3 + drt_render_backward with the
+ * dense d loss / d out_dir, without that [N,3] tensor (zero in all but the listed rows) ever being written or read:
+ * the loss gradient of a listed ray is recomputed from its path. */
+int drt_render_backward_ray_loss(drt_scene_t* s, const double* d_verts, const double* d_origin,
+                                 const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
+                                 const int32_t* d_face1, const int32_t* d_face2,
+                                 const int32_t* d_rows, const uint32_t* d_n_rows,
+                                 const double* d_screen_pixel, const double* d_scale,
+                                 double* d_grad_verts, void* stream);
+
 /* One pass: render_transparent + ray_loss + d ray_loss / d vertices, nothing dense written.
  * *d_loss += loss, d_grad_verts [V,3] += gradient (both float64, zero them first);
  * d_n_valid (int64, may be NULL) += number of contributing rays. */

@@ -724,3 +724,42 @@ def test_b1_torch_extension_used_like_the_reference(hand, horse50k):
     Ta, IDa = mesh.intersect(big)
     Tb, IDb = _tracer(horse50k).intersect(big)
     assert torch.equal(IDa, IDb) and torch.equal(Ta, Tb) and 0.01 < (IDa >= 0).float().mean().item() < 0.6
+
+
+def test_ray_loss_gradient_as_row_list_equals_the_dense_tensor(Render, hand):
+    """ray_loss hands its gradient to render_transparent's backward as a row list (diffrender._GradLink) when out_dir is the
+    tensor render_transparent returned; the dense [N,3] form (SPARSE_LOSS_GRAD = False, or a detached / re-wrapped out_dir)
+    must give the same vertex gradient, alone, next to other consumers of out_dir, twice on one graph, and with two losses."""
+    g = golden("hand_r128_v41")
+    o, d, sp, valid = fixture_view(g)
+    o, d, sp, valid = o.cuda(), d.cuda(), sp.cuda(), valid.cuda()
+    Render.resx = Render.resy = int(g["res"])
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+    w = torch.randn(o.shape, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+
+    def grads(sparse):
+        Render.SPARSE_LOSS_GRAD = sparse
+        try:
+            V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+            scene.update_verticex(V)
+            oo, od, mk = scene.render_transparent(o, d)
+            l1 = Render.ray_loss(oo, od, mk, sp, valid)
+            l2 = Render.ray_loss(oo, od, mk, sp + 1.0, valid)
+            out = [torch.autograd.grad(2.5 * l1, V, retain_graph=True)[0],                        # alone, scaled
+                   torch.autograd.grad(l1 + (od * w).sum() + (oo * w).sum(), V, retain_graph=True)[0],   # next to dense consumers
+                   torch.autograd.grad(l1, V, retain_graph=True)[0],                              # again on the same graph
+                   torch.autograd.grad(l1 + 0.5 * l2, V, retain_graph=True)[0]]                   # two losses on one out_dir
+            assert l1.item() == pytest.approx(float(g["ray_loss"]), rel=1e-10)
+            if not sparse:
+                g_od, = torch.autograd.grad(l1, od)                                               # the dense form can be asked for
+                assert g_od.shape == od.shape and int((g_od.abs().sum(dim=1) > 0).sum()) > 100
+            return out
+        finally:
+            Render.SPARSE_LOSS_GRAD = True
+
+    a, b = grads(True), grads(False)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=1e-11, atol=1e-13 * y.abs().max().item())
+    ref = g["grad_ray_loss"]
+    np.testing.assert_allclose(a[2].cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    np.testing.assert_allclose(a[0].cpu().numpy(), 2.5 * ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
