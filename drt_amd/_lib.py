@@ -31,12 +31,12 @@ SIGNATURES = {
     "drt_intersect_bruteforce": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
     "drt_bvh_check": (_c.c_int, [_P, _P, _c.POINTER(_I64), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32)]),
     "drt_bvh_sorted_faces": (_c.c_int, [_P, _P, _P]),
-    "drt_render_forward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P]),
+    "drt_render_forward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "drt_render_backward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "drt_ray_loss": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "drt_scale_rows3": (_c.c_int, [_P, _P, _P, _P, _P]),
     "drt_render_backward_ray_loss": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "drt_render_ray_loss_fused": (_c.c_int, [_P, _P, _P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _c.c_int, _c.c_int, _P]),
+    "drt_render_ray_loss_fused": (_c.c_int, [_P, _P, _P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "drt_dihedral_forward": (_c.c_int, [_P, _P, _I64, _P, _P]),
     "drt_dihedral_backward": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
     "drt_sm_loss_fused": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),

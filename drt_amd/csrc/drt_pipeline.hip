@@ -103,7 +103,8 @@ __device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
 // goes to R0 with its face already known; only rays that do not verify take the top-box test and are listed in
 // `gen_list` for the traversal kernel, exactly as every candidate was before.
 struct RasterIn {
-    const ViewModel* views;          // null: BVH path for every ray
+    ViewModel* views;                // null: BVH path for every ray
+    int mode;                        // DRT_GRID_*: TRUST: images with ok && all need no verification, and no ray loads where no key was written
     unsigned long long* zbuf;
     uint32_t* zmask;
     int32_t* gen_list;               // R0 slots that still need k_trace (count in p.count[3])
@@ -138,7 +139,11 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
         f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f};
         if (i < n) {
             unsigned long long key = kRasterEmpty;
+            bool trusted = false;
+            int64_t view = 0;
             if (raster) {
+                view = y / rz.img_h;                                   // block-uniform: a patch never straddles two images
+                trusted = rz.mode == DRT_GRID_TRUST && rz.views[view].ok && rz.views[view].all;
                 // the 64 rays of a wave are one 64-aligned run: one group bit decides whether any key was written here
                 const unsigned word = rz.zmask[i >> 11], bit = 1u << ((i >> 6) & 31);
                 if (word & bit) {
@@ -147,15 +152,23 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
                     if ((tid & 63) == 0) atomicAnd(&rz.zmask[i >> 11], ~bit);
                 }
             }
-            // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
-            if (!FUSED || valid[i]) {
+            if (trusted) {
+                // every ray of this image is known to be a grid ray: its primary hit is its key, and a pixel without a
+                // key needs nothing from its ray -- no load at all for nine patches out of ten
+                if (key != kRasterEmpty && (!FUSED || valid[i])) {
+                    o = to_f32(load_d3(origin, i)); d = to_f32(load_d3(dir, i));
+                    cand = true;
+                    face = (int32_t)(uint32_t)key;
+                }
+            } else if (!FUSED || valid[i]) {
+                // the fused loss ignores pixels without a target (reference optim.py:105): their rays are not traced
                 const d3 o64 = load_d3(origin, i), d64 = load_d3(dir, i);
                 o = to_f32(o64); d = to_f32(d64);
                 bool verified = false;
                 if (raster) {
-                    const int64_t view = y / rz.img_h;
-                    const ViewModel& vm = rz.views[view];
+                    ViewModel& vm = rz.views[view];
                     verified = vm.ok && view_verify(vm, o64, d64, (double)x, (double)(y - view * rz.img_h));
+                    if (!verified && vm.all) __hip_atomic_store(&vm.all, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (verified) {
                     cand = key != kRasterEmpty;
@@ -164,6 +177,11 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
                     cand = n_tris > 0 && hits_top_boxes(nodes, o, d);
                     generic = cand;
                 }
+            } else if (raster && rz.mode == DRT_GRID_ESTABLISH) {
+                // (fused, establishing the cache) a pixel without a target is not traced, but its ray still counts for `all`
+                ViewModel& vm = rz.views[view];
+                if (vm.all && !(vm.ok && view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)(y - view * rz.img_h))))
+                    __hip_atomic_store(&vm.all, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (!cand) {
                 face1[i] = -1;
@@ -645,6 +663,18 @@ static Plan plan_call(const drt_scene* s, int64_t n_rays, int tile_w, int tile_h
     return pl;
 }
 
+// ESTABLISH: the fitted model of every image and whether all of its rays verified (k_cull cleared `all` otherwise).  `ok` is
+// stored as "all rays verified" too: an image whose projection had no bound in THIS call (camera plane through a
+// triangle) verified nothing and is simply never trusted.
+__global__ void k_store_models(const ViewModel* __restrict__ work, ViewModel* __restrict__ cache, int n) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    ViewModel m = work[v];
+    m.all = (m.ok && m.all) ? 1 : 0;
+    m.ok = m.all;
+    cache[v] = m;
+}
+
 // Whole images of a multiple-of-64 width and multiple-of-4 height: the sub-batch can use the projected primary visibility.
 static bool raster_on(const drt_scene* s, int64_t n, int tile_w, int tile_h) {
     if (!s->use_raster || s->n_faces <= 0 || tile_w < 64 || tile_w % 64 != 0 || tile_h < 4 || tile_h % 4 != 0) return false;
@@ -658,22 +688,26 @@ static bool raster_on(const drt_scene* s, int64_t n, int tile_w, int tile_h) {
 extern "C++" {
 template <bool FUSED>
 static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
-                        int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h) {
+                        int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h,
+                        int grid_mode, ViewModel* grid_cache /* models of the images of THIS sub-batch */) {
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
-    RasterIn rz{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
     const int64_t image = (int64_t)tile_w * tile_h;
     if (raster_on(s, n, tile_w, tile_h)) {
         const int n_views = (int)(n / image);
         int rc = ensure_raster(s, w, n, n_views, st);
         if (rc) return rc;
+        if (!grid_cache) grid_mode = DRT_GRID_NONE;
         StageTimer t(s, st, kStageRaster);
-        rc = launch_raster(s, w, st, o, d, n_views, tile_w, tile_h);
+        rc = launch_raster(s, w, st, o, d, n_views, tile_w, tile_h, grid_mode == DRT_GRID_TRUST ? grid_cache : nullptr);
         if (rc) return rc;
-        rz = RasterIn{w.vmodel, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h};
+        rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h};
     }
     { StageTimer t(s, st, kStageCull);
       k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz); }
+    if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
+        k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
     { StageTimer t(s, st, kStageTrace1);
       if (rz.views) {       // only the R0 slots listed by k_cull (rays that are not grid rays)
           const TraceOut out{p.r0.face, nullptr, nullptr, w.gen_list};
@@ -712,6 +746,11 @@ static int join_streams(drt_scene* s, hipStream_t st, int streams) {
     return DRT_OK;
 }
 
+// the cache entries of the images of the sub-batch that starts at ray b
+static ViewModel* sub_cache(void* d_grid_cache, int64_t b, int tile_w, int tile_h) {
+    if (!d_grid_cache || tile_w <= 0 || tile_h <= 0) return nullptr;
+    return static_cast<ViewModel*>(d_grid_cache) + b / ((int64_t)tile_w * tile_h);
+}
 static PathCtx sub_ctx(const drt_scene* s, const drt_scene::Sub& w, const double* d_verts, double ior_int, double ior_ext) {
     PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
     pc.tc.slow_stack = w.slow_stack;     // concurrent kernels must not share overflow stacks
@@ -727,7 +766,8 @@ extern "C" {
 
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
-                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h, void* stream) {
+                       int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h,
+                       int grid_mode, void* d_grid_cache, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -750,7 +790,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         const Pipe p = pipe_of(s, w);
         HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
         rc = launch_chunk<false>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h);
+                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h));
         if (rc) return rc;
         { StageTimer t(s, w.stream, kStageFinish);
           k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
@@ -840,7 +880,8 @@ int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list
 
 int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir,
                               const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays, double ior_int,
-                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, int tile_w, int tile_h, void* stream) {
+                              double ior_ext, double* d_loss, double* d_grad_verts, int64_t* d_n_valid, int tile_w, int tile_h,
+                              int grid_mode, void* d_grid_cache, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     if (n_rays == 0) return DRT_OK;
@@ -857,7 +898,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
         HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
-        rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h);
+        rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h));
         if (rc) return rc;
         { StageTimer t(s, w.stream, kStageLossBwdFused);
           k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,

@@ -9,6 +9,11 @@
 // by a 64-bit atomic minimum of (t bits, face id) -- i.e. the contract of oracle/tracer.c (minimum t, ties -> lowest
 // face id) without walking a tree: ~3 tests per (view, triangle) instead of ~14 node visits per candidate ray.
 //
+// A caller that presents the SAME, unchanged ray tensors again (a capture's views are constants of the optimisation) can
+// keep the verdict: a call in DRT_GRID_ESTABLISH mode records the fitted models and, per image, whether every single ray
+// verified, in a caller-owned cache; later calls in DRT_GRID_TRUST mode then neither re-fit nor re-read the rays of
+// pixels no projected triangle touches (nine out of ten): k_cull writes their zeros without loading anything.
+//
 // Nothing is assumed about the caller's rays: the model (origin, M^-1) of every image is FITTED on the device from four
 // of its rays, every single ray is then VERIFIED against it in k_cull (origin bit-equal, pixel position within
 // kRasterVerifyTol), and a ray that does not verify -- calibrated per-pixel rays of a real capture, arbitrary ray
@@ -24,8 +29,10 @@ struct ViewModel {
     double o[3];        // common origin of the image's rays
     double minv[9];     // (x, y, 1) ~ minv * direction, row-major
     int32_t ok;         // 1: pinhole grid; 0: take the BVH path for every ray of this image
-    int32_t pad;
+    int32_t all;        // 1: EVERY ray of the image verified against the model (established by a call in DRT_GRID_ESTABLISH mode)
 };
+
+static_assert(sizeof(ViewModel) == 104, "DRT_GRID_CACHE_BYTES of include/drt_hip.h");
 
 constexpr double kRasterPad = 0.25;          // pixels added on every side of a projected triangle's bounding box
 constexpr double kRasterVerifyTol = 1e-3;    // a ray belongs to the grid if its direction projects within this of its pixel
@@ -37,7 +44,7 @@ DRT_HD bool fit_view_model(d3 o, d3 d00, d3 dW0, d3 d0H, d3 dWH, double wm1, dou
     // beta dW0 + gamma d0H - eps dWH = d00   (from (W-1) m0 = beta dW0 - d00, (H-1) m1 = gamma d0H - d00, m2 = d00)
     const d3 c0 = dW0, c1 = d0H, c2 = -dWH;
     const double det = dot(c0, cross(c1, c2));
-    vm.ok = 0; vm.pad = 0;
+    vm.ok = 0; vm.all = 0;
     vm.o[0] = o.x; vm.o[1] = o.y; vm.o[2] = o.z;
     for (int k = 0; k < 9; ++k) vm.minv[k] = 0.0;
     if (!(fabs(det) > 1e-300) || !(wm1 > 0.0) || !(hm1 > 0.0)) return false;

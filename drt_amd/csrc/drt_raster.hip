@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(64) k_fit_views(const double* __restrict__ ori
     const bool all_good = __ballot(good) == ~0ull;
     if (threadIdx.x == 0) {
         vm.ok = all_good ? 1 : 0;
+        vm.all = vm.ok;              // k_cull clears it when a ray of the image does not verify
         views[blockIdx.x] = vm;
     }
 }
@@ -191,10 +192,12 @@ int ensure_raster(drt_scene* s, drt_scene::Sub& w, int64_t n_rays, int n_views, 
 }
 
 // Fit the image models and rasterise every triangle into the key buffer of `w` (rays [0, n_views * w * h) of the sub-batch).
-int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih) {
+int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih,
+                  const ViewModel* trusted) {
     const int n = (int)s->n_faces;
     HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
-    k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
+    if (trusted) HIP_TRY(hipMemcpyAsync(w.vmodel, trusted, sizeof(ViewModel) * n_views, hipMemcpyDeviceToDevice, st));   // models of an earlier call
+    else k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
     if (n > 0) {
         k_raster<<<dim3((n + 255) / 256, n_views), 256, 0, st>>>(s->tris, n, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                                   reinterpret_cast<BigItem*>(w.big), w.big_count, drt_scene::kBigCap);

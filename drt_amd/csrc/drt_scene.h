@@ -153,7 +153,8 @@ int pipeline_blocks_per_cu();
 
 // defined in drt_raster.hip
 int ensure_raster(drt_scene* s, drt_scene::Sub& w, int64_t n_rays, int n_views, hipStream_t st);
-int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih);
+int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih,
+                  const ViewModel* trusted);
 
 // defined in drt_build.hip
 void scene_free_mesh(drt_scene* s);

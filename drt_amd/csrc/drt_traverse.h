@@ -171,6 +171,15 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
     float t[4];
     bool h[4];
     slab_node4q(q0, q1, q2, s.inv, s.oi, s.best_t, t, h);
+#if defined(DRT_EXP_SLAB2) && defined(__HIP_DEVICE_COMPILE__)
+    {   // experiment: the slab arithmetic twice (opaque copy of the inputs), results combined without changing them
+        F4 r0 = q0, r1 = q1, r2 = q2;
+        asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w), "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w));
+        float t2[4]; bool h2[4];
+        slab_node4q(r0, r1, r2, s.inv, s.oi, s.best_t, t2, h2);
+        for (int k = 0; k < 4; ++k) { h[k] = h[k] & h2[k]; t[k] = fminf(t[k], t2[k]); }
+    }
+#endif
     const bool h0 = h[0] & (c0 != kEmptyChild), h1 = h[1] & (c1 != kEmptyChild), h2 = h[2] & (c2 != kEmptyChild), h3 = h[3] & (c3 != kEmptyChild);
     // Entry distances are >= 0, so their bit patterns order like unsigned integers; the two low
     // mantissa bits are replaced by the child slot (ordering only -- culling used the exact value);

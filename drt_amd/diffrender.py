@@ -74,6 +74,34 @@ def _flag_bytes(t, name, n):
     return t.contiguous().view(torch.uint8)
 
 
+GRID_CACHE = True      # remember, per (origin, ray_dir) tensor pair, that its images verified as pinhole grids (see _grid_cache)
+_GRID_BYTES = 104      # DRT_GRID_CACHE_BYTES of include/drt_hip.h
+
+
+def _grid_cache(origin, ray_dir, n, w, h):
+    """(grid_mode, cache tensor or None) for a render call on these ray tensors.
+
+    The views of a capture are constants of the optimisation: the same tensor objects come back every iteration.  The
+    first call on a pair ESTABLISHES, on the device, which of its images are pinhole ray grids in every single ray
+    (drt_raster.h); the record -- a small device buffer -- is kept on the ``ray_dir`` tensor object together with the
+    identity of ``origin`` and both tensors' in-place version counters, and later calls TRUST it as long as those
+    match: the library then does not re-read the rays of pixels nothing projects onto.  Any in-place write to either
+    tensor bumps its version and the next call re-establishes.  (``t.data = ...`` and writes through raw pointers are not
+    seen by the version counter: do not do that to tensors you render from, or set GRID_CACHE = False.)"""
+    if not GRID_CACHE or w <= 0 or h <= 0 or n == 0:
+        return 0, None
+    rec = getattr(ray_dir, "_drt_grid", None)
+    key = (n, w, h, origin._version, ray_dir._version, origin.data_ptr(), ray_dir.data_ptr())
+    if rec is not None and rec[0] == key and rec[1]() is origin:
+        return 2, rec[2]
+    cache = torch.zeros((n // (w * h)) * _GRID_BYTES, dtype=torch.uint8, device=ray_dir.device)
+    try:
+        ray_dir._drt_grid = (key, weakref.ref(origin), cache)
+    except Exception:           # a tensor that takes no attributes: no cache
+        return 0, None
+    return 1, cache
+
+
 def _f64c(t, name):
     if t.dtype != torch.float64:
         raise RuntimeError(f"{name} must be float64, got {t.dtype}")
@@ -111,7 +139,7 @@ class _RenderTransparent(torch.autograd.Function):
     """render_transparent as a function of the vertices (the reference's implicit input)."""
 
     @staticmethod
-    def forward(ctx, vertices, origin, ray_dir, scene, ior_int, ior_ext, link):
+    def forward(ctx, vertices, origin, ray_dir, scene, ior_int, ior_ext, link, grid=(0, None)):
         ctx.link = link
         v = _f64c(vertices.detach(), "vertices")
         o = _f64c(origin.detach(), "origin")
@@ -129,7 +157,7 @@ class _RenderTransparent(torch.autograd.Function):
             _lib.check(_lib.lib().drt_render_forward(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
                 out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
-                _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), _stream()))
+                _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0], _lib.ptr(grid[1]), _stream()))
         ctx.scene = scene
         ctx.ior = (float(ior_int), float(ior_ext))
         ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)
@@ -162,7 +190,7 @@ class _RenderTransparent(torch.autograd.Function):
                 _lib.check(_lib.lib().drt_render_backward_ray_loss(
                     h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1], face1.data_ptr(), face2.data_ptr(),
                     rows.data_ptr(), n_rows.data_ptr(), sp.data_ptr(), scale.data_ptr(), grad_v.data_ptr(), _stream()))
-        return grad_v, None, None, None, None, None, None
+        return grad_v, None, None, None, None, None, None, None
 
 
 class _RayLoss(torch.autograd.Function):
@@ -223,7 +251,7 @@ class _RenderRayLossFused(torch.autograd.Function):
     """render_transparent + ray_loss + d/d vertices in ONE kernel pass (nothing dense written)."""
 
     @staticmethod
-    def forward(ctx, vertices, origin, ray_dir, screen_pixel, valid, scene, ior_int, ior_ext):
+    def forward(ctx, vertices, origin, ray_dir, screen_pixel, valid, scene, ior_int, ior_ext, grid=(0, None)):
         v = _f64c(vertices.detach(), "vertices")
         o = _f64c(origin, "origin")
         d = _f64c(ray_dir, "ray_dir")
@@ -234,14 +262,14 @@ class _RenderRayLossFused(torch.autograd.Function):
         with torch.cuda.device(o.device):
             _lib.check(_lib.lib().drt_render_ray_loss_fused(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), o.shape[0],
-                float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, *_tile_hint(o.shape[0]), _stream()))
+                float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, *_tile_hint(o.shape[0]), grid[0], _lib.ptr(grid[1]), _stream()))
         ctx.save_for_backward(grad_v)
         return loss
 
     @staticmethod
     def backward(ctx, g_loss):
         (grad_v,) = ctx.saved_tensors
-        return grad_v * g_loss, None, None, None, None, None, None, None
+        return grad_v * g_loss, None, None, None, None, None, None, None, None
 
 
 def ray_loss(out_ori, out_dir, mask, screen_pixel, valid):
@@ -330,13 +358,15 @@ class Scene(StepwiseMixin):
     # ------------------------------------------------------------------ refraction path
     def render_transparent(self, origin: torch.Tensor, ray_dir: torch.Tensor):
         link = _GradLink()
-        out_ori, out_dir, mask = _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR, link)
+        grid = _grid_cache(origin, ray_dir, origin.shape[0], *_tile_hint(origin.shape[0])) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
+        out_ori, out_dir, mask = _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR, link, grid)
         out_dir._drt_link = link            # lets ray_loss hand its gradient over as a row list (see _GradLink)
         return out_ori, out_dir, mask
 
     def ray_loss_fused(self, origin, ray_dir, screen_pixel, valid):
         """ray_loss of this view without materialising out_ori/out_dir/mask."""
-        return _RenderRayLossFused.apply(self.vertices, origin, ray_dir, screen_pixel, valid, self, intIOR, extIOR)
+        grid = _grid_cache(origin, ray_dir, origin.shape[0], *_tile_hint(origin.shape[0])) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
+        return _RenderRayLossFused.apply(self.vertices, origin, ray_dir, screen_pixel, valid, self, intIOR, extIOR, grid)
 
     # ------------------------------------------------------------------ smoothness branch
     def dihedral_angle(self):
@@ -472,7 +502,7 @@ class _EdgeSample(torch.autograd.Function):
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().drt_edge_sample_backward(v.data_ptr(), edges.data_ptr(), edges.shape[0], cam.data_ptr(), f.data_ptr(),
                                                            coef.data_ptr(), int(ctx.detach_depth), grad_v.data_ptr(), _stream()))
-        return grad_v, None, None, None, None, None, None, None
+        return grad_v, None, None, None, None, None, None, None, None
 
 
 class _VhLossFused(torch.autograd.Function):

@@ -86,12 +86,23 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
  *      16x4-pixel screen tiles and, when every image verifies as a pinhole ray grid (generate_ray, reference
  *      captured_data.py:23-40), decide the primary hits by projecting the triangles instead of traversing the
  *      tree (csrc/drt_raster.h).  Every ray is checked against the fitted grid on the device and takes the
- *      tree otherwise: results do not depend on the hint. */
+ *      tree otherwise: results do not depend on the hint.
+ *      grid_mode, d_grid_cache: DRT_GRID_NONE / NULL, or a caller-owned device buffer of DRT_GRID_CACHE_BYTES per image that
+ *      belongs to THIS (origin, dir) pair with THIS tile_w x tile_h.  DRT_GRID_ESTABLISH: the call fits and verifies as
+ *      above and records, per image, the model and whether every ray verified.  DRT_GRID_TRUST: the caller guarantees the
+ *      ray arrays have not changed since the establishing call; images recorded as all-verified are then neither
+ *      re-fitted nor re-verified, and rays of pixels that no projected triangle touches are not even loaded.  (The
+ *      Python layer ties the buffer to the tensor objects and their version counters.) */
+#define DRT_GRID_NONE 0
+#define DRT_GRID_ESTABLISH 1
+#define DRT_GRID_TRUST 2
+#define DRT_GRID_CACHE_BYTES 104
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                        double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
                        int32_t* d_face1, int32_t* d_face2,
-                       int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h, void* stream);
+                       int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h,
+                       int grid_mode, void* d_grid_cache, void* stream);
 /* Adjoint of drt_render_forward w.r.t. the vertices: d_grad_verts float64 [V,3] += ...
  * (atomic accumulation; zero it first).  Either incoming gradient may be NULL (= zeros). */
 int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_origin,
@@ -135,7 +146,8 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
                               const double* d_dir, const double* d_screen_pixel,
                               const uint8_t* d_valid, int64_t n_rays, double ior_int,
                               double ior_ext, double* d_loss, double* d_grad_verts,
-                              int64_t* d_n_valid, int tile_w, int tile_h, void* stream);
+                              int64_t* d_n_valid, int tile_w, int tile_h,
+                              int grid_mode, void* d_grid_cache, void* stream);
 
 /* ---- smoothness branch: Scene.dihedral_angle (DiffRender.py:440-443, edge_face_norm :149-163)
  * and Loss_calculator.sm_loss (optim.py:82-89) ---------------------------------------------------

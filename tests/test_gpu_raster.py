@@ -159,3 +159,73 @@ def test_key_buffer_is_clean_after_every_call(Render):
     with torch.no_grad():
         scene.render_transparent(o, d)
     assert torch.equal(scene.last_face1, _primary_reference(scene, o, d))
+
+
+def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_writes(Render):
+    """Scene.render_transparent on the SAME ray tensors again trusts the recorded verdict (no re-verification, rays of
+    untouched pixels not even read); results stay equal to the exhaustive test while the mesh moves, and an in-place write
+    to either tensor (version counter) makes the next call establish again -- including one that breaks the grid."""
+    from drt_amd import diffrender
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(mesh, 0)
+    c, ext = views.mesh_frame(mesh.vertices)
+    res = 256
+    cams = views.turntable_cameras(c, ext, 72, res, res)
+    rays = [views.generate_ray(res, res, cams[k][3], cams[k][2], device="cuda") for k in (4, 22, 47)]
+    o = torch.cat([r[0] for r in rays]).contiguous(); d = torch.cat([r[1] for r in rays]).contiguous()
+    # image 1 is a distorted grid: it must never be trusted, the other two are
+    P = res * res
+    d[P:2 * P] = torch.nn.functional.normalize(d[P:2 * P] + 0.003 * torch.sin(torch.arange(P, device="cuda", dtype=torch.float64) / 977.0).unsqueeze(1), dim=1)
+    Render.resx = Render.resy = res
+    V0 = scene.vertices.detach().clone()
+    tr = scene.optix_mesh
+    sp = torch.randn(o.shape, dtype=torch.float64, device="cuda"); valid = torch.rand(len(o), device="cuda") < 0.6
+
+    def run(expect_mode):
+        assert diffrender._grid_cache(o, d, len(o), res, res)[0] == expect_mode or expect_mode is None
+        tr.profile_enable(1); tr.profile_read()
+        with torch.no_grad():
+            oo, od, mk = scene.render_transparent(o, d)
+        prof = tr.profile_read(); tr.profile_enable(0)
+        assert torch.equal(scene.last_face1, _primary_reference(scene, o, d))
+        return prof, (oo, od, mk)
+
+    # (peeking at the cache state creates it: drop the attribute so that the first render establishes)
+    for it in range(4):
+        scene.update_verticex(V0 * (1.0 + 0.05 * it) + 2.0 * it)
+        if it == 0 and hasattr(d, "_drt_grid"):
+            del d._drt_grid
+        prof, out = run(None)
+        assert prof["trace1"][2] > 0                       # the distorted image takes the tree, every time
+        if it > 0:
+            assert diffrender._grid_cache(o, d, len(o), res, res)[0] == 2
+        # the fused loss on the same tensors shares the verdict
+        V = scene.vertices.detach().clone().requires_grad_(True)
+        scene.update_verticex(V)
+        lf = scene.ray_loss_fused(o, d, sp, valid)
+        oo, od, mk = scene.render_transparent(o, d)
+        l2 = Render.ray_loss(oo, od, mk, sp, valid)
+        assert lf.item() == pytest.approx(l2.item(), rel=1e-12, abs=1e-300)
+    # the same values through fresh tensor objects (no cache) and with the cache disabled: identical outputs
+    ref = run(None)[1]
+    diffrender.GRID_CACHE = False
+    try:
+        with torch.no_grad():
+            again = scene.render_transparent(o, d)
+    finally:
+        diffrender.GRID_CACHE = True
+    with torch.no_grad():
+        fresh = scene.render_transparent(o.clone(), d.clone())
+    for a, b, c2 in zip(ref, again, fresh):
+        assert torch.equal(a, b) and torch.equal(a, c2)
+    # in-place writes: image 0 loses a few grid rays (and its trust), image 2 keeps it
+    ver = d._version
+    d[1000:1010] = d[5000:5010].clone()
+    assert d._version > ver and diffrender._grid_cache(o, d, len(o), res, res)[0] == 1
+    del d._drt_grid
+    prof, _ = run(None)
+    prof2, _ = run(None)                                   # trusted call after the re-establishment
+    assert prof2["trace1"][2] == prof["trace1"][2] > 0
+    o[2 * P + 5] += 1.0                                    # and an origin write
+    prof3, _ = run(None)
+    assert prof3["trace1"][2] >= prof2["trace1"][2]
