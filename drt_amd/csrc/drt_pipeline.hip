@@ -98,6 +98,24 @@ __device__ __forceinline__ void store_ray32(float* ray, int slot, f3 o, f3 d) {
 // multiple-of-4 height, concatenated).  A block then takes a 64x4 pixel patch per iteration and
 // appends its candidates in 16x4-tile order, so that the 64 rays a traversal wave picks up come from
 // a compact screen region (same BVH nodes, same depth) instead of a 64x1 strip.
+// Dead outputs of one wave's 64-aligned run of 64 rays starting at i0: 1536 + 1536 + 192 + 256 + 256 bytes in lane-consecutive
+// 16-byte stores (per-ray stores -- 8-byte pieces at a 24-byte stride, single mask bytes -- move the same bytes at half the rate).
+template <bool FUSED>
+__device__ __forceinline__ void write_dead_row(int64_t i0, int lane, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2) {
+    const F4 zero{0.f, 0.f, 0.f, 0.f};
+    F4 ones;
+    { const int32_t m1 = -1; memcpy(&ones.x, &m1, 4); ones.y = ones.x; ones.z = ones.x; ones.w = ones.x; }
+    if (!FUSED) {
+        F4* po = reinterpret_cast<F4*>(out_ori + 3 * i0);
+        F4* pd = reinterpret_cast<F4*>(out_dir + 3 * i0);
+        po[lane] = zero; pd[lane] = zero;
+        if (lane < 32) { po[64 + lane] = zero; pd[64 + lane] = zero; }
+        if (lane < 12) reinterpret_cast<F4*>(mask + 3 * i0)[lane] = zero;
+        if (lane >= 16 && lane < 32) reinterpret_cast<F4*>(face2 + i0)[lane - 16] = ones;
+    }
+    if (lane >= 32 && lane < 48) reinterpret_cast<F4*>(face1 + i0)[lane - 32] = ones;
+}
+
 // Raster mode (`rz.views` non-null; needs tile_w > 0): the primary hit of a ray that verifies as a ray of its image's
 // pinhole grid was decided by k_raster (drt_raster.h) -- its key is read here, consumed (reset to empty) and the ray
 // goes to R0 with its face already known; only rays that do not verify take the top-box test and are listed in
@@ -125,31 +143,54 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
     // node is never clobbered: it is then fetched once, through the scalar cache, instead of by four vector loads per ray)
     // patch = 64 pixels wide x 4 rows (every wave reads one full 1536-byte row segment); tiles of 16x4 pixels
     const int vt = ((tid & 63) >> 4) * 64 + (tid >> 6) * 16 + (tid & 15);   // position of this thread's pixel in tile order
-    const int64_t patches_per_row = tile_w > 0 ? tile_w / 64 : 1;
-    for (int64_t base = blockIdx.x * (int64_t)kPathBlock; base < n; base += (int64_t)gridDim.x * kPathBlock) {
-        int64_t i = base + tid;
-        int64_t y = 0, x = 0;
+    // One block per patch of 256 rays (block-uniform 32-bit index arithmetic: n < 2^31).  Not a persistent loop: the kernel
+    // keeps no state between patches, nine patches out of ten only issue their stores, and a pure stream of those stores
+    // runs fastest with one short block per patch (tools/ubench/dead_fill.hip: 0.40 ms vs 0.43 ms per 2.2 GB).
+    const unsigned patches_per_row = tile_w > 0 ? (unsigned)tile_w / 64u : 1u;
+    {
+        const unsigned patch = blockIdx.x;
+        int64_t i = (int64_t)patch * kPathBlock + tid;
+        unsigned y = 0, x = 0;
         if (tile_w > 0) {
-            const int64_t patch = base / kPathBlock;
-            y = 4 * (patch / patches_per_row) + (tid >> 6); x = 64 * (patch % patches_per_row) + (tid & 63);
-            i = y * tile_w + x;
+            const unsigned prow = patch / patches_per_row;
+            y = 4u * prow + (unsigned)(tid >> 6); x = 64u * (patch - prow * patches_per_row) + (unsigned)(tid & 63);
+            i = (int64_t)y * tile_w + x;
+        }
+        if (raster && rz.mode == DRT_GRID_TRUST) {
+            // A patch of a trusted image on which no projected triangle wrote a key: nothing to decide, nothing to load.
+            // The test is block-uniform (every thread reads the same four group bits, which only this block ever clears),
+            // so the block skips the rest of the iteration -- barriers included -- together.
+            const unsigned view = y / (unsigned)rz.img_h;
+            if (rz.views[view].ok && rz.views[view].all) {
+                const int64_t row0 = i - (int64_t)(tid >> 6) * tile_w - (tid & 63);      // first ray of the patch
+                unsigned any = 0;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t g = (row0 + (int64_t)r * tile_w) >> 6;
+                    any |= rz.zmask[g >> 5] >> (g & 31);
+                }
+                if (!(any & 1u)) {
+                    write_dead_row<FUSED>(i - (tid & 63), tid & 63, out_ori, out_dir, mask, face1, face2);
+                    return;
+                }
+            }
         }
         bool cand = false, generic = false;
         int32_t face = -1;
+        unsigned clear_bit = 0;
         f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f};
         if (i < n) {
             unsigned long long key = kRasterEmpty;
             bool trusted = false;
-            int64_t view = 0;
+            unsigned view = 0;
             if (raster) {
-                view = y / rz.img_h;                                   // block-uniform: a patch never straddles two images
+                view = y / (unsigned)rz.img_h;                         // block-uniform: a patch never straddles two images
                 trusted = rz.mode == DRT_GRID_TRUST && rz.views[view].ok && rz.views[view].all;
                 // the 64 rays of a wave are one 64-aligned run: one group bit decides whether any key was written here
                 const unsigned word = rz.zmask[i >> 11], bit = 1u << ((i >> 6) & 31);
                 if (word & bit) {
                     key = rz.zbuf[i];
                     if (key != kRasterEmpty) rz.zbuf[i] = kRasterEmpty;          // consumed: the buffer is empty again for the next call
-                    if ((tid & 63) == 0) atomicAnd(&rz.zmask[i >> 11], ~bit);
+                    clear_bit = bit;                                             // (cleared after the barrier below: see there)
                 }
             }
             if (trusted) {
@@ -167,7 +208,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
                 bool verified = false;
                 if (raster) {
                     ViewModel& vm = rz.views[view];
-                    verified = vm.ok && view_verify(vm, o64, d64, (double)x, (double)(y - view * rz.img_h));
+                    verified = vm.ok && view_verify(vm, o64, d64, (double)x, (double)(y - view * (unsigned)rz.img_h));
                     if (!verified && vm.all) __hip_atomic_store(&vm.all, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (verified) {
@@ -180,16 +221,26 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
             } else if (raster && rz.mode == DRT_GRID_ESTABLISH) {
                 // (fused, establishing the cache) a pixel without a target is not traced, but its ray still counts for `all`
                 ViewModel& vm = rz.views[view];
-                if (vm.all && !(vm.ok && view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)(y - view * rz.img_h))))
+                if (vm.all && !(vm.ok && view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)(y - view * (unsigned)rz.img_h))))
                     __hip_atomic_store(&vm.all, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (!cand) {
-                face1[i] = -1;
-                if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
-            }
+        }
+        // Outputs of the rays that go no further.  A wave whose 64 rays (one 64-aligned run of a row) are ALL dead -- nine
+        // out of ten -- writes its 1536 + 1536 + 192 + 256 + 256 bytes with lane-consecutive 16-byte stores; per-ray stores
+        // (8-byte pieces at a 24-byte stride, single mask bytes) move the same bytes at half the rate.
+        const bool live = i < n;
+        if (tile_w > 0 && __ballot(cand || !live) == 0ull) {
+            write_dead_row<FUSED>(i - (tid & 63), tid & 63, out_ori, out_dir, mask, face1, face2);
+        } else if (live && !cand) {
+            face1[i] = -1;
+            if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
         }
         // nine out of ten patches are pure background: one barrier (with an OR-reduction) instead of the six of the push
-        if (!__syncthreads_or(cand ? 1 : 0)) continue;
+        const int any_cand = __syncthreads_or(cand ? 1 : 0);
+        // the group bits are cleared only now, after every wave of the block has read all four of them: the waves of a block
+        // drift apart over barrier-free iterations, and a wave arriving late must still see what the early one saw
+        if (clear_bit && (tid & 63) == 0) atomicAnd(&rz.zmask[i >> 11], ~clear_bit);
+        if (!any_cand) return;
         int slot;
         if (tile_w > 0) {
             s_flag[vt] = cand ? 1 : 0;
@@ -705,7 +756,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h};
     }
     { StageTimer t(s, st, kStageCull);
-      k_cull<FUSED><<<grid_for(n, kPathBlock, gs), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz); }
+      k_cull<FUSED><<<(unsigned)((n + kPathBlock - 1) / kPathBlock), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz); }
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
     { StageTimer t(s, st, kStageTrace1);
