@@ -280,23 +280,34 @@ def ray_loss(out_ori, out_dir, mask, screen_pixel, valid):
     return _RayLoss.apply(out_ori, out_dir, mask, screen_pixel, valid, link)
 
 
-def edge_tables(F, V):
-    """Edges [E,2], E2F [E,2,3], mean_len (reference DiffRender.py:338-355) on the device of ``F`` / ``V`` by one
-    stable sort of the 3F directed-edge keys -- the reference goes through trimesh's host-side ``group_rows`` /
-    ``edges_face``.  Order as pinned in mesh_io.group_rows_pairs: edges ascend by (min vertex, max vertex); the
-    first face of a pair is the one with the lower directed-edge row.  Asserts watertightness (DiffRender.py:305)."""
-    n_v = V.shape[0]
-    directed = F[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2)           # rows 3f..3f+2 belong to face f
-    lo, hi = directed.min(dim=1).values, directed.max(dim=1).values
-    keys, order = torch.sort(lo * n_v + hi, stable=True)
-    first, second = keys[0::2], keys[1::2]
-    watertight = keys.numel() % 2 == 0 and keys.numel() > 0 and bool(((first == second).all() & (first[1:] > first[:-1]).all()).item())
-    assert watertight, "mesh is not watertight: every edge must be shared by exactly two faces"
-    rows = torch.stack((order[0::2], order[1::2]), dim=1)        # [E,2] directed-edge rows of each edge
-    Edges = torch.stack((lo[rows[:, 0]], hi[rows[:, 0]]), dim=1)
-    E2F = F[rows // 3]
-    mean_len = float((V[directed[:, 0]] - V[directed[:, 1]]).norm(dim=1).mean().item())
-    return Edges, E2F, mean_len
+def edge_tables(F, V, want_rows=False):
+    """Edges [E,2], E2F [E,2,3], mean_len (reference DiffRender.py:338-355) on the device of ``F`` / ``V`` -- the reference
+    goes through trimesh's host-side ``group_rows`` / ``edges_face``.  One stable radix sort of the 3F directed-edge keys
+    in libdrt_hip (``drt_edge_tables``).  Order as pinned in mesh_io.group_rows_pairs: edges ascend by (min vertex, max
+    vertex); the first face of a pair is the one with the lower directed-edge row.  Asserts watertightness
+    (DiffRender.py:305); that check and ``mean_len`` come back in ONE small device->host copy (a topology change is not
+    on the per-iteration path).  ``want_rows``: also the int32 [3F] directed-edge -> unique-edge map."""
+    if not F.is_cuda:
+        raise RuntimeError("edge_tables needs GPU tensors (there is no CPU path in the product)")
+    Fc = F.to(torch.long).contiguous()
+    Vc = _f64c(V.detach(), "V")
+    n_f, n_v = Fc.shape[0], Vc.shape[0]
+    assert (3 * n_f) % 2 == 0 and n_f > 0, "mesh is not watertight: every edge must be shared by exactly two faces"
+    n_e = 3 * n_f // 2
+    dev = Fc.device
+    Edges = torch.empty((n_e, 2), dtype=torch.long, device=dev)
+    E2F = torch.empty((n_e, 2, 3), dtype=torch.long, device=dev)
+    rows = torch.empty(3 * n_f, dtype=torch.int32, device=dev)
+    out = torch.zeros(2, dtype=torch.float64, device=dev)           # [mean_len, status (int32 in the low bytes of word 1)]
+    with torch.cuda.device(dev):
+        ws = torch.empty(int(_lib.lib().drt_edge_tables_workspace(n_f)), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().drt_edge_tables(Fc.data_ptr(), n_f, Vc.data_ptr(), n_v, ws.data_ptr(), Edges.data_ptr(), E2F.data_ptr(),
+                                              rows.data_ptr(), out.data_ptr(), out[1:].data_ptr(), _stream()))
+    host = out.cpu()
+    status = int(host[1:].view(torch.int32)[0])
+    assert status == 0, "mesh is not watertight: every edge must be shared by exactly two faces"
+    mean_len = float(host[0])
+    return (Edges, E2F, mean_len, rows) if want_rows else (Edges, E2F, mean_len)
 
 
 class Scene(StepwiseMixin):
@@ -323,12 +334,37 @@ class Scene(StepwiseMixin):
         self.optix_mesh.update_mesh(opt_F, opt_v)
 
     def init_edge(self):
-        self.Edges, self.E2F, self.mean_len = edge_tables(self.faces, self.vertices.detach())
+        self.Edges, self.E2F, self.mean_len, self._row2edge = edge_tables(self.faces, self.vertices.detach(), want_rows=True)
+
+    def subdivide_midpoint(self, float32_positions=True):
+        """One 1 -> 4 midpoint refinement of the current mesh entirely on the device (a level-of-detail step that is pure
+        subdivision needs no host remesher): new vertices, faces, edge tables and LBVH.  Same vertex / face order as
+        drt_amd.mesh_io.subdivide_midpoint."""
+        V = _f64c(self.vertices.detach(), "vertices")
+        F = self.faces.contiguous()
+        n_v, n_f, n_e = V.shape[0], F.shape[0], self.Edges.shape[0]
+        V2 = torch.empty((n_v + n_e, 3), dtype=torch.float64, device=V.device)
+        F2 = torch.empty((4 * n_f, 3), dtype=torch.long, device=V.device)
+        with torch.cuda.device(V.device):
+            _lib.check(_lib.lib().drt_subdivide_midpoint(F.data_ptr(), n_f, V.data_ptr(), n_v, self.Edges.contiguous().data_ptr(), n_e,
+                                                         self._row2edge.data_ptr(), int(float32_positions), F2.data_ptr(), V2.data_ptr(), _stream()))
+        self._set_topology(V2, F2)
+
+    def _set_topology(self, vertices, faces):
+        """Install device-resident vertices / faces as the new mesh (host record synced lazily, see `mesh`)."""
+        self.vertices, self.faces = vertices, faces
+        self._mesh = mesh_io.TriMesh(np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64))
+        self._mesh_stale = self._faces_stale = True
+        self.init_edge()
+        self.optix_mesh.update_mesh(self.faces.to(torch.int32), self.vertices.detach().to(torch.float32))
 
     @property
     def mesh(self):
         """Host-side mesh record; vertex positions are copied back lazily (the reference pays a
         device->host sync on every iteration for this, DiffRender.py:381)."""
+        if getattr(self, "_faces_stale", False):
+            self._mesh = mesh_io.TriMesh(self.vertices.detach().cpu().numpy(), self.faces.cpu().numpy())
+            self._faces_stale = self._mesh_stale = False
         if self._mesh_stale:
             self._mesh.vertices = self.vertices.detach().cpu().numpy()
             self._mesh_stale = False

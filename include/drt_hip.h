@@ -225,6 +225,25 @@ int drt_mesh_buf_size(const drt_mesh_buf_t* b, int64_t* n_verts, int64_t* n_face
 int drt_mesh_buf_copy(const drt_mesh_buf_t* b, double* verts, int32_t* faces);
 void drt_mesh_buf_free(drt_mesh_buf_t* b);
 
+/* ---- topology: Scene.init_edge (DiffRender.py:338-355; trimesh group_rows / edges_face on the host in the reference) and
+ * the 1 -> 4 midpoint refinement of a level-of-detail step, on the device ---------------------------------------
+ * drt_edge_tables: d_faces int64 [F,3], d_verts float64 [V,3] -> d_edges int64 [3F/2,2] (ascending by (min, max) vertex),
+ * d_e2f int64 [3F/2,2,3] (vertex ids of the two faces of every edge; first the face with the lower directed-edge row),
+ * d_row2edge int32 [3F] (nullable: unique-edge id of directed edge 3f+j = (F[f][j], F[f][(j+1)%3])), *d_mean_len float64
+ * (mean length of the 3F directed edges), *d_status int32: 0, or 1 when some edge is not shared by exactly two faces (the
+ * mesh is not watertight, DiffRender.py:305; the tables are then unspecified).  d_workspace: drt_edge_tables_workspace(F)
+ * bytes of device memory.  Everything is enqueued on `stream`; nothing synchronises for an even 3F. */
+int64_t drt_edge_tables_workspace(int64_t n_faces);
+int drt_edge_tables(const int64_t* d_faces, int64_t n_faces, const double* d_verts, int64_t n_verts,
+                    void* d_workspace, int64_t* d_edges, int64_t* d_e2f, int32_t* d_row2edge,
+                    double* d_mean_len, int32_t* d_status, void* stream);
+/* d_verts_out float64 [V+E,3] = the vertices followed by the midpoint of every unique edge (rounded through float32 when
+ * round_f32, like a PLY round trip); d_faces_out int64 [4F,3]: face f -> (v0,m01,m20), (m01,v1,m12), (m20,m12,v2),
+ * (m01,m12,m20) at rows 4f..4f+3.  d_edges / d_row2edge: from drt_edge_tables of the same mesh. */
+int drt_subdivide_midpoint(const int64_t* d_faces, int64_t n_faces, const double* d_verts, int64_t n_verts,
+                           const int64_t* d_edges, int64_t n_edges, const int32_t* d_row2edge, int round_f32,
+                           int64_t* d_faces_out, double* d_verts_out, void* stream);
+
 /* ---- measurement (bench.py's live per-kernel timing) --------------------------------------------
  * When enabled (on = 1; on = 2 additionally collects the traversal statistics below, which perturbs
  * timing; on = 3 runs the sub-batches of a call one after the other on ONE internal stream instead of two, so that

@@ -24,12 +24,10 @@ def hand():
 
 def test_topology_tables(hand):
     g = golden("hand_topology")
-    # the product builds the same tables with one torch sort on the device (here: on the CPU)
+    # (the product builds these tables with a radix sort in libdrt_hip, tests/test_gpu_topology.py; no CPU path there)
     from drt_amd import diffrender
-    tE, tE2F, tlen = diffrender.edge_tables(torch.tensor(hand.faces), torch.tensor(hand.vertices))
-    assert np.array_equal(tE.numpy(), g["Edges"]) and np.array_equal(tE2F.numpy(), g["E2F"]) and tlen == pytest.approx(float(g["mean_len"]), rel=1e-14)
-    with pytest.raises(AssertionError):
-        diffrender.edge_tables(torch.tensor(hand.faces[:-1]), torch.tensor(hand.vertices))
+    with pytest.raises(RuntimeError):
+        diffrender.edge_tables(torch.tensor(hand.faces), torch.tensor(hand.vertices))
     edges, e2f, mean_len = mesh_io.edge_tables(hand)
     assert hand.is_watertight
     assert np.array_equal(edges, g["Edges"])
