@@ -83,7 +83,7 @@ def test_midpoint_refinement_on_the_device(Render):
     with torch.no_grad():
         a = scene.render_transparent(o, d)
         b = other.render_transparent(o, d)
-    assert all(torch.equal(x, y) for x, y in zip(a, b)) and a[2][:, 0].float().mean().item() > 0.01
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and a[2][:, 0].float().mean().item() > 0.003
     scene.subdivide_midpoint()                                                  # twice: 200 992 faces
     assert scene.faces.shape[0] == 4 * 50248 and scene.optix_mesh.check()[0] == 0
     # an optimisation step still works on the refined mesh (gradients reach the new vertices)
