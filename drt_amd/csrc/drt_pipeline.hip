@@ -129,26 +129,33 @@ struct RasterIn {
     int img_w, img_h;
 };
 
+struct CullShared {
+    unsigned tmp[kPathWaves + 1];
+    uint8_t flag[kPathBlock];
+    int slot[kPathBlock];
+};
+
+// One patch of 256 rays (must be reached by the whole block: barriers).  `prefilled`: the dense outputs already hold the
+// dead values (zeros / -1) everywhere, so dead rays write nothing.
 template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                      const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
-                                                      double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz) {
-    __shared__ unsigned s_tmp[kPathWaves + 1];
-    __shared__ uint8_t s_flag[kPathBlock];
-    __shared__ int s_slot[kPathBlock];
+__device__ __forceinline__ void cull_patch(unsigned patch, bool prefilled, CullShared& sh, const Node4Q* __restrict__ nodes, int n_tris,
+                                           const double* __restrict__ origin, const double* __restrict__ dir,
+                                           const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
+                                           double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                           int32_t* __restrict__ face1, int32_t* __restrict__ face2, const Pipe& p, int tile_w, const RasterIn& rz) {
+    unsigned* s_tmp = sh.tmp;
+    uint8_t* s_flag = sh.flag;
+    int* s_slot = sh.slot;
+    const bool dead_writes = !FUSED && !prefilled;       // (the fused pass reads face ids of listed rays only: nothing to write for dead ones)
     const int tid = threadIdx.x;
     const bool raster = rz.views != nullptr;
     // (`nodes` is a __restrict__ parameter of its own, not the TraceCtx struct, so that the compiler can prove the root
     // node is never clobbered: it is then fetched once, through the scalar cache, instead of by four vector loads per ray)
     // patch = 64 pixels wide x 4 rows (every wave reads one full 1536-byte row segment); tiles of 16x4 pixels
     const int vt = ((tid & 63) >> 4) * 64 + (tid >> 6) * 16 + (tid & 15);   // position of this thread's pixel in tile order
-    // One block per patch of 256 rays (block-uniform 32-bit index arithmetic: n < 2^31).  Not a persistent loop: the kernel
-    // keeps no state between patches, nine patches out of ten only issue their stores, and a pure stream of those stores
-    // runs fastest with one short block per patch (tools/ubench/dead_fill.hip: 0.40 ms vs 0.43 ms per 2.2 GB).
+    // (block-uniform 32-bit index arithmetic: n < 2^31)
     const unsigned patches_per_row = tile_w > 0 ? (unsigned)tile_w / 64u : 1u;
     {
-        const unsigned patch = blockIdx.x;
         int64_t i = (int64_t)patch * kPathBlock + tid;
         unsigned y = 0, x = 0;
         if (tile_w > 0) {
@@ -169,7 +176,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
                     any |= rz.zmask[g >> 5] >> (g & 31);
                 }
                 if (!(any & 1u)) {
-                    write_dead_row<FUSED>(i - (tid & 63), tid & 63, out_ori, out_dir, mask, face1, face2);
+                    if (dead_writes) write_dead_row<FUSED>(i - (tid & 63), tid & 63, out_ori, out_dir, mask, face1, face2);
                     return;
                 }
             }
@@ -229,11 +236,12 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
         // out of ten -- writes its 1536 + 1536 + 192 + 256 + 256 bytes with lane-consecutive 16-byte stores; per-ray stores
         // (8-byte pieces at a 24-byte stride, single mask bytes) move the same bytes at half the rate.
         const bool live = i < n;
-        if (tile_w > 0 && __ballot(cand || !live) == 0ull) {
+        if (!dead_writes) {
+        } else if (tile_w > 0 && __ballot(cand || !live) == 0ull) {
             write_dead_row<FUSED>(i - (tid & 63), tid & 63, out_ori, out_dir, mask, face1, face2);
         } else if (live && !cand) {
             face1[i] = -1;
-            if (!FUSED) write_dead(i, out_ori, out_dir, mask, face2);
+            write_dead(i, out_ori, out_dir, mask, face2);
         }
         // nine out of ten patches are pure background: one barrier (with an OR-reduction) instead of the six of the push
         const int any_cand = __syncthreads_or(cand ? 1 : 0);
@@ -261,6 +269,57 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
             if (g >= 0) rz.gen_list[g] = slot;
         }
     }
+}
+
+// Every patch of the sub-batch, one short block each (the kernel keeps no state between patches; a pure stream of the dead
+// stores runs fastest this way, tools/ubench/dead_fill.hip).
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                      const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
+                                                      double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                      int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz) {
+    __shared__ CullShared sh;
+    cull_patch<FUSED>(blockIdx.x, false, sh, nodes, n_tris, origin, dir, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
+}
+
+// DRT_GRID_TRUST: only the patches k_patch_list selected -- those on which a projected triangle wrote a key, and all
+// patches of images that are not trusted -- with the dense outputs pre-filled by memsets: the other nine tenths of the
+// rays are never touched by a thread.
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock, 8) k_cull_listed(const uint32_t* __restrict__ patches, const unsigned* __restrict__ n_patches,
+                                                             const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                             const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
+                                                             double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                             int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz) {
+    __shared__ CullShared sh;
+    const unsigned count = *n_patches;
+    for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
+        cull_patch<FUSED>(patches[k], true, sh, nodes, n_tris, origin, dir, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
+        __syncthreads();
+    }
+}
+
+// Which patches k_cull_listed has to visit: one thread per patch.
+__global__ void __launch_bounds__(kPathBlock) k_patch_list(unsigned n_patches, int tile_w, RasterIn rz, uint32_t* __restrict__ list, unsigned* count) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    const unsigned patch = blockIdx.x * kPathBlock + threadIdx.x;
+    bool take = false;
+    if (patch < n_patches) {
+        const unsigned ppr = (unsigned)tile_w / 64u, prow = patch / ppr;
+        const unsigned view = (4u * prow) / (unsigned)rz.img_h;
+        take = true;
+        if (rz.views[view].ok && rz.views[view].all) {
+            const int64_t row0 = (int64_t)(4u * prow) * tile_w + 64u * (patch - prow * ppr);
+            unsigned any = 0;
+            for (int r = 0; r < 4; ++r) {
+                const int64_t g = (row0 + (int64_t)r * tile_w) >> 6;
+                any |= rz.zmask[g >> 5] >> (g & 31);
+            }
+            take = (any & 1u) != 0;
+        }
+    }
+    const int slot = block_push(take, count, s_tmp);
+    if (slot >= 0) list[slot] = patch;
 }
 
 // R0 -> R1: primary hit -> float64 bounce #1 -> refracted ray
@@ -756,7 +815,20 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h};
     }
     { StageTimer t(s, st, kStageCull);
-      k_cull<FUSED><<<(unsigned)((n + kPathBlock - 1) / kPathBlock), kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz); }
+      const unsigned n_patches = (unsigned)((n + kPathBlock - 1) / kPathBlock);
+      if (rz.views && grid_mode == DRT_GRID_TRUST) {
+          // dead values everywhere first (plain memsets run at the full write rate), then only the patches that matter
+          if (!FUSED) {
+              (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
+              (void)hipMemsetAsync(mask, 0, 3 * n, st);
+              (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st);
+          }
+          uint32_t* list = reinterpret_cast<uint32_t*>(p.redo);          // free until the first k_trace of this sub-batch
+          k_patch_list<<<(n_patches + kPathBlock - 1) / kPathBlock, kPathBlock, 0, st>>>(n_patches, tile_w, rz, list, p.count + 7);
+          k_cull_listed<FUSED><<<gs, kPathBlock, 0, st>>>(list, p.count + 7, pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
+      } else {
+          k_cull<FUSED><<<n_patches, kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
+      } }
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
     { StageTimer t(s, st, kStageTrace1);
