@@ -57,21 +57,44 @@ def per_view_mesh_bytes(V, F):
     return 24 * V + 12 * V + 12 * F + 48 * F + 64 * (F - 1) + 24 * V
 
 
-def roofline(prof, args, P, n_local_views, V, F, elapsed, world):
-    """Per-kernel live timing (hipEvents on the launch stream, drt_profile_*) -> roofline of the kernel
-    that takes the most time, plus every stage for context.  Algorithmic bytes follow DESIGN.md section 4:
-    float64 ray I/O of the reference's tensor signature + queue indices; mesh/BVH gathers are cache-resident
-    and counted once per launch (per_view_mesh_bytes)."""
+VALU_PEAK = 256 * 4 * 2.4e9 / 2     # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32 units, two cycles per wave-instruction (MI355X_MICROARCH.md)
+# which bench.py stage is which kernel(s) in a rocprofv3 trace
+KERNELS = {"k_trace<closest>": ("trace1", "trace2"), "k_trace<any>": ("trace3",), "fill + k_cull": ("cull",), "k_raster": ("raster",),
+           "k_shade1": ("shade1",), "k_shade2": ("shade2",), "k_finish": ("finish",), "k_render_bwd": ("backward", "collect"),
+           "k_loss_bwd_fused": ("loss_bwd_fused",), "build": ("build",)}
+PMC_NAMES = {"k_trace<closest>": ("k_trace<false, 0>",), "k_trace<any>": ("k_trace<true, 0>",)}
+
+
+def _pmc(mode):
+    path = os.path.join(ROOT, "profiles", "pmc.json")        # tools/make_pmc_json.py, from rocprofv3 --pmc passes of this command
+    try:
+        return json.load(open(path)).get(mode, {})
+    except Exception:
+        return {}
+
+
+def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None):
+    """Per-kernel live timing (hipEvents on the launch streams, drt_profile_*) -> the kernel that takes the most time, BY
+    KERNEL NAME (the two closest-hit traversals are one kernel), with the bound that applies to it, and the HBM-streaming
+    stage beside it.
+
+    * `k_trace` walks an L2-resident tree: its bound is VALU issue (measured: doubling the slab arithmetic of an inner visit
+      costs +24 %).  achieved = VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of the same
+      command, profiles/pmc.json) / the live launch time; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles.
+    * `fill + k_cull` (dead values into the dense float64 outputs + the patches that matter) is the HBM stage: algorithmic
+      bytes = 59 B per ray written + (48 read + 36 list) per primary hit, DESIGN.md section 4.
+    Stage times of the timed region overlap (two internal streams); `alone` = the same steps with the streams serialised."""
     n = P * n_local_views * args.steps                 # rays through the pipeline in the timed region
     it = {k: v[2] for k, v in prof.items()}
-    c, h, s2 = it["trace1"], it["trace2"], it["trace3"]          # candidates, refracted primary hits, exit rays
+    h0 = it["shade1"]                                  # primary hits (list R0)
+    c, h, s2 = it["trace1"], it["trace2"], it["trace3"]          # rays left to the tree, refracted primary hits, exit rays
     v = it["loss_bwd_fused"] if args.mode == "fused" else it["backward"]
     fused = args.mode == "fused"
     # bytes per item: list entry = 4 (index) + 24 (float32 ray) + 4 (face); float64 ray = 48; dense outputs = 51 + 8 (face ids)
     alg = {
-        "cull": (49 * n + 28 * c) if fused else (48 * n + 59 * (n - c) + 28 * c),
+        "cull": (0 if fused else 59 * n) + (48 + 36 + 8) * h0,
         "trace1": 28 * c, "trace2": 28 * h, "trace3": 28 * s2,
-        "shade1": (8 + 48 + 4) * c + 28 * h + (0 if fused else 59 * (c - h)),
+        "shade1": (8 + 48 + 4) * h0 + 28 * h,
         "shade2": (8 + 48 + 4) * h + 28 * s2 + (4 * h if fused else 59 * h),
         "finish": 8 * s2 + 4 * v,
         "collect": 4 * n + 4 * v,
@@ -79,32 +102,77 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world):
         "loss_bwd_fused": (8 + 48 + 8 + 24) * s2 + 144 * s2,
         "build": per_view_mesh_bytes(V, F) * args.steps,
         # projected primary visibility: every image reads the triangle records once; per written key a 24-byte ray and a 16-byte atomic
-        "raster": 48 * F * n_local_views * args.steps + 40 * c,
+        "raster": 48 * F * n_local_views * args.steps + 40 * h0,
     }
-    stages = {}
-    for k, (ms, launches, items) in prof.items():
-        if launches == 0:
-            continue
-        mesh_b = per_view_mesh_bytes(V, F) * launches if k in ("trace1", "trace2", "trace3") else 0
-        gbs = (alg[k] + mesh_b) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        stages[k] = {"ms_per_step": round(ms / args.steps, 4), "avg_launch_ms": round(ms / launches, 4), "launches": launches,
+
+    def table(pr):
+        st = {}
+        for k, (ms, launches, items) in pr.items():
+            if launches == 0:
+                continue
+            mesh_b = per_view_mesh_bytes(V, F) * launches if k in ("trace1", "trace2", "trace3") else 0
+            gbs = (alg.get(k, 0) + mesh_b) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            st[k] = {"ms_per_step": round(ms / args.steps, 4), "avg_launch_ms": round(ms / launches, 4), "launches": launches,
                      "items_per_launch": items // launches, "alg_GBps": round(gbs, 1)}
-    dom = max((k for k in stages if k != "build"), key=lambda k: stages[k]["ms_per_step"])
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC FETCH_SIZE/WRITE_SIZE of the same command (tools/profile.sh)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(args.mode, {}).get(dom)
-        except Exception:
-            traffic = None
+        return st
+
+    stages = table(prof)
+    alone = table(prof_alone) if prof_alone else {}
+    by_kernel = {}
+    for name, members in KERNELS.items():
+        ms = sum(stages[m]["ms_per_step"] for m in members if m in stages)
+        if ms > 0:
+            by_kernel[name] = {"ms_per_step": round(ms, 4), "launches": sum(stages[m]["launches"] for m in members if m in stages),
+                               "alone_ms_per_step": round(sum(alone[m]["ms_per_step"] for m in members if m in alone), 4) if alone else None}
+    dom = max((k for k in by_kernel if k != "build"), key=lambda k: by_kernel[k]["ms_per_step"])
+    pmc = _pmc(args.mode)
+
+    def issue_entry(name):
+        """VALU-issue bound of a traversal kernel: wave-instructions per launch (PMC) over the live launch time."""
+        members = [m for m in KERNELS[name] if m in stages and stages[m]["items_per_launch"] > 0]
+        launches = sum(stages[m]["launches"] for m in members)
+        ms = sum(stages[m]["ms_per_step"] for m in members) * args.steps
+        rec = next((pmc[q] for q in PMC_NAMES.get(name, ()) if q in pmc), None)
+        out = {"kernel": name, "bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK / 1e9, 1), "avg_launch_ms": round(ms / max(1, launches), 4),
+               "achieved": None, "frac": None, "valu_instr_per_launch": None}
+        if rec and launches and ms > 0 and "SQ_INSTS_VALU" in rec:
+            ach = rec["SQ_INSTS_VALU"] / (ms / launches * 1e-3)
+            out.update(achieved=round(ach / 1e9, 1), frac=round(ach / VALU_PEAK, 4), valu_instr_per_launch=int(rec["SQ_INSTS_VALU"]),
+                       valu_busy_quadcycles_per_launch=rec.get("SQ_ACTIVE_INST_VALU"), salu_instr_per_launch=rec.get("SQ_INSTS_SALU"),
+                       l2_hit=round(rec["TCC_HIT_sum"] / (rec["TCC_HIT_sum"] + rec["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in rec and "TCC_MISS_sum" in rec else None,
+                       hbm_bytes_per_launch=rec.get("hbm_bytes_per_launch"))
+            if alone:
+                ms_a = sum(alone[m]["ms_per_step"] for m in members if m in alone) * args.steps
+                out["alone"] = {"avg_launch_ms": round(ms_a / launches, 4), "achieved": round(rec["SQ_INSTS_VALU"] / (ms_a / launches * 1e-3) / 1e9, 1),
+                                "frac": round(rec["SQ_INSTS_VALU"] / (ms_a / launches * 1e-3) / VALU_PEAK, 4)}
+        return out
+
+    def hbm_entry(stage):
+        st = stages[stage]
+        traffic = None
+        if pmc:       # HBM bytes of the kernels of the stage (memset fills + k_patch_list + k_cull_listed), per stage launch
+            names = [q for q in pmc if q.startswith(("__amd_rocclr_fill", "k_patch_list", "k_cull"))]
+            if names and all("hbm_bytes_per_launch" in pmc[q] for q in names):
+                per_step = sum(pmc[q]["hbm_bytes_per_launch"] * pmc[q]["launches"] for q in names)
+                ref_launches = pmc.get("k_patch_list", {}).get("launches") or pmc.get(next((q for q in names if q.startswith("k_cull")), ""), {}).get("launches")
+                traffic = round(per_step / ref_launches) if ref_launches else None
+        out = {"kernel": "fill + k_cull", "bound": "hbm", "achieved": st["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(st["alg_GBps"] / HBM_PEAK_GBS, 5),
+               "traffic": traffic, "alg_bytes_per_launch": round(alg[stage] / st["launches"]), "avg_launch_ms": st["avg_launch_ms"]}
+        if stage in alone:
+            out["alone"] = {"achieved": alone[stage]["alg_GBps"], "frac": round(alone[stage]["alg_GBps"] / HBM_PEAK_GBS, 5), "avg_launch_ms": alone[stage]["avg_launch_ms"]}
+        return out
+
     step_alg = ((73 if fused else B_STEP) * P + per_view_mesh_bytes(V, F)) * args.views
-    ach = stages[dom]["alg_GBps"]
-    return {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "avg_launch_ms": stages[dom]["avg_launch_ms"], "stages": stages,
-            "whole_step_alg_GBps_per_gpu": round(step_alg / (elapsed / args.steps) / 1e9 / world, 1),
-            "note": "per-kernel times are hipEvent pairs on the launch streams over the timed region; sub-batches run on two internal "
-                    "streams, so stage durations overlap (their sum exceeds the step). Traversal stages are issue/latency-bound on a "
-                    "cache-resident BVH (see node_visits_per_ray, lane_utilisation); k_cull is the HBM-streaming stage."}
+    top = issue_entry(dom) if dom.startswith("k_trace") else hbm_entry("cull")
+    top.update({"dominant_by_kernel_name": dom, "kernels": by_kernel, "hbm": hbm_entry("cull"),
+                "traversal": {k: issue_entry(k) for k in ("k_trace<closest>", "k_trace<any>") if k in by_kernel},
+                "stages": stages, "stages_alone_avg_launch_ms": {k: v["avg_launch_ms"] for k, v in alone.items()} if alone else None,
+                "whole_step_alg_GBps_per_gpu": round(step_alg / (elapsed / args.steps) / 1e9 / world, 1),
+                "note": "times are hipEvent pairs on the launch streams over the timed region; sub-batches run on two internal streams, so stage "
+                        "durations overlap (`alone`: the same steps, untimed, with the streams serialised). The kernel that takes the most time is "
+                        "the closest-hit traversal: VALU-issue bound on an L2-resident tree (see node_visits_per_ray, lane_utilisation); the HBM "
+                        "stage is the fill of the dense outputs + k_cull."})
+    return top
 
 
 def cpu_baseline(mesh, center, extent):
@@ -363,15 +431,7 @@ def main():
         prof_iso = scene.optix_mesh.profile_read()
     scene.optix_mesh.profile_enable(0)
     if rank == 0:
-        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world)
-        if prof_iso:
-            iso = roofline(prof_iso, args, P, len(my_views), n_verts, n_faces, elapsed, world)
-            dom = out["roofline"]["kernel"][2:]
-            out["roofline"]["isolated"] = {
-                "kernel": "k_" + dom, "achieved": iso["stages"][dom]["alg_GBps"], "frac": round(iso["stages"][dom]["alg_GBps"] / HBM_PEAK_GBS, 5),
-                "avg_launch_ms": iso["stages"][dom]["avg_launch_ms"],
-                "stages_avg_launch_ms": {k: v["avg_launch_ms"] for k, v in iso["stages"].items()},
-                "note": "same K steps, untimed, with the internal pipelines serialised on one stream: each kernel's duration and rate when it has the GPU to itself"}
+        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso)
         for k, (ws, ls, rf, mx) in tstats.items():
             if ws and k in out["roofline"]["stages"]:
                 out["roofline"]["stages"][k].update({"node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),

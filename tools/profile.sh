@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of bench.py.
+# (PMC passes: one warm-up step -- it ESTABLISHES the grid verdict -- and two steady-state steps; per-kernel means.)
 # Big raw outputs stay in /tmp; only summaries land in gpurun_out/<tag>/.
 # usage: tools/profile.sh <tag> [bench args...]
 set -u
@@ -49,11 +50,12 @@ with open(out + '/kernel_summary.txt', 'w') as o:
 PY
 run_pmc () {  # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
   local f=$(find "$W/$name" -name '*counter_collection.csv' | head -1)
-  if [ -n "$f" ]; then python tools/pmc_summary.py "$f" k_ > "$O/$name.txt"; else echo "no counter file" > "$O/$name.txt"; fi
+  if [ -n "$f" ]; then python tools/pmc_summary.py "$f" > "$O/$name.txt"; else echo "no counter file" > "$O/$name.txt"; fi
 }
 BARGS=("$@")
+if [ -n "${PROFILE_SKIP_PMC:-}" ]; then du -sh "$O"; grep -A30 "last 3 steps" "$O/kernel_summary.txt"; exit 0; fi
 run_pmc pmc_sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run_pmc pmc_sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR
 run_pmc pmc_tcc TCC_HIT_sum TCC_MISS_sum
@@ -70,7 +72,7 @@ out = sys.argv[1]
 def parse(path, counter):
     res, cur = {}, None
     for line in open(path):
-        m = re.match(r"(?:void )?(k_\w+(?:<\w+>)?)\s+launches=(\d+)", line)
+        m = re.match(r"(?:void )?((?:k_|__amd_rocclr_fill)\w*(?:<[^>]*>)?)\s+launches=(\d+)", line)
         if m:
             cur = (m.group(1), int(m.group(2)))
             continue
@@ -84,7 +86,7 @@ try:
     for k in f:
         fetch = 2.0 * f[k][0] * 1024 / f[k][1]
         write = w.get(k, (0.0, 1))[0] * 1024 / max(1, w.get(k, (0.0, 1))[1])
-        t[k[2:]] = {"fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write), "hbm_bytes_per_launch": round(fetch + write), "launches": f[k][1]}
+        t[k] = {"fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write), "hbm_bytes_per_launch": round(fetch + write), "launches": f[k][1]}
     json.dump(t, open(out + "/traffic_raw.json", "w"), indent=1)
 except Exception as e:
     print("traffic summary failed:", e)
