@@ -1,16 +1,24 @@
 #!/bin/bash
-# Copy the summaries of tools/profile.sh runs (gpurun_out/final, gpurun_out/final_fused) into profiles/.
-# usage: tools/collect_profiles.sh <prefix>     e.g. r01_final
+# Copy the summaries of tools/profile.sh runs into profiles/ (tracked).
+# usage: tools/collect_profiles.sh <prefix> [<tag of the drop-in run> [<tag of the serialised run>]]     e.g. r02 r02 r02_serial
 set -eu
-P=${1:-r01_final}
+P=${1:-r02}; T=${2:-$P}; S=${3:-}
 cd "$(dirname "$0")/.."
-for m in "" "_fused"; do
-  S=gpurun_out/final$m
-  cp $S/kernel_summary.txt profiles/${P}${m}_kernel_summary.txt
-  cp $S/kernel_stats.csv profiles/${P}${m}_rocprofv3_kernel_stats.csv
-  cp $S/traffic_raw.json profiles/${P}${m}_traffic_raw.json
-  cat $S/pmc_sq1.txt $S/pmc_sq2.txt $S/pmc_tcc.txt $S/pmc_tcp.txt $S/pmc_fetch.txt $S/pmc_write.txt $S/pmc_grbm.txt > profiles/${P}${m}_pmc.txt
-done
-python tools/make_traffic.py gpurun_out/final/traffic_raw.json gpurun_out/final_fused/traffic_raw.json profiles/traffic.json
-cp gpurun_out/bench_final.json profiles/${P}_bench.json 2>/dev/null || true
-cp gpurun_out/bench_final_fused.json profiles/${P}_fused_bench.json 2>/dev/null || true
+cp gpurun_out/$T/kernel_summary.txt profiles/${P}_kernel_summary.txt
+cp gpurun_out/$T/kernel_stats.csv profiles/${P}_rocprofv3_kernel_stats.csv
+cp gpurun_out/$T/traffic_raw.json profiles/${P}_traffic_raw.json
+cat gpurun_out/$T/pmc_sq1.txt gpurun_out/$T/pmc_sq2.txt gpurun_out/$T/pmc_tcc.txt gpurun_out/$T/pmc_tcp.txt gpurun_out/$T/pmc_fetch.txt gpurun_out/$T/pmc_write.txt gpurun_out/$T/pmc_grbm.txt \
+  | python -c "
+import sys
+keep = False
+for line in sys.stdin:
+    if not line.startswith(' '):
+        keep = line.startswith(('k_', 'void k_', '__amd_rocclr_fill'))
+    if keep:
+        sys.stdout.write(line)
+" > profiles/${P}_pmc.txt
+python tools/make_pmc_json.py gpurun_out/$T profiles/pmc.json dropin
+if [ -n "$S" ]; then
+  cp gpurun_out/$S/kernel_summary.txt profiles/${P}_serial_kernel_summary.txt
+  cp gpurun_out/$S/kernel_stats.csv profiles/${P}_serial_rocprofv3_kernel_stats.csv
+fi
