@@ -604,6 +604,33 @@ __global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restric
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
 }
 
+// ray_loss over the forward's list of completed paths (the rays with mask = 1) instead of a pass over all N rays: loss and
+// the list of contributing rows (valid target) for drt_render_backward_ray_loss.  O(valid paths), a few per cent of N.
+__global__ void __launch_bounds__(256) k_ray_loss_listed(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
+                                                         const double* __restrict__ screen_pixel, const uint8_t* __restrict__ valid,
+                                                         const int32_t* __restrict__ paths, const int64_t* __restrict__ n_paths, double* loss,
+                                                         int32_t* __restrict__ rows, unsigned* n_rows) {
+    __shared__ unsigned s_tmp[kPathWaves + 1];
+    const int64_t n = *n_paths;
+    double acc = 0.0;
+    for (int64_t base = blockIdx.x * 256ll; base < n; base += (int64_t)gridDim.x * 256) {
+        const int64_t k = base + threadIdx.x;
+        bool on = false;
+        int32_t i = 0;
+        if (k < n) {
+            i = paths[k];
+            on = valid[i] != 0;
+            if (on) { d3 g; acc += ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g); }
+        }
+        if (rows) {
+            const int slot = block_push(on, n_rows, s_tmp);
+            if (slot >= 0) rows[slot] = i;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+}
+
 // x[list[k], 0..2] *= *scale
 __global__ void __launch_bounds__(256) k_scale_rows3(double* __restrict__ x, const int32_t* __restrict__ list, const unsigned* __restrict__ n_ptr,
                                                      const double* __restrict__ scale) {
@@ -990,6 +1017,18 @@ int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t
     if ((d_list == nullptr) != (d_n_list == nullptr)) return fail(DRT_E_INVALID, "d_list and d_n_list go together");
     k_ray_loss<<<grid_for((n_rays + kLossRays - 1) / kLossRays, kPathBlock, 4096), kPathBlock, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays,
                                                                                           d_loss, d_grad_out_dir, d_list, d_n_list);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_ray_loss_listed(const double* d_out_ori, const double* d_out_dir, const double* d_screen_pixel, const uint8_t* d_valid,
+                        const int32_t* d_paths, const int64_t* d_n_paths, int64_t n_rays, double* d_loss,
+                        int32_t* d_rows, uint32_t* d_n_rows, void* stream) {
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_out_ori || !d_out_dir || !d_screen_pixel || !d_valid || !d_paths || !d_n_paths || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
+    if ((d_rows == nullptr) != (d_n_rows == nullptr)) return fail(DRT_E_INVALID, "d_rows and d_n_rows go together");
+    k_ray_loss_listed<<<1024, 256, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_screen_pixel, d_valid, d_paths, d_n_paths, d_loss, d_rows, d_n_rows);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

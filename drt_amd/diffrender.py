@@ -124,6 +124,8 @@ class _GradLink:
     def __init__(self):
         self.pending = []
         self._token = None
+        self.paths = None
+        self.mask = None
 
     def token(self, n, device):
         if self._token is None or self._token.shape[0] != n:
@@ -161,6 +163,8 @@ class _RenderTransparent(torch.autograd.Function):
         ctx.scene = scene
         ctx.ior = (float(ior_int), float(ior_ext))
         ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)
+        if link is not None:
+            link.paths = (valid_idx, n_valid)        # the rays with mask = 1: ray_loss walks this list instead of all N rays
         # an output the loss does not use must reach backward() as None, not as a materialised [N,3] float64 zero tensor:
         # the reference's ray_loss detaches out_ori (optim.py:100), and filling 1.8 GB of zeros per step cost 0.3 ms
         ctx.set_materialize_grads(False)
@@ -211,8 +215,13 @@ class _RayLoss(torch.autograd.Function):
         rows = torch.empty(n, dtype=torch.int32, device=oo.device) if need else None
         n_rows = torch.zeros(1, dtype=torch.int32, device=oo.device) if need else None
         with torch.cuda.device(oo.device):
-            _lib.check(_lib.lib().drt_ray_loss(oo.data_ptr(), od.data_ptr(), m.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
-                                               loss.data_ptr(), _lib.ptr(g), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
+            if (link is not None and link.paths is not None and link.paths[0] is not None and link.mask is not None
+                    and link.mask() is mask and mask._version == 0):     # the forward's own mask, untouched: its list of set rows is exact
+                _lib.check(_lib.lib().drt_ray_loss_listed(oo.data_ptr(), od.data_ptr(), sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(),
+                                                          link.paths[1].data_ptr(), n, loss.data_ptr(), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
+            else:
+                _lib.check(_lib.lib().drt_ray_loss(oo.data_ptr(), od.data_ptr(), m.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
+                                                   loss.data_ptr(), _lib.ptr(g), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
         ctx.save_for_backward(g, rows, n_rows, sp if (need and link is not None) else None)
         ctx.applied = None                       # scale already multiplied into the saved rows (see backward)
         ctx.n_rays = n
@@ -397,6 +406,7 @@ class Scene(StepwiseMixin):
         grid = _grid_cache(origin, ray_dir, origin.shape[0], *_tile_hint(origin.shape[0])) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
         out_ori, out_dir, mask = _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR, link, grid)
         out_dir._drt_link = link            # lets ray_loss hand its gradient over as a row list (see _GradLink)
+        link.mask = weakref.ref(mask)
         return out_ori, out_dir, mask
 
     def ray_loss_fused(self, origin, ray_dir, screen_pixel, valid):

@@ -122,6 +122,12 @@ int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t
                  const double* d_screen_pixel, const uint8_t* d_valid, int64_t n_rays,
                  double* d_loss, double* d_grad_out_dir,
                  int32_t* d_list, uint32_t* d_n_list, void* stream);
+/* The same loss over a list of the rays with mask = 1 (drt_render_forward's d_valid_idx / d_n_valid) instead of a pass over
+ * all N rays: *d_loss += ..., and (optional, both or neither) d_rows / *d_n_rows (uint32, zero it first) = the listed rays that
+ * also have a target -- what drt_render_backward_ray_loss takes. */
+int drt_ray_loss_listed(const double* d_out_ori, const double* d_out_dir, const double* d_screen_pixel,
+                        const uint8_t* d_valid, const int32_t* d_paths, const int64_t* d_n_paths, int64_t n_rays,
+                        double* d_loss, int32_t* d_rows, uint32_t* d_n_rows, void* stream);
 /* Backward helper of the loss: x[list[k], 0..2] *= *d_scale for the *d_n_list rows listed (the rows
  * drt_ray_loss reported as contributing) -- rescales d loss / d out_dir by the incoming scalar
  * gradient without another pass over the dense [N,3] tensor. */
