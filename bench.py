@@ -151,10 +151,10 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
         st = stages[stage]
         traffic = None
         if pmc:       # HBM bytes of the kernels of the stage (memset fills + k_patch_list + k_cull_listed), per stage launch
-            names = [q for q in pmc if q.startswith(("__amd_rocclr_fill", "k_patch_list", "k_cull"))]
+            names = [q for q in pmc if q.startswith(("__amd_rocclr_fill", "k_patch_list", "k_cull_listed"))]    # (k_cull<...> is the establishing step's kernel)
             if names and all("hbm_bytes_per_launch" in pmc[q] for q in names):
                 per_step = sum(pmc[q]["hbm_bytes_per_launch"] * pmc[q]["launches"] for q in names)
-                ref_launches = pmc.get("k_patch_list", {}).get("launches") or pmc.get(next((q for q in names if q.startswith("k_cull")), ""), {}).get("launches")
+                ref_launches = pmc.get("k_patch_list", {}).get("launches")
                 traffic = round(per_step / ref_launches) if ref_launches else None
         out = {"kernel": "fill + k_cull", "bound": "hbm", "achieved": st["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(st["alg_GBps"] / HBM_PEAK_GBS, 5),
                "traffic": traffic, "alg_bytes_per_launch": round(alg[stage] / st["launches"]), "avg_launch_ms": st["avg_launch_ms"]}
