@@ -284,19 +284,81 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_cull(const Node4Q* __restrict
 
 // DRT_GRID_TRUST: only the patches k_patch_list selected -- those on which a projected triangle wrote a key, and all
 // patches of images that are not trusted -- with the dense outputs pre-filled by memsets: the other nine tenths of the
-// rays are never touched by a thread.
+// rays are never touched by a thread.  The hits of a trusted patch go to R0 through an LDS stage (index, float32 ray, face)
+// that reserves list space once per ~600 entries: one returning atomic per patch -- ~15 000 per launch on ONE counter word,
+// served at ~90 per microsecond -- was most of this kernel's time.
+struct StageFace {
+    StageMem m;
+    int32_t face[kStageCap];
+};
 template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock, 8) k_cull_listed(const uint32_t* __restrict__ patches, const unsigned* __restrict__ n_patches,
-                                                             const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                             const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
-                                                             double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                             int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz) {
+__global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __restrict__ patches, const unsigned* __restrict__ n_patches,
+                                                           const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                           const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
+                                                           double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                           int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz) {
     __shared__ CullShared sh;
+    __shared__ StageFace st;
+    stage_init(st.m);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int vt = ((tid & 63) >> 4) * 64 + (tid >> 6) * 16 + (tid & 15);   // position of this thread's pixel in tile order
+    const unsigned ppr = (unsigned)tile_w / 64u;
+    auto flush = [&]() {                                    // whole block; st.m.n stable
+        const unsigned cnt = st.m.n;
+        if (tid == 0) st.m.base = cnt ? atomicAdd(&p.count[0], cnt) : 0u;
+        __syncthreads();
+        const unsigned base = st.m.base;
+        for (unsigned k = tid; k < cnt; k += kPathBlock) { p.r0.idx[base + k] = st.m.idx[k]; p.r0.face[base + k] = st.face[k]; }
+        for (unsigned k = tid; k < 6u * cnt; k += kPathBlock) p.r0.ray[6 * (int64_t)base + k] = st.m.ray[k];
+        __syncthreads();
+        if (tid == 0) st.m.n = 0u;
+        __syncthreads();
+    };
     const unsigned count = *n_patches;
     for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
-        cull_patch<FUSED>(patches[k], true, sh, nodes, n_tris, origin, dir, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
+        const unsigned patch = patches[k];
+        const unsigned prow = patch / ppr;
+        const unsigned y = 4u * prow + (unsigned)wave, x = 64u * (patch - prow * ppr) + (unsigned)lane;
+        const unsigned view = y / (unsigned)rz.img_h;
+        if (!(rz.views[view].ok && rz.views[view].all)) {   // an image that is not trusted (block-uniform): the general per-ray path
+            cull_patch<FUSED>(patch, true, sh, nodes, n_tris, origin, dir, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
+            __syncthreads();
+            continue;
+        }
+        const int64_t i = (int64_t)y * tile_w + x;
+        unsigned long long key = kRasterEmpty;
+        const unsigned word = rz.zmask[i >> 11], bit = 1u << ((i >> 6) & 31);
+        if (word & bit) {
+            key = rz.zbuf[i];
+            if (key != kRasterEmpty) rz.zbuf[i] = kRasterEmpty;            // consumed: the buffer is empty again for the next call
+        }
+        const bool cand = key != kRasterEmpty && (!FUSED || valid[i]);
+        // rank of this thread's hit among the patch's hits, in 16x4-tile order
+        sh.flag[vt] = cand ? 1 : 0;
         __syncthreads();
+        if ((word & bit) && lane == 0) atomicAnd(&rz.zmask[i >> 11], ~bit);  // (after the barrier: every wave has read its bit)
+        const bool mine = sh.flag[tid] != 0;
+        const unsigned long long bm = __ballot(mine);
+        if (lane == 0) sh.tmp[wave] = (unsigned)__popcll(bm);
+        __syncthreads();
+        unsigned before = 0, tot = 0;
+        for (int w = 0; w < kPathWaves; ++w) { const unsigned c = sh.tmp[w]; if (w < wave) before += c; tot += c; }
+        sh.slot[tid] = mine ? (int)(before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))) : -1;
+        __syncthreads();
+        if (cand) {
+            const unsigned slot = st.m.n + (unsigned)sh.slot[vt];
+            const f3 o = to_f32(load_d3(origin, i)), d = to_f32(load_d3(dir, i));
+            st.m.idx[slot] = (int32_t)i;
+            float* e = st.m.ray + 6 * slot;
+            e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z;
+            st.face[slot] = (int32_t)(uint32_t)key;
+        }
+        __syncthreads();
+        if (tid == 0) st.m.n += tot;
+        __syncthreads();
+        if (st.m.n > kStageCap - kPathBlock) flush();
     }
+    flush();
 }
 
 // Which patches k_cull_listed has to visit: one thread per patch.
