@@ -62,7 +62,7 @@ struct RasterLane {            // what a lane publishes for the wave: its triang
 __global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris, int n_tris, ViewModel* views,
                                                 const double* __restrict__ dir, int w, int h,
                                                 unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask,
-                                                BigItem* __restrict__ big, unsigned* big_count, unsigned big_cap) {
+                                                BigItem* __restrict__ big, unsigned* big_count, unsigned big_cap, int pass) {
     __shared__ RasterLane s_lane[256];
     const int view = blockIdx.y;
     const ViewModel vm = views[view];
@@ -80,11 +80,20 @@ __global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris,
         // relative to the origin, in float32 (|error| ~1e-4 px at these magnitudes, the pad is 0.25 px)
         const f3 a{t.v0x - o32.x, t.v0y - o32.y, t.v0z - o32.z};
         const f3 b{a.x + t.e1x, a.y + t.e1y, a.z + t.e1z}, c{a.x + t.e2x, a.y + t.e2y, a.z + t.e2z};
+        // Two launches: triangles facing the camera first (pass 0), the others second (pass 1).  Every triangle is handled in
+        // exactly one of them, so the result is the same minimum; but a pixel's closest hit is nearly always a front face,
+        // and the second launch sees the finished keys of the first: its read-before-atomic check then skips almost every
+        // back face, which cuts the 64-bit atomics -- what bounds this kernel -- by more than half.
+        const f3 nrm = cross(f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z});
+        const bool back = dot(a, nrm) > 0.0f;
+        if ((pass == 1) != back) count = -1;
         const float m0 = (float)vm.minv[0], m1 = (float)vm.minv[1], m2 = (float)vm.minv[2], m3 = (float)vm.minv[3], m4 = (float)vm.minv[4],
                     m5 = (float)vm.minv[5], m6 = (float)vm.minv[6], m7 = (float)vm.minv[7], m8 = (float)vm.minv[8];
         const float az = fmaf(m6, a.x, fmaf(m7, a.y, m8 * a.z)), bz = fmaf(m6, b.x, fmaf(m7, b.y, m8 * b.z)), cz = fmaf(m6, c.x, fmaf(m7, c.y, m8 * c.z));
         const float zmin = fminf(az, fminf(bz, cz));
-        if (!(zmin > 1e-20f)) {        // the camera plane cuts (or touches) this triangle: no projection bound for this image
+        if (count < 0) {
+            count = 0;                     // the other launch's triangle
+        } else if (!(zmin > 1e-20f)) {        // the camera plane cuts (or touches) this triangle: no projection bound for this image
             __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             const float ra = 1.0f / az, rb = 1.0f / bz, rc = 1.0f / cz;
@@ -199,8 +208,15 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
     if (trusted) HIP_TRY(hipMemcpyAsync(w.vmodel, trusted, sizeof(ViewModel) * n_views, hipMemcpyDeviceToDevice, st));   // models of an earlier call
     else k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
     if (n > 0) {
-        k_raster<<<dim3((n + 255) / 256, n_views), 256, 0, st>>>(s->tris, n, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
-                                                                  reinterpret_cast<BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
+        for (int pass = 0; pass < 2; ++pass) {
+            k_raster<<<dim3((n + 255) / 256, n_views), 256, 0, st>>>(s->tris, n, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+                                                                      reinterpret_cast<BigItem*>(w.big), w.big_count, drt_scene::kBigCap, pass);
+            if (pass == 0) {   // the large triangles of the first launch before the second one reads the keys
+                k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+                                                           reinterpret_cast<const BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
+                HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
+            }
+        }
         k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                    reinterpret_cast<const BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
     }
