@@ -82,7 +82,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
       costs +24 %).  achieved = VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of the same
       command, profiles/pmc.json) / the live launch time; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles.
     * `fill + k_cull` (dead values into the dense float64 outputs + the patches that matter) is the HBM stage: algorithmic
-      bytes = 59 B per ray written + (48 read + 36 list) per primary hit, DESIGN.md section 4.
+      bytes = 51 B per ray written + (48 read + 36 list + 8 key) per primary hit, DESIGN.md section 4.
     Stage times of the timed region overlap (two internal streams); `alone` = the same steps with the streams serialised."""
     n = P * n_local_views * args.steps                 # rays through the pipeline in the timed region
     it = {k: v[2] for k, v in prof.items()}
@@ -92,7 +92,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
     fused = args.mode == "fused"
     # bytes per item: list entry = 4 (index) + 24 (float32 ray) + 4 (face); float64 ray = 48; dense outputs = 51 + 8 (face ids)
     alg = {
-        "cull": (0 if fused else 59 * n) + (48 + 36 + 8) * h0,
+        "cull": (0 if fused else 51 * n) + (48 + 36 + 8) * h0,      # dense outputs 24 + 24 + 3 B per ray (face ids only where mask = 1)
         "trace1": 28 * c, "trace2": 28 * h, "trace3": 28 * s2,
         "shade1": (8 + 48 + 4) * h0 + 28 * h,
         "shade2": (8 + 48 + 4) * h + 28 * s2 + (4 * h if fused else 59 * h),

@@ -889,6 +889,8 @@ template <bool FUSED>
 static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h,
                         int grid_mode, ViewModel* grid_cache /* models of the images of THIS sub-batch */) {
+    const bool sparse_faces = (grid_mode & DRT_GRID_SPARSE_FACES) != 0;
+    grid_mode &= 3;
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
     RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
@@ -910,7 +912,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
           if (!FUSED) {
               (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
               (void)hipMemsetAsync(mask, 0, 3 * n, st);
-              (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st);
+              if (!sparse_faces) { (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st); }
           }
           uint32_t* list = reinterpret_cast<uint32_t*>(p.redo);          // free until the first k_trace of this sub-batch
           k_patch_list<<<(n_patches + kPathBlock - 1) / kPathBlock, kPathBlock, 0, st>>>(n_patches, tile_w, rz, list, p.count + 7);

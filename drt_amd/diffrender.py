@@ -74,6 +74,8 @@ def _flag_bytes(t, name, n):
     return t.contiguous().view(torch.uint8)
 
 
+DENSE_FACE_IDS = False  # True: Scene.last_face1 / last_face2 hold -1 for every ray without a hit (diagnostics, tests); False: only the entries of
+                        # the rays with mask = 1 are defined (all the backward needs), which saves filling 8 bytes per ray
 GRID_CACHE = True      # remember, per (origin, ray_dir) tensor pair, that its images verified as pinhole grids (see _grid_cache)
 _GRID_BYTES = 104      # DRT_GRID_CACHE_BYTES of include/drt_hip.h
 
@@ -159,7 +161,7 @@ class _RenderTransparent(torch.autograd.Function):
             _lib.check(_lib.lib().drt_render_forward(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
                 out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
-                _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0], _lib.ptr(grid[1]), _stream()))
+                _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0] | (0 if DENSE_FACE_IDS else 16), _lib.ptr(grid[1]), _stream()))
         ctx.scene = scene
         ctx.ior = (float(ior_int), float(ior_ext))
         ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)

@@ -97,6 +97,9 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
 #define DRT_GRID_ESTABLISH 1
 #define DRT_GRID_TRUST 2
 #define DRT_GRID_CACHE_BYTES 104
+/* OR-ed into grid_mode: d_face1 / d_face2 are only guaranteed for the rays with mask = 1 (what drt_render_backward* read);
+ * in DRT_GRID_TRUST mode the -1 entries of all other rays are then not written (8 bytes per ray less to fill). */
+#define DRT_GRID_SPARSE_FACES 16
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                        double* d_out_ori, double* d_out_dir, uint8_t* d_mask,

@@ -30,6 +30,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _dense_face_ids():
+    """The parity tests compare Scene.last_face1 / last_face2 for EVERY ray: ask the library to define them everywhere."""
+    from drt_amd import diffrender
+    old = diffrender.DENSE_FACE_IDS
+    diffrender.DENSE_FACE_IDS = True
+    yield
+    diffrender.DENSE_FACE_IDS = old
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

@@ -229,3 +229,33 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     o[2 * P + 5] += 1.0                                    # and an origin write
     prof3, _ = run(None)
     assert prof3["trace1"][2] >= prof2["trace1"][2]
+
+
+def test_sparse_face_ids_leave_results_unchanged(Render):
+    """DENSE_FACE_IDS = False (the production setting): face ids are defined for the rays with mask = 1 only; outputs, loss and
+    gradient do not change."""
+    from drt_amd import diffrender
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(mesh, 0)
+    c, ext = views.mesh_frame(mesh.vertices)
+    res = 256
+    cam = views.turntable_cameras(c, ext, 72, res, res)[9]
+    o, d = views.generate_ray(res, res, cam[3], cam[2], device="cuda")
+    Render.resx = Render.resy = res
+    sp = torch.randn(o.shape, dtype=torch.float64, device="cuda") * 50; valid = torch.rand(len(o), device="cuda") < 0.7
+    outs = []
+    for dense in (True, False, False):               # (twice: the second sparse call runs in TRUST mode)
+        diffrender.DENSE_FACE_IDS = dense
+        V = scene.vertices.detach().clone().requires_grad_(True)
+        scene.update_verticex(V)
+        oo, od, mk = scene.render_transparent(o, d)
+        loss = Render.ray_loss(oo, od, mk, sp, valid)
+        loss.backward()
+        outs.append((oo.detach(), od.detach(), mk, loss.item(), V.grad.clone(), scene.last_face1.clone(), scene.last_face2.clone()))
+    diffrender.DENSE_FACE_IDS = True
+    a = outs[0]
+    for b in outs[1:]:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert b[3] == pytest.approx(a[3], rel=1e-12) and torch.allclose(a[4], b[4], rtol=1e-11, atol=1e-14 * a[4].abs().max().item())
+        m = a[2][:, 0]
+        assert torch.equal(a[5][m], b[5][m]) and torch.equal(a[6][m], b[6][m])
