@@ -326,7 +326,7 @@ def main():
     torch.cuda.empty_cache()
 
     from drt_amd import optim as O
-    init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False)    # reference optim.py:164-171
+    init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False, fused=True)    # reference optim.py:164-171; limit_hook + SGD in one kernel
     limit_hook = O.limit_hook
     w_ray = O.loss_weights(O.HyperParams, res, scene.mean_len)[0]     # 40 * 217.5 / res^2 (reference optim.py:127, config.py defaults)
     local_views = [(sp, valid, o, d) for sp, valid, o, d in data]

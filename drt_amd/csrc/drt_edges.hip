@@ -192,6 +192,29 @@ __global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const doub
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
 }
 
+// limit_hook + one SGD(nesterov) step (reference optim.py:155-171, 215) in one pass over the [V,3] parameter: the gradient is
+// sanitised in place (NaN -> 0, clamp to +-max_abs: what the reference's hook does to parameter.grad), the momentum buffer and
+// the parameter follow torch.optim.SGD (dampening 0, no weight decay): buf = g on the first step, momentum * buf + g after;
+// step = g + momentum * buf with nesterov, buf without; param -= lr * step.  Replaces ~8 elementwise launches per iteration.
+__global__ void __launch_bounds__(256) k_limit_sgd(double* __restrict__ param, double* __restrict__ grad, double* __restrict__ buf, int64_t n,
+                                                   double lr, double momentum, int nesterov, int first, double max_abs) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double g = grad[i];
+        if (max_abs > 0.0) {
+            g = g != g ? 0.0 : g;
+            g = g > max_abs ? max_abs : (g < -max_abs ? -max_abs : g);
+            grad[i] = g;
+        }
+        double step = g;
+        if (momentum != 0.0) {
+            const double b = first ? g : buf[i] * momentum + g;
+            buf[i] = b;
+            step = nesterov ? g + momentum * b : b;
+        }
+        param[i] = param[i] + (-lr) * step;
+    }
+}
+
 extern "C" {
 
 int drt_dihedral_forward(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, double* d_cos, void* stream) {
@@ -284,5 +307,15 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
     return DRT_OK;
 }
 
+
+int drt_limit_sgd_step(double* d_param, double* d_grad, double* d_buf, int64_t n, double lr, double momentum, int nesterov, int first,
+                       double max_abs, void* stream) {
+    if (n < 0) return fail(DRT_E_INVALID, "negative size");
+    if (n == 0) return DRT_OK;
+    if (!d_param || !d_grad || (momentum != 0.0 && !d_buf)) return fail(DRT_E_INVALID, "null pointer argument");
+    k_limit_sgd<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_buf, n, lr, momentum, nesterov, first, max_abs);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
 
 }  // extern "C"

@@ -115,9 +115,46 @@ def limit_hook(grad, max_abs=1.0):
     return g.clamp_(-max_abs, max_abs)
 
 
-def setup_opt(scene, lr, HyperParams, hook=True):
+class FusedLimitSGD:
+    """limit_hook + torch.optim.SGD(momentum, nesterov) for ONE float64 parameter in one kernel (drt_limit_sgd_step) instead
+    of ~8 elementwise launches: ``step()`` sanitises ``parameter.grad`` in place (NaN -> 0, clamp +-max_abs: the
+    reference's hook, optim.py:155-162) and applies the update.  Same numbers as the hook + torch.optim.SGD."""
+
+    applies_limit = True
+
+    def __init__(self, parameter, lr, momentum=0.0, nesterov=False, max_abs=1.0):
+        self.parameter, self.lr, self.momentum, self.nesterov, self.max_abs = parameter, float(lr), float(momentum), bool(nesterov), float(max_abs)
+        self.buf = None
+        self.param_groups = [{"params": [parameter], "lr": self.lr, "momentum": self.momentum, "nesterov": self.nesterov}]
+
+    def zero_grad(self, set_to_none=True):
+        if set_to_none:
+            self.parameter.grad = None
+        elif self.parameter.grad is not None:
+            self.parameter.grad.zero_()
+
+    def step(self):
+        from . import _lib
+        from .optix_mesh import _stream
+        p, g = self.parameter, self.parameter.grad
+        if g is None:
+            return
+        assert p.is_cuda and p.dtype == torch.float64 and g.dtype == torch.float64 and p.is_contiguous() and g.is_contiguous()
+        first = self.buf is None
+        if first and self.momentum != 0.0:
+            self.buf = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().drt_limit_sgd_step(p.data_ptr(), g.data_ptr(), _lib.ptr(self.buf), p.numel(), self.param_groups[0]["lr"], self.momentum,
+                                                      int(self.nesterov), int(first), self.max_abs, _stream()))
+
+
+def setup_opt(scene, lr, HyperParams, hook=True, fused=False):
+    """``fused=True`` (needs ``hook=False``): a FusedLimitSGD, which applies limit_hook itself inside its one-kernel step."""
     init_vertices = scene.vertices.detach().clone()
     parameter = torch.zeros(init_vertices.shape, dtype=Float, requires_grad=True, device=init_vertices.device)
+    if fused:
+        assert not hook, "FusedLimitSGD applies the limit itself: build it with hook=False"
+        return init_vertices, parameter, FusedLimitSGD(parameter, lr, HyperParams["momentum"], nesterov=True)
     if hook:
         parameter.register_hook(limit_hook)
     # foreach=False: the multi-tensor kernels of the default implementation take ~35 us each for this ONE small tensor
@@ -191,6 +228,6 @@ def full_batch_step(scene, local_views, init_vertices, parameter, opt, ray_w, fu
         (ray_w * loss).backward()
     g = parameter.grad if parameter.grad is not None else torch.zeros_like(parameter)   # a rank with no views
     ddist.allreduce_sum_(g)                 # the only exchange of the step
-    parameter.grad = limit_hook(g)          # clamp after the sum over views, as on one GPU
+    parameter.grad = g if getattr(opt, "applies_limit", False) else limit_hook(g)     # clamp after the sum over views, as on one GPU
     opt.step()
     return loss

@@ -234,6 +234,12 @@ int drt_mesh_buf_size(const drt_mesh_buf_t* b, int64_t* n_verts, int64_t* n_face
 int drt_mesh_buf_copy(const drt_mesh_buf_t* b, double* verts, int32_t* faces);
 void drt_mesh_buf_free(drt_mesh_buf_t* b);
 
+/* ---- limit_hook + SGD step (optim.py:155-171, 215) in one pass.  d_grad is sanitised in place when max_abs > 0 (NaN -> 0, clamp to
+ * +-max_abs); d_buf is torch.optim.SGD's momentum buffer (first != 0: initialised from the gradient); n = number of float64
+ * elements of the parameter. */
+int drt_limit_sgd_step(double* d_param, double* d_grad, double* d_buf, int64_t n, double lr, double momentum,
+                       int nesterov, int first, double max_abs, void* stream);
+
 /* ---- topology: Scene.init_edge (DiffRender.py:338-355; trimesh group_rows / edges_face on the host in the reference) and
  * the 1 -> 4 midpoint refinement of a level-of-detail step, on the device ---------------------------------------
  * drt_edge_tables: d_faces int64 [F,3], d_verts float64 [V,3] -> d_edges int64 [3F/2,2] (ascending by (min, max) vertex),

@@ -38,7 +38,7 @@ def _run(rank, world, fused):
         rng = np.random.default_rng(100 + k)
         sp = torch.tensor(rng.standard_normal((RES * RES, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0]), device="cuda")
         local.append((sp, torch.tensor(rng.random(RES * RES) > 0.1, device="cuda"), o, d))
-    init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False)
+    init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False, fused=fused)     # (the fused terms with the one-kernel optimiser)
     ray_w = 40 * 217.5 / RES / RES
     losses = []
     for _ in range(STEPS):

@@ -763,3 +763,25 @@ def test_ray_loss_gradient_as_row_list_equals_the_dense_tensor(Render, hand):
     ref = g["grad_ray_loss"]
     np.testing.assert_allclose(a[2].cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
     np.testing.assert_allclose(a[0].cpu().numpy(), 2.5 * ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+
+
+def test_fused_limit_sgd_equals_hook_plus_torch_sgd():
+    """drt_amd.optim.FusedLimitSGD (one kernel) against limit_hook + torch.optim.SGD(momentum, nesterov) over five steps with NaN,
+    inf and out-of-range gradient entries (reference optim.py:155-171, 215)."""
+    from drt_amd import optim as O
+    g = torch.Generator(device="cuda").manual_seed(0)
+    p0 = torch.randn((1000, 3), dtype=torch.float64, device="cuda", generator=g)
+    pa = p0.clone().requires_grad_(True)
+    pb = p0.clone().requires_grad_(True)
+    ref = torch.optim.SGD([pa], lr=0.1, momentum=0.95, nesterov=True, foreach=False)
+    fus = O.FusedLimitSGD(pb, 0.1, 0.95, nesterov=True)
+    for it in range(5):
+        grad = 3.0 * torch.randn(p0.shape, dtype=torch.float64, device="cuda", generator=g)
+        grad[it, 0] = float("nan"); grad[it + 7, 1] = float("inf"); grad[it + 9, 2] = -float("inf")
+        pa.grad = O.limit_hook(grad.clone())
+        ref.step()
+        pb.grad = grad.clone()
+        fus.step()
+        assert torch.equal(pb.grad, pa.grad)                                   # sanitised in place, like the hook
+        torch.testing.assert_close(pb.detach(), pa.detach(), rtol=1e-14, atol=1e-15)
+    assert torch.isfinite(pb).all()
