@@ -260,10 +260,8 @@ def main():
     ap.add_argument("--subdiv", type=int, default=None, help="midpoint subdivisions of the input hull (default: 1 for horse/mouse)")
     ap.add_argument("--batch-views", type=int, default=0,
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
-    ap.add_argument("--graph", type=int, default=-1,
-                    help="0: eager; 1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it; "
-                         "2: capture the rank-local part only, all-reduce and optimiser eager (drt_amd.optim.GraphedFullBatchStep); "
-                         "-1 (default): 2 when a rank's share is small (fewer than 24 views), else 0")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras after the timed region (fused-mode comparison, traversal statistics); "
@@ -338,13 +336,8 @@ def main():
         all-reduce of grad[V,3], limit_hook, SGD(nesterov) -- the same function the 2-rank tests run."""
         return O.full_batch_step(scene, local_views, init_vertices, parameter, opt, w_ray, fused=args.mode == "fused")
 
-    if args.graph < 0:
-        args.graph = 2 if len(my_views) < 24 else 0
     graph = None
-    if args.graph == 2:
-        graphed = O.GraphedFullBatchStep(scene, local_views, init_vertices, parameter, opt, w_ray, fused=args.mode == "fused", warmup=max(3, args.warmup))
-        run = graphed
-    elif args.graph:
+    if args.graph:
         # The step has no host-side data dependence (every list size lives on the device), so it can be
         # captured once and replayed: one graph launch per step instead of ~60 kernel launches.
         side = torch.cuda.Stream()
@@ -386,7 +379,7 @@ def main():
         "vs_baseline": None, "dtype": "f32 traversal + f64 shading/gradients", "data": "synthetic",
         "config": {"workload": f"{mesh_src} = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD",
-                   "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": {0: False, 1: "whole step", 2: "rank-local part; all-reduce + optimiser eager"}[args.graph], "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
+                   "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
                    "final_loss": float(loss.item())},
     }
     prof_timed = scene.optix_mesh.profile_read() if live_profile else None

@@ -238,48 +238,3 @@ def full_batch_step(scene, local_views, init_vertices, parameter, opt, ray_w, fu
     parameter.grad = g if getattr(opt, "applies_limit", False) else limit_hook(g)     # clamp after the sum over views, as on one GPU
     opt.step()
     return loss
-
-
-class GraphedFullBatchStep:
-    """full_batch_step with its rank-local part (rebuild, projection / traversal pipelines, loss, backward: ~60 kernel launches
-    on three streams) captured ONCE in a HIP graph and replayed; the all-reduce and the optimiser stay eager, so the graph
-    holds no collective.  The step has no host-side data dependence (every list size lives on the device, the ray tensors are
-    constants whose grid verdict is established during the warm-up), which is what makes it capturable.  Pays off when a
-    rank's share is small (9 of 72 views on 8 GPUs: the step is then bound by launch latency, not by the kernels)."""
-
-    def __init__(self, scene, local_views, init_vertices, parameter, opt, ray_w, fused=False, warmup=3):
-        if getattr(parameter, "_backward_hooks", None):
-            raise RuntimeError("GraphedFullBatchStep: build `parameter` with setup_opt(..., hook=False)")
-        self.parameter, self.opt = parameter, opt
-        self.grad = torch.zeros_like(parameter)            # static: what the graph leaves the local gradient in
-
-        def local():
-            parameter.grad = None
-            loss = local_loss_backward(scene, local_views, init_vertices, parameter, ray_w, fused)
-            if parameter.grad is None:
-                self.grad.zero_()
-            else:
-                self.grad.copy_(parameter.grad)
-            parameter.grad = None
-            return loss.detach()
-
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(2, warmup)):                # allocator pools, workspaces, the grid verdict of the ray tensors
-                local()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = local()
-
-    def __call__(self):
-        self.graph.replay()
-        g = self.grad
-        ddist.allreduce_sum_(g)
-        self.parameter.grad = g if getattr(self.opt, "applies_limit", False) else limit_hook(g)
-        self.opt.step()
-        return self.loss
-
-
