@@ -29,6 +29,10 @@ int drt_create(int device, drt_scene_t** out) {
     if (e == hipSuccess) e = hipMalloc(&s->scratch, sizeof(unsigned long long) * 8);
     if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->build_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->build_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->build_done, hipEventDisableTiming);
+    if (const char* ev = getenv("DRT_ASYNC_BUILD")) s->async_build = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_STREAMS")) { const int v = atoi(ev); if (v >= 1 && v <= drt_scene::kMaxSub) s->n_sub = v; }
     if (const char* ev = getenv("DRT_RASTER")) s->use_raster = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_SUB_PER_STREAM")) { const int v = atoi(ev); if (v >= 1 && v <= 16) s->sub_per_stream = v; }
@@ -67,7 +71,11 @@ int drt_create(int device, drt_scene_t** out) {
 void drt_destroy(drt_scene_t* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    if (s->build_stream) (void)hipStreamSynchronize(s->build_stream);
     scene_free_mesh(s);
+    if (s->build_fork) (void)hipEventDestroy(s->build_fork);
+    if (s->build_done) (void)hipEventDestroy(s->build_done);
+    if (s->build_stream) (void)hipStreamDestroy(s->build_stream);
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
     (void)hipFree(s->scratch);
@@ -109,6 +117,7 @@ int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int6
     for (int k = 0; k < kProfStages; ++k) { ms_out[k] = 0.0; launches_out[k] = 0; items_out[k] = 0; }
     if (s->prof_ev.empty()) return DRT_OK;
     HIP_TRY(hipStreamSynchronize(s->prof_stream));
+    if (s->build_stream) HIP_TRY(hipStreamSynchronize(s->build_stream));
     if (s->prof_dropped) {       // the stage times would under-report: say so instead of returning them
         const size_t lost = s->prof_dropped;
         s->prof_dropped = 0; s->prof_used = 0;

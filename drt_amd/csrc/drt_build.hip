@@ -6,8 +6,8 @@ void scene_free_mesh(drt_scene* s) {
     (void)hipFree(s->faces); (void)hipFree(s->verts); (void)hipFree(s->nodes); (void)hipFree(s->tris);
     (void)hipFree(s->keys[0]); (void)hipFree(s->keys[1]); (void)hipFree(s->idx[0]); (void)hipFree(s->idx[1]);
     (void)hipFree(s->hist); (void)hipFree(s->parent_inner); (void)hipFree(s->parent_leaf); (void)hipFree(s->flags);
-    (void)hipFree(s->wide); (void)hipFree(s->range_lo); (void)hipFree(s->range_hi);
-    s->wide = nullptr; s->range_lo = s->range_hi = nullptr;
+    (void)hipFree(s->wide); (void)hipFree(s->range_lo); (void)hipFree(s->range_hi); (void)hipFree(s->tris_flat);
+    s->wide = nullptr; s->range_lo = s->range_hi = nullptr; s->tris_flat = nullptr;
     s->faces = nullptr; s->verts = nullptr; s->nodes = nullptr; s->tris = nullptr;
     s->keys[0] = s->keys[1] = s->idx[0] = s->idx[1] = nullptr;
     s->hist = nullptr; s->parent_inner = s->parent_leaf = nullptr; s->flags = nullptr;
@@ -321,6 +321,7 @@ int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
     HIP_TRY(hipMalloc(&s->range_lo, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->range_hi, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->tris, sizeof(TriRec) * F));
+    HIP_TRY(hipMalloc(&s->tris_flat, sizeof(TriRec) * F));
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&s->keys[k], sizeof(uint32_t) * F));
         HIP_TRY(hipMalloc(&s->idx[k], sizeof(uint32_t) * F));
@@ -365,9 +366,44 @@ static int rebuild_impl(drt_scene* s, hipStream_t st) {
     return DRT_OK;
 }
 
+// Triangle records in FACE order: what the projected primary-visibility pass reads (it needs no tree), so that it can run
+// while the tree is still being built.
+__global__ void k_tri_flat(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n, TriRec* __restrict__ tris) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    tris[f] = make_tri(ld_vert(verts, faces[3 * f]), ld_vert(verts, faces[3 * f + 1]), ld_vert(verts, faces[3 * f + 2]), f);
+}
+
+// The LBVH build is ten small dependent launches (~0.17 ms at 50 k triangles, launch-latency bound).  It runs on the
+// scene's own stream, after the vertices are in place on the caller's stream, and every consumer of the tree waits for
+// `build_done` (wait_build): the next render call's output fills and projection pass, which only need the flat triangle
+// records written here, overlap it.
 int rebuild(drt_scene* s, hipStream_t st) {
-    StageTimer t(s, st, kStageBuild);
-    return rebuild_impl(s, st);
+    const int n = (int)s->n_faces;
+    if (n > 0) k_tri_flat<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->tris_flat);
+    hipStream_t bs = s->async_build ? s->build_stream : st;
+    if (bs != st) {
+        HIP_TRY(hipEventRecord(s->build_fork, st));
+        HIP_TRY(hipStreamWaitEvent(bs, s->build_fork, 0));
+    }
+    int rc;
+    { StageTimer t(s, bs, kStageBuild);
+      rc = rebuild_impl(s, bs); }
+    if (bs != st) HIP_TRY(hipEventRecord(s->build_done, bs));
+    s->build_pending = bs != st;
+    return rc;
+}
+
+// Before the caller's stream overwrites the mesh buffers of a build that may still be running.
+static int begin_update(drt_scene* s, hipStream_t st) {
+    if (s->build_pending) HIP_TRY(hipStreamWaitEvent(st, s->build_done, 0));
+    return DRT_OK;
+}
+
+// Before `st` reads the tree (nodes, sorted triangle records, sorted order).
+int wait_build(drt_scene* s, hipStream_t st) {
+    if (s->build_pending) HIP_TRY(hipStreamWaitEvent(st, s->build_done, 0));
+    return DRT_OK;
 }
 
 extern "C" {
@@ -377,7 +413,10 @@ int drt_update_mesh(drt_scene_t* s, const int32_t* d_faces, int64_t n_faces, con
     if (n_faces < 0 || n_verts < 0 || (n_faces && !d_faces) || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "bad mesh arguments");
     if (n_faces > (int64_t)1 << 30) return fail(DRT_E_INVALID, "too many faces");
     hipStream_t st = (hipStream_t)stream;
-    int rc = ensure_capacity(s, n_faces, n_verts);
+    int rc = begin_update(s, st);
+    if (rc) return rc;
+    if (n_faces > s->cap_faces || n_verts > s->cap_verts) HIP_TRY(hipStreamSynchronize(s->build_stream));   // buffers are about to be freed
+    rc = ensure_capacity(s, n_faces, n_verts);
     if (rc) return rc;
     s->n_faces = n_faces;
     s->n_verts = n_verts;
@@ -390,6 +429,8 @@ int drt_update_vert(drt_scene_t* s, const float* d_verts, int64_t n_verts, void*
     CHECK_BUILT(s);
     if (n_verts != s->n_verts || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "vertex count %lld != %lld", (long long)n_verts, (long long)s->n_verts);
     hipStream_t st = (hipStream_t)stream;
+    int rc = begin_update(s, st);
+    if (rc) return rc;
     if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
     return rebuild(s, st);
 }
@@ -398,6 +439,8 @@ int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, 
     CHECK_BUILT(s);
     if (n_verts != s->n_verts || (n_verts && !d_verts)) return fail(DRT_E_INVALID, "vertex count %lld != %lld", (long long)n_verts, (long long)s->n_verts);
     hipStream_t st = (hipStream_t)stream;
+    int rc = begin_update(s, st);
+    if (rc) return rc;
     if (n_verts) k_cast_verts<<<grid_for(3 * n_verts, 256, 1024), 256, 0, st>>>(d_verts, s->verts, 3 * n_verts);
     return rebuild(s, st);
 }
@@ -405,6 +448,7 @@ int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, 
 int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height, int32_t* wide_depth) {
     CHECK_BUILT(s);
     hipStream_t st = (hipStream_t)stream;
+    { int rc = wait_build(s, st); if (rc) return rc; }
     unsigned long long v[3] = {0, 0, 0};
     if (s->n_faces) {
         HIP_TRY(hipMemsetAsync(s->scratch, 0, 3 * sizeof(unsigned long long), st));
@@ -426,6 +470,7 @@ int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* 
 int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream) {
     CHECK_BUILT(s);
     if (s->n_faces && !d_order) return fail(DRT_E_INVALID, "d_order is null");
+    { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
     if (s->n_faces) HIP_TRY(hipMemcpyAsync(d_order, s->idx[0], sizeof(int32_t) * s->n_faces, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DRT_OK;
 }

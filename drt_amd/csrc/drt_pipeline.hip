@@ -900,20 +900,25 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         int rc = ensure_raster(s, w, n, n_views, st);
         if (rc) return rc;
         if (!grid_cache) grid_mode = DRT_GRID_NONE;
+        if (!FUSED && grid_mode == DRT_GRID_TRUST) {
+            // dead values into every dense output first (plain memsets run at the full write rate); k_cull_listed then only
+            // visits the patches that matter.  Together with the projection pass this needs no tree: it overlaps the build.
+            StageTimer t(s, st, kStageCull);
+            (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
+            (void)hipMemsetAsync(mask, 0, 3 * n, st);
+            if (!sparse_faces) { (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st); }
+        }
         StageTimer t(s, st, kStageRaster);
         rc = launch_raster(s, w, st, o, d, n_views, tile_w, tile_h, grid_mode == DRT_GRID_TRUST ? grid_cache : nullptr);
         if (rc) return rc;
         rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h};
     }
+    // everything from here on may read the tree: wait for the build (it ran beside the fills and the projection pass above)
+    { int rc = wait_build(s, st); if (rc) return rc; }
     { StageTimer t(s, st, kStageCull);
       const unsigned n_patches = (unsigned)((n + kPathBlock - 1) / kPathBlock);
       if (rz.views && grid_mode == DRT_GRID_TRUST) {
-          // dead values everywhere first (plain memsets run at the full write rate), then only the patches that matter
-          if (!FUSED) {
-              (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
-              (void)hipMemsetAsync(mask, 0, 3 * n, st);
-              if (!sparse_faces) { (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st); }
-          }
+          // (the dense outputs were pre-filled with the dead values above, before the projection pass)
           uint32_t* list = reinterpret_cast<uint32_t*>(p.redo);          // free until the first k_trace of this sub-batch
           k_patch_list<<<(n_patches + kPathBlock - 1) / kPathBlock, kPathBlock, 0, st>>>(n_patches, tile_w, rz, list, p.count + 7);
           k_cull_listed<FUSED><<<gs, kPathBlock, 0, st>>>(list, p.count + 7, pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);

@@ -209,15 +209,15 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
     else k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
     if (n > 0) {
         for (int pass = 0; pass < 2; ++pass) {
-            k_raster<<<dim3((n + 255) / 256, n_views), 256, 0, st>>>(s->tris, n, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+            k_raster<<<dim3((n + 255) / 256, n_views), 256, 0, st>>>(s->tris_flat, n, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                                       reinterpret_cast<BigItem*>(w.big), w.big_count, drt_scene::kBigCap, pass);
             if (pass == 0) {   // the large triangles of the first launch before the second one reads the keys
-                k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+                k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris_flat, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                            reinterpret_cast<const BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
                 HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
             }
         }
-        k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+        k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris_flat, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                    reinterpret_cast<const BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
     }
     HIP_TRY(hipGetLastError());

@@ -78,6 +78,11 @@ struct drt_scene {
     Node4Q* wide = nullptr;        // [max(F-1,1)] 4-wide tree (quantised, 64 B/node) read by the traversal, indexed by binary root
     int32_t *range_lo = nullptr, *range_hi = nullptr;   // sorted-slot range of each binary node
     TriRec* tris = nullptr;        // [F] Morton order
+    TriRec* tris_flat = nullptr;   // [F] face order (projected primary visibility: needs no tree)
+    hipStream_t build_stream = nullptr;   // the LBVH build runs here, beside the caller's next fills / projection pass
+    hipEvent_t build_fork = nullptr, build_done = nullptr;
+    bool build_pending = false;    // a build was enqueued on build_stream: consumers of the tree wait for build_done
+    bool async_build = true;       // DRT_ASYNC_BUILD=0: build on the caller's stream
     uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
     uint32_t* hist = nullptr;      // [kRadix * tiles]
     int32_t *parent_inner = nullptr, *parent_leaf = nullptr;
@@ -160,6 +165,7 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
 void scene_free_mesh(drt_scene* s);
 int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts);
 int rebuild(drt_scene* s, hipStream_t st);
+int wait_build(drt_scene* s, hipStream_t st);
 
 inline int grid_for(int64_t n, int block, int cap) {
     int64_t g = (n + block - 1) / block;

@@ -77,6 +77,7 @@ int query_blocks_per_cu() {
 template <bool ANY>
 static int b1_query(drt_scene* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, uint8_t* d_hit, hipStream_t st) {
     if (n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    { int rc = wait_build(s, st); if (rc) return rc; }
     if (n_rays > s->b1_cap) {
         (void)hipFree(s->b1_list); (void)hipFree(s->b1_redo);
         s->b1_list = s->b1_redo = nullptr; s->b1_cap = 0;
@@ -115,6 +116,7 @@ int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays
     CHECK_BUILT(s);
     if (n_rays < 0 || (n_rays && (!d_rays || !d_T || !d_ID))) return fail(DRT_E_INVALID, "bad ray arguments");
     if (n_rays == 0) return DRT_OK;
+    { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
     k_bruteforce<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(s->tris, (int)s->n_faces, d_rays, n_rays, d_T, d_ID);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -125,6 +127,7 @@ int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double*
     if (n < 0) return fail(DRT_E_INVALID, "negative point count");
     if (n == 0) return DRT_OK;
     if (!d_points || !d_dist) return fail(DRT_E_INVALID, "null pointer argument");
+    { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
     k_closest_point<<<grid_for(n, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), s->faces, s->verts, d_points, n, d_dist, d_face, d_closest);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
