@@ -401,6 +401,40 @@ def main():
                        "alg_bytes_per_ray": 73, "api": "Scene.ray_loss_fused (render_transparent + ray_loss + backward in one pass)"}
         scene.optix_mesh.profile_enable(1)
         scene.optix_mesh.profile_read()
+    route_b = None
+    if rank == 0 and world == 1 and not args.no_extras and args.mode == "dropin":
+        # INTEGRATION.md route B: the reference's own DiffRender structure -- Dintersect / refract_ray / trace2 as float64
+        # torch ops with autograd, the occlusion query, boolean-mask compaction between the steps -- on top of the HIP tracer
+        # class only (drt_intersect behind optix_mesh.intersect), one view per call like the reference's loop.
+        o1, d1 = local_views[0][2][:P].contiguous(), local_views[0][3][:P].contiguous()
+        sp1, va1 = local_views[0][0][:P].contiguous(), local_views[0][1][:P].contiguous()
+
+        def route_b_view():
+            verts = (init_vertices + parameter).detach().requires_grad_(True)
+            scene.update_verticex(verts)
+            out = scene.trace2(Render.Ray(o1, d1))
+            _, occluded = scene.optix_intersect(out)
+            keep = torch.logical_not(occluded)
+            idx = out.ray_ind[keep]
+            target = sp1[idx] - out.origin[keep].detach()
+            target = target / target.norm(dim=1, keepdim=True)
+            vm = va1[idx]
+            loss = (out.direction[keep] - target)[vm].pow(2).sum()
+            loss.backward()
+            return loss
+
+        for _ in range(2):
+            route_b_view()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        nb = 10
+        for _ in range(nb):
+            route_b_view()
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - tb) / nb
+        route_b = {"M_rays_per_s": round(P / tb / 1e6, 3), "ms_per_view": round(1e3 * tb, 3),
+                   "what": f"one {res}x{res} view per call: update_vert + Scene.trace2 (stepwise float64 torch ops, autograd) + occlusion query + ray loss + "
+                           "backward, all traversals through optix_mesh.intersect (drt_intersect) -- the reference's DiffRender.py shape on the HIP tracer"}
     if not live_profile:
         # (events cannot be recorded inside a replayed graph either:) repeat the same K steps eagerly, right after the
         # timed region, with the per-kernel event pairs on (same kernels, same inputs, same launch stream)
@@ -438,6 +472,8 @@ def main():
                                                      "lane_utilisation": round(ls / (64.0 * ws), 3), "longest_wave_visits": mx})
         if fused_extra:
             out["fused_mode"] = fused_extra
+        if route_b:
+            out["route_b"] = route_b
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mesh, center, extent)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,29 @@
+#!/bin/bash
+# The measurement batch whose outputs go to profiles/ at the end of a round (run on the GPU box through gpurun).
+# usage: bash tools/final_runs.sh <prefix>      e.g. r02
+set -u
+P=${1:-r02}
+O=gpurun_out/final_$P; mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --mode fused --no-cpu-baseline > $O/bench_fused.json 2> /dev/null
+{
+  for cfg in "--mesh hand --res 512 --views 72" "--mesh mouse --res 1024 --views 72" "--mesh horse --res 1024 --views 72" "--mesh monkey --res 1024 --views 72" "--mesh monkey --res 1024 --views 144"; do
+    python bench.py $cfg --no-cpu-baseline --no-extras --steps 10 --warmup 3 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg ::', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s ;', d['config']['workload'])"
+  done
+} > $O/configs.txt 2>&1
+{
+  for v in 72 36 18 9; do
+    python bench.py --views $v --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
+  done
+  python bench.py --views 9 --graph 1 --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views 9 whole-step hipGraph', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
+} > $O/scaling_proxy.txt 2>&1
+python tools/iter_bench.py > $O/iter_bench.txt 2>&1
+bash tools/profile.sh $P > $O/profile.log 2>&1
+PROFILE_SKIP_PMC=1 DRT_STREAMS=1 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
+tail -3 $O/configs.txt $O/scaling_proxy.txt $O/iter_bench.txt; python tools/benchsum.py $O/bench.json | head -3
