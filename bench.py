@@ -59,16 +59,18 @@ def per_view_mesh_bytes(V, F):
 
 VALU_PEAK = 256 * 4 * 2.4e9 / 2     # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32 units, two cycles per wave-instruction (MI355X_MICROARCH.md)
 # which bench.py stage is which kernel(s) in a rocprofv3 trace
-KERNELS = {"k_trace<closest>": ("trace1", "trace2"), "k_trace<any>": ("trace3",), "fill + k_cull": ("cull",), "k_raster": ("raster",),
+KERNELS = {"k_trace<closest>": ("trace1", "trace2"), "k_trace<any>": ("trace3",), "fill + k_cull": ("fill", "cull"), "k_raster": ("raster",),
            "k_shade1": ("shade1",), "k_shade2": ("shade2",), "k_finish": ("finish",), "k_render_bwd": ("backward", "collect"),
            "k_loss_bwd_fused": ("loss_bwd_fused",), "build": ("build",)}
 PMC_NAMES = {"k_trace<closest>": ("k_trace<false, 0>",), "k_trace<any>": ("k_trace<true, 0>",)}
 
 
-def _pmc(mode):
-    path = os.path.join(ROOT, "profiles", "pmc.json")        # tools/make_pmc_json.py, from rocprofv3 --pmc passes of this command
+def _pmc(mode, workload):
+    """Per-launch PMC means of profiles/pmc.json (tools/make_pmc_json.py) -- only for the workload they were collected on."""
+    path = os.path.join(ROOT, "profiles", "pmc.json")
     try:
-        return json.load(open(path)).get(mode, {})
+        rec = json.load(open(path))
+        return rec.get(mode, {}) if rec.get("workload") == workload else {}
     except Exception:
         return {}
 
@@ -92,7 +94,8 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
     fused = args.mode == "fused"
     # bytes per item: list entry = 4 (index) + 24 (float32 ray) + 4 (face); float64 ray = 48; dense outputs = 51 + 8 (face ids)
     alg = {
-        "cull": (0 if fused else 51 * n) + (48 + 36 + 8) * h0,      # dense outputs 24 + 24 + 3 B per ray (face ids only where mask = 1)
+        "fill": 0 if fused else 51 * n,                      # dense outputs 24 + 24 + 3 B per ray (face ids only where mask = 1)
+        "cull": (48 + 36 + 8) * h0 + (0 if it.get("fill", 0) or fused else 51 * n),
         "trace1": 28 * c, "trace2": 28 * h, "trace3": 28 * s2,
         "shade1": (8 + 48 + 4) * h0 + 28 * h,
         "shade2": (8 + 48 + 4) * h + 28 * s2 + (4 * h if fused else 59 * h),
@@ -125,7 +128,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
             by_kernel[name] = {"ms_per_step": round(ms, 4), "launches": sum(stages[m]["launches"] for m in members if m in stages),
                                "alone_ms_per_step": round(sum(alone[m]["ms_per_step"] for m in members if m in alone), 4) if alone else None}
     dom = max((k for k in by_kernel if k != "build"), key=lambda k: by_kernel[k]["ms_per_step"])
-    pmc = _pmc(args.mode)
+    pmc = _pmc(args.mode, f"{args.mesh} res {args.res} views {n_local_views} streams default")
 
     def issue_entry(name):
         """VALU-issue bound of a traversal kernel: wave-instructions per launch (PMC) over the live launch time."""
@@ -147,19 +150,26 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
                                 "frac": round(rec["SQ_INSTS_VALU"] / (ms_a / launches * 1e-3) / VALU_PEAK, 4)}
         return out
 
-    def hbm_entry(stage):
-        st = stages[stage]
+    def hbm_entry(_stage=None):
+        """The HBM stage: pre-fill of the dense outputs (memsets) + k_patch_list + k_cull_listed, per sub-batch."""
+        members = [m for m in ("fill", "cull") if m in stages]
+        launches = stages["cull"]["launches"]
+        ms = sum(stages[m]["ms_per_step"] for m in members) * args.steps
+        bytes_ = sum(alg[m] for m in members)
+        ach = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         traffic = None
-        if pmc:       # HBM bytes of the kernels of the stage (memset fills + k_patch_list + k_cull_listed), per stage launch
+        if pmc:       # HBM bytes of the kernels of the stage (memset fills + k_patch_list + k_cull_listed), per sub-batch
             names = [q for q in pmc if q.startswith(("__amd_rocclr_fill", "k_patch_list", "k_cull_listed"))]    # (k_cull<...> is the establishing step's kernel)
             if names and all("hbm_bytes_per_launch" in pmc[q] for q in names):
                 per_step = sum(pmc[q]["hbm_bytes_per_launch"] * pmc[q]["launches"] for q in names)
                 ref_launches = pmc.get("k_patch_list", {}).get("launches")
                 traffic = round(per_step / ref_launches) if ref_launches else None
-        out = {"kernel": "fill + k_cull", "bound": "hbm", "achieved": st["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(st["alg_GBps"] / HBM_PEAK_GBS, 5),
-               "traffic": traffic, "alg_bytes_per_launch": round(alg[stage] / st["launches"]), "avg_launch_ms": st["avg_launch_ms"]}
-        if stage in alone:
-            out["alone"] = {"achieved": alone[stage]["alg_GBps"], "frac": round(alone[stage]["alg_GBps"] / HBM_PEAK_GBS, 5), "avg_launch_ms": alone[stage]["avg_launch_ms"]}
+        out = {"kernel": "fill + k_cull", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+               "traffic": traffic, "alg_bytes_per_launch": round(bytes_ / max(1, launches)), "avg_launch_ms": round(ms / max(1, launches), 4)}
+        if alone and all(m in alone for m in members):
+            ms_a = sum(alone[m]["ms_per_step"] for m in members) * args.steps
+            out["alone"] = {"achieved": round(bytes_ / (ms_a * 1e-3) / 1e9, 1), "frac": round(bytes_ / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                            "avg_launch_ms": round(ms_a / max(1, launches), 4)}
         return out
 
     step_alg = ((73 if fused else B_STEP) * P + per_view_mesh_bytes(V, F)) * args.views

@@ -793,6 +793,7 @@ __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long
     // sub-batches on different streams may report concurrently: atomics
     atomicAdd(&tot[kStageCull], n_rays);
     if (raster) atomicAdd(&tot[kStageRaster], n_rays);
+    if (raster && !fused) atomicAdd(&tot[kStageFill], n_rays);
     atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
     atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
     atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[2]);
@@ -903,7 +904,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         if (!FUSED && grid_mode == DRT_GRID_TRUST) {
             // dead values into every dense output first (plain memsets run at the full write rate); k_cull_listed then only
             // visits the patches that matter.  Together with the projection pass this needs no tree: it overlaps the build.
-            StageTimer t(s, st, kStageCull);
+            StageTimer t(s, st, kStageFill);
             (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
             (void)hipMemsetAsync(mask, 0, 3 * n, st);
             if (!sparse_faces) { (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st); }

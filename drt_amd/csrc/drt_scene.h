@@ -59,7 +59,7 @@ constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds th
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
 
 // stage ids of drt_profile_read
-enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kStageRaster, kProfStages };
+enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kStageRaster, kStageFill, kProfStages };
 
 struct BuildParams {   // written by k_bounds, read by the later build kernels
     float lox, loy, loz;

@@ -269,10 +269,10 @@ int drt_subdivide_midpoint(const int64_t* d_faces, int64_t n_faces, const double
  * items (rays in the stage's input queue) since the previous read.  Arrays have DRT_PROFILE_STAGES
  * entries: 0 build, 1 cull, 2 trace1, 3 shade1, 4 trace2, 5 shade2, 6 trace3 (occlusion),
  * 7 finish, 8 collect (backward compaction when no list was saved), 9 backward,
- * 10 fused loss+backward, 11 projected primary visibility (fit + raster kernels).  The event pool grows with the number of launches between two reads; if it could not
+ * 10 fused loss+backward, 11 projected primary visibility (fit + raster kernels), 12 pre-fill of the dense outputs (memsets, DRT_GRID_TRUST).  The event pool grows with the number of launches between two reads; if it could not
  * (allocation failure), drt_profile_read FAILS (DRT_E_INVALID, message with the number of lost timings) instead
  * of returning under-reported stage times. */
-#define DRT_PROFILE_STAGES 12
+#define DRT_PROFILE_STAGES 13
 int drt_profile_enable(drt_scene_t* s, int on);
 int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out);
 /* Traversal diagnostics of the last drt_profile_read interval, 4 values for each of the three

@@ -36,6 +36,7 @@ try:
 except Exception:
     res = {}
 res[mode] = out
+res["workload"] = os.environ.get("PMC_WORKLOAD", "horse res 1024 views 72 streams default")
 res["note"] = ("per-launch means from separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-extras --random-targets` "
                "(tools/profile.sh); SQ_* cycle counters are quad-cycles; FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte requests as 64, "
                "MI355X_MICROARCH.md) + WRITE_SIZE x 1024")
