@@ -498,8 +498,17 @@ __global__ void k_store_count(const unsigned* __restrict__ count, int64_t* __res
 // independent of scope or per-XCD privatisation), and neighbouring rays hit neighbouring triangles
 // that share vertices: a block first sums its contributions per vertex in LDS (ds_add_f64 after a
 // compare-and-swap probe on the key) and then issues three global atomics per DISTINCT vertex.
-constexpr int kHashBits = 11, kHashSize = 1 << kHashBits;      // 2048 slots: 8 KB keys + 48 KB sums
-constexpr int kBwdBatch = 1024;                                 // rays per table fill (6 vertex refs each)
+#ifndef DRT_HASH_BITS
+#define DRT_HASH_BITS 11
+#endif
+#ifndef DRT_BWD_BATCH
+#define DRT_BWD_BATCH 1024
+#endif
+#ifndef DRT_BWD_BPC
+#define DRT_BWD_BPC 2
+#endif
+constexpr int kHashBits = DRT_HASH_BITS, kHashSize = 1 << kHashBits;      // 2048 slots: 8 KB keys + 48 KB sums
+constexpr int kBwdBatch = DRT_BWD_BATCH;                                 // rays per table fill (6 vertex refs each)
 
 struct HashAdd3 {
     int32_t* keys;      // LDS [kHashSize]
@@ -1037,7 +1046,7 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
     if (d_valid_idx) {   // the forward's list of completed paths: no pass over the dense arrays at all
         StageTimer t(s, st, kStageBackward);
-        k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+        k_render_bwd<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
                                                    d_valid_idx, nullptr, d_n_valid);
     } else {             // no list saved: compact face2 >= 0 first (on the caller's stream, workspace of sub-stream 0)
         drt_scene::Sub& w = s->sub[0];
@@ -1050,7 +1059,7 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
             { StageTimer t(s, st, kStageCollect);
               k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, b, w.q_idx[0], s->vcount); }
             { StageTimer t(s, st, kStageBackward);
-              k_render_bwd<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+              k_render_bwd<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
                                                          w.q_idx[0], s->vcount, nullptr); }
             if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->vcount, (unsigned long long)n, s->prof_counts);
         }
@@ -1072,7 +1081,7 @@ int drt_render_backward_ray_loss(drt_scene_t* s, const double* d_verts, const do
     hipStream_t st = (hipStream_t)stream;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
     { StageTimer t(s, st, kStageBackward);
-      k_render_bwd_rows<<<2 * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_face1, d_face2, d_rows, d_n_rows, d_scale, d_grad_verts); }
+      k_render_bwd_rows<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_face1, d_face2, d_rows, d_n_rows, d_scale, d_grad_verts); }
     if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1133,7 +1142,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
         rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h));
         if (rc) return rc;
         { StageTimer t(s, w.stream, kStageLossBwdFused);
-          k_loss_bwd_fused<<<2 * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
+          k_loss_bwd_fused<<<DRT_BWD_BPC * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
                                                                d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
         if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1, raster_on(s, n, tile_w, tile_h));
     }
