@@ -22,6 +22,7 @@
 // (the BVH's own leaf padding, 2^-13 of the scene extent, is ~0.06 px in the benchmark geometry).
 #pragma once
 #include "drt_common.h"
+#include "drt_tri.h"
 
 namespace drt {
 
@@ -82,21 +83,35 @@ struct PixelBox {
     bool unsafe;            // a vertex at or behind the camera plane (or a non-finite projection): no projection bound
 };
 
-// Padded pixel bounding box of the triangle (a, a + e1, a + e2) given relative to the ray origin.
-DRT_HD PixelBox project_tri_box(const ViewModel& vm, d3 a, d3 b, d3 c, int w, int h) {
+// Padded pixel bounding box of the triangle record `t` seen from the image's origin, in float32 (|error| ~1e-4 px at these
+// magnitudes; the pad is 0.25 px).  Used by k_raster and by the host-side unit test alike.
+DRT_HD PixelBox project_tri_box(const ViewModel& vm, f3 o32, const TriRec& t, int w, int h) {
     PixelBox r{0, -1, 0, -1, false};
-    const d3 pa = view_project(vm, a), pb = view_project(vm, b), pc = view_project(vm, c);
-    const double zmin = fmin(pa.z, fmin(pb.z, pc.z));
-    if (!(zmin > 1e-30)) { r.unsafe = true; return r; }
-    const double ax = pa.x / pa.z, ay = pa.y / pa.z, bx = pb.x / pb.z, by = pb.y / pb.z, cx = pc.x / pc.z, cy = pc.y / pc.z;
-    const double lox = fmin(ax, fmin(bx, cx)) - kRasterPad, hix = fmax(ax, fmax(bx, cx)) + kRasterPad;
-    const double loy = fmin(ay, fmin(by, cy)) - kRasterPad, hiy = fmax(ay, fmax(by, cy)) + kRasterPad;
-    if (!(fabs(lox) < 1e15 && fabs(hix) < 1e15 && fabs(loy) < 1e15 && fabs(hiy) < 1e15)) { r.unsafe = true; return r; }
-    const double fx0 = fmax(ceil(lox), 0.0), fx1 = fmin(floor(hix), (double)(w - 1));
-    const double fy0 = fmax(ceil(loy), 0.0), fy1 = fmin(floor(hiy), (double)(h - 1));
+    const f3 a{t.v0x - o32.x, t.v0y - o32.y, t.v0z - o32.z};
+    const f3 b{a.x + t.e1x, a.y + t.e1y, a.z + t.e1z}, c{a.x + t.e2x, a.y + t.e2y, a.z + t.e2z};
+    const float m0 = (float)vm.minv[0], m1 = (float)vm.minv[1], m2 = (float)vm.minv[2], m3 = (float)vm.minv[3], m4 = (float)vm.minv[4],
+                m5 = (float)vm.minv[5], m6 = (float)vm.minv[6], m7 = (float)vm.minv[7], m8 = (float)vm.minv[8];
+    const float az = fmaf(m6, a.x, fmaf(m7, a.y, m8 * a.z)), bz = fmaf(m6, b.x, fmaf(m7, b.y, m8 * b.z)), cz = fmaf(m6, c.x, fmaf(m7, c.y, m8 * c.z));
+    if (!(fminf(az, fminf(bz, cz)) > 1e-20f)) { r.unsafe = true; return r; }      // at or behind the camera plane
+    const float ra = 1.0f / az, rb = 1.0f / bz, rc = 1.0f / cz;
+    const float ax = fmaf(m0, a.x, fmaf(m1, a.y, m2 * a.z)) * ra, ay = fmaf(m3, a.x, fmaf(m4, a.y, m5 * a.z)) * ra;
+    const float bx = fmaf(m0, b.x, fmaf(m1, b.y, m2 * b.z)) * rb, by = fmaf(m3, b.x, fmaf(m4, b.y, m5 * b.z)) * rb;
+    const float cx = fmaf(m0, c.x, fmaf(m1, c.y, m2 * c.z)) * rc, cy = fmaf(m3, c.x, fmaf(m4, c.y, m5 * c.z)) * rc;
+    const float pad = (float)kRasterPad;
+    const float lox = fminf(ax, fminf(bx, cx)) - pad, hix = fmaxf(ax, fmaxf(bx, cx)) + pad;
+    const float loy = fminf(ay, fminf(by, cy)) - pad, hiy = fmaxf(ay, fmaxf(by, cy)) + pad;
+    if (!(fabsf(lox) < 1e9f && fabsf(hix) < 1e9f && fabsf(loy) < 1e9f && fabsf(hiy) < 1e9f)) { r.unsafe = true; return r; }
+    const float fx0 = fmaxf(ceilf(lox), 0.0f), fx1 = fminf(floorf(hix), (float)(w - 1));
+    const float fy0 = fmaxf(ceilf(loy), 0.0f), fy1 = fminf(floorf(hiy), (float)(h - 1));
     if (fx0 > fx1 || fy0 > fy1) return r;
     r.x0 = (int)fx0; r.x1 = (int)fx1; r.y0 = (int)fy0; r.y1 = (int)fy1;
     return r;
+}
+
+// Camera-facing?  (k_raster handles these in its first launch, the others in the second: see there.)
+DRT_HD bool tri_faces_away(f3 o32, const TriRec& t) {
+    const f3 a{t.v0x - o32.x, t.v0y - o32.y, t.v0z - o32.z};
+    return dot(a, cross(f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z})) > 0.0f;
 }
 
 // 64-bit key of a hit: t > 0, so its bit pattern orders like an unsigned integer; equal t -> lowest face id wins.

@@ -76,49 +76,24 @@ __global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris,
     me.x0 = me.y0 = 0; me.nx = 1;
     if (k < n_tris) {
         me.tri = tris[k];
-        const TriRec& t = me.tri;
-        // relative to the origin, in float32 (|error| ~1e-4 px at these magnitudes, the pad is 0.25 px)
-        const f3 a{t.v0x - o32.x, t.v0y - o32.y, t.v0z - o32.z};
-        const f3 b{a.x + t.e1x, a.y + t.e1y, a.z + t.e1z}, c{a.x + t.e2x, a.y + t.e2y, a.z + t.e2z};
         // Two launches: triangles facing the camera first (pass 0), the others second (pass 1).  Every triangle is handled in
         // exactly one of them, so the result is the same minimum; but a pixel's closest hit is nearly always a front face,
         // and the second launch sees the finished keys of the first: its read-before-atomic check then skips almost every
         // back face, which cuts the 64-bit atomics -- what bounds this kernel -- by more than half.
-        const f3 nrm = cross(f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z});
-        const bool back = dot(a, nrm) > 0.0f;
-        if ((pass == 1) != back) count = -1;
-        const float m0 = (float)vm.minv[0], m1 = (float)vm.minv[1], m2 = (float)vm.minv[2], m3 = (float)vm.minv[3], m4 = (float)vm.minv[4],
-                    m5 = (float)vm.minv[5], m6 = (float)vm.minv[6], m7 = (float)vm.minv[7], m8 = (float)vm.minv[8];
-        const float az = fmaf(m6, a.x, fmaf(m7, a.y, m8 * a.z)), bz = fmaf(m6, b.x, fmaf(m7, b.y, m8 * b.z)), cz = fmaf(m6, c.x, fmaf(m7, c.y, m8 * c.z));
-        const float zmin = fminf(az, fminf(bz, cz));
-        if (count < 0) {
-            count = 0;                     // the other launch's triangle
-        } else if (!(zmin > 1e-20f)) {        // the camera plane cuts (or touches) this triangle: no projection bound for this image
-            __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            const float ra = 1.0f / az, rb = 1.0f / bz, rc = 1.0f / cz;
-            const float ax = fmaf(m0, a.x, fmaf(m1, a.y, m2 * a.z)) * ra, ay = fmaf(m3, a.x, fmaf(m4, a.y, m5 * a.z)) * ra;
-            const float bx = fmaf(m0, b.x, fmaf(m1, b.y, m2 * b.z)) * rb, by = fmaf(m3, b.x, fmaf(m4, b.y, m5 * b.z)) * rb;
-            const float cx = fmaf(m0, c.x, fmaf(m1, c.y, m2 * c.z)) * rc, cy = fmaf(m3, c.x, fmaf(m4, c.y, m5 * c.z)) * rc;
-            const float pad = (float)kRasterPad;
-            const float lox = fminf(ax, fminf(bx, cx)) - pad, hix = fmaxf(ax, fmaxf(bx, cx)) + pad;
-            const float loy = fminf(ay, fminf(by, cy)) - pad, hiy = fmaxf(ay, fmaxf(by, cy)) + pad;
-            if (!(fabsf(lox) < 1e9f && fabsf(hix) < 1e9f && fabsf(loy) < 1e9f && fabsf(hiy) < 1e9f)) {
+        if ((pass == 1) == tri_faces_away(o32, me.tri)) {
+            const PixelBox box = project_tri_box(vm, o32, me.tri, w, h);
+            if (box.unsafe) {          // the camera plane cuts (or touches) this triangle: no projection bound for this image
                 __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                const float fx0 = fmaxf(ceilf(lox), 0.0f), fx1 = fminf(floorf(hix), (float)(w - 1));
-                const float fy0 = fmaxf(ceilf(loy), 0.0f), fy1 = fminf(floorf(hiy), (float)(h - 1));
-                if (fx0 <= fx1 && fy0 <= fy1) {
-                    me.x0 = (int)fx0; me.y0 = (int)fy0; me.nx = (int)fx1 - me.x0 + 1;
-                    const int ny = (int)fy1 - me.y0 + 1;
-                    const int64_t cnt = (int64_t)me.nx * ny;
-                    if (cnt > kRasterMaxPerLane) {
-                        const unsigned slot = atomicAdd(big_count, 1u);
-                        if (slot < big_cap) big[slot] = BigItem{view, k, me.x0, me.y0, me.nx, ny};
-                        else __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // list full: BVH path for this image
-                    } else {
-                        count = (int)cnt;
-                    }
+            } else if (box.x0 <= box.x1 && box.y0 <= box.y1) {
+                me.x0 = box.x0; me.y0 = box.y0; me.nx = box.x1 - box.x0 + 1;
+                const int ny = box.y1 - box.y0 + 1;
+                const int64_t cnt = (int64_t)me.nx * ny;
+                if (cnt > kRasterMaxPerLane) {
+                    const unsigned slot = atomicAdd(big_count, 1u);
+                    if (slot < big_cap) big[slot] = BigItem{view, k, me.x0, me.y0, me.nx, ny};
+                    else __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // list full: BVH path for this image
+                } else {
+                    count = (int)cnt;
                 }
             }
         }

@@ -14,6 +14,7 @@
 #include "../../drt_amd/csrc/drt_edge.h"
 #include "../../drt_amd/csrc/drt_lbvh.h"
 #include "../../drt_amd/csrc/drt_path.h"
+#include "../../drt_amd/csrc/drt_raster.h"
 
 using namespace drt;
 
@@ -354,6 +355,74 @@ void hs_edge_sample_backward(const double* verts, const int64_t* edges, int64_t 
         add((int32_t)edges[2 * e], project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
         add((int32_t)edges[2 * e + 1], project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
     }
+}
+
+// ---- projected primary visibility (drt_raster.h): the per-image model, per-ray verification, projected pixel boxes, and the
+// whole decision for a grid of rays -- closest hit per pixel by testing each triangle against the pixels of its padded box only.
+int hs_fit_view(const double* origin, const double* dir, int w, int h, double* model14 /* o[3], minv[9], ok, lattice_ok */) {
+    ViewModel vm;
+    const int64_t i00 = 0, iW0 = w - 1, i0H = (int64_t)(h - 1) * w, iWH = i0H + (w - 1);
+    const bool ok = fit_view_model(load_d3(origin, i00), load_d3(dir, i00), load_d3(dir, iW0), load_d3(dir, i0H), load_d3(dir, iWH), (double)(w - 1), (double)(h - 1), vm);
+    vm.ok = ok ? 1 : 0;
+    bool lattice = ok;
+    for (int sy = 0; sy < 8 && lattice; ++sy)
+        for (int sx = 0; sx < 8 && lattice; ++sx) {
+            const int x = (int)(((int64_t)(w - 1) * sx) / 7), y = (int)(((int64_t)(h - 1) * sy) / 7);
+            const int64_t i = (int64_t)y * w + x;
+            lattice = view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)y);
+        }
+    for (int k = 0; k < 3; ++k) model14[k] = vm.o[k];
+    for (int k = 0; k < 9; ++k) model14[3 + k] = vm.minv[k];
+    model14[12] = vm.ok; model14[13] = lattice ? 1 : 0;
+    return ok ? 1 : 0;
+}
+
+// every ray verified against the model: flags [w*h]
+void hs_verify_rays(const double* model14, const double* origin, const double* dir, int w, int h, uint8_t* flags) {
+    ViewModel vm;
+    for (int k = 0; k < 3; ++k) vm.o[k] = model14[k];
+    for (int k = 0; k < 9; ++k) vm.minv[k] = model14[3 + k];
+    vm.ok = 1; vm.all = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int64_t i = (int64_t)y * w + x;
+            flags[i] = view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)y) ? 1 : 0;
+        }
+}
+
+// Primary hits of one image by projection (what k_raster + k_cull decide on the GPU): T, ID as hs_intersect; returns the number
+// of (triangle, pixel) tests, or -1 when some triangle has no projection bound (camera plane).
+int64_t hs_raster(void* hnd, const double* model14, const double* origin, const double* dir, int w, int h, float* T, int32_t* ID) {
+    HsScene* s = (HsScene*)hnd;
+    ViewModel vm;
+    for (int k = 0; k < 3; ++k) vm.o[k] = model14[k];
+    for (int k = 0; k < 9; ++k) vm.minv[k] = model14[3 + k];
+    vm.ok = 1; vm.all = 0;
+    std::vector<unsigned long long> key((size_t)w * h, kRasterEmpty);
+    const d3 o{vm.o[0], vm.o[1], vm.o[2]};
+    const f3 o32 = to_f32(o);
+    int64_t tests = 0;
+    for (const TriRec& t : s->tris) {
+        const PixelBox box = project_tri_box(vm, o32, t, w, h);        // the function k_raster calls
+        if (box.unsafe) return -1;
+        for (int y = box.y0; y <= box.y1; ++y)
+            for (int x = box.x0; x <= box.x1; ++x) {
+                const int64_t i = (int64_t)y * w + x;
+                ++tests;
+                float tt;
+                if (tri_hit(o32, to_f32(load_d3(dir, i)), f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) {
+                    const unsigned long long k = raster_key(tt, t.face);
+                    if (k < key[i]) key[i] = k;
+                }
+            }
+    }
+    for (int64_t i = 0; i < (int64_t)w * h; ++i) {
+        if (key[i] == kRasterEmpty) { T[i] = -1.0f; ID[i] = -1; continue; }
+        const uint32_t tb = (uint32_t)(key[i] >> 32);
+        memcpy(&T[i], &tb, 4);
+        ID[i] = (int32_t)(uint32_t)key[i];
+    }
+    return tests;
 }
 
 }  // extern "C"

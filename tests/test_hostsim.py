@@ -322,3 +322,50 @@ def test_degenerate_faces_vs_golden(hostsim, hand):
     ref = g["grad_sm"]
     assert np.array_equal(np.isnan(gsm), np.isnan(ref))
     np.testing.assert_allclose(gsm, ref, rtol=1e-8, atol=1e-10 * np.nanmax(np.abs(ref)), equal_nan=True)
+
+
+def test_projected_primary_visibility_math(hostsim, hand):
+    """drt_raster.h compiled for the host: the pinhole model fitted from four rays of a generate_ray image reproduces K^-1 / R^-1,
+    every ray verifies (and perturbed ones do not), and deciding the primary hits by testing each triangle against the pixels of
+    its padded projected box equals the exhaustive float32 test bit for bit -- with ~3 tests per triangle."""
+    s = HostScene(hostsim, hand.faces, hand.vertices)
+    c, ext = views.mesh_frame(hand.vertices)
+    for (w, h, view) in ((128, 128, 5), (192, 64, 40), (64, 96, 23)):
+        R, K, Rinv, Kinv = views.turntable_cameras(c, ext, 72, w, h)[view]
+        o, d = views.generate_ray(h, w, Kinv, Rinv)
+        on, dn = np.ascontiguousarray(o.numpy()), np.ascontiguousarray(d.numpy())
+        model = np.zeros(14)
+        assert hostsim.hs_fit_view(on.ctypes.data, dn.ctypes.data, w, h, model.ctypes.data) == 1 and model[12] == 1 and model[13] == 1
+        assert np.array_equal(model[:3], Rinv[:3, 3])
+        # minv ~ (R^-1[:3,:3] K^-1)^-1 = K R[:3,:3] up to the scale fixed by the first ray
+        M = np.asarray(K) @ np.asarray(R)[:3, :3]
+        minv = model[3:12].reshape(3, 3)
+        np.testing.assert_allclose(minv / minv[2, 2], M / M[2, 2], rtol=1e-9, atol=1e-9)
+        flags = np.zeros(w * h, np.uint8)
+        hostsim.hs_verify_rays(model.ctypes.data, on.ctypes.data, dn.ctypes.data, w, h, flags.ctypes.data)
+        assert flags.all()
+        T = np.zeros(w * h, np.float32); ID = np.zeros(w * h, np.int32)
+        tests = hostsim.hs_raster(s.h, model.ctypes.data, on.ctypes.data, dn.ctypes.data, w, h, T.ctypes.data, ID.ctypes.data)
+        To, IDo = orc.trace_closest(s.f32, s.v32, _rays32(o, d))
+        assert np.array_equal(ID, IDo) and np.array_equal(T, To)
+        assert (IDo >= 0).sum() > 50 and 0 < tests < 8 * len(hand.faces) + 4 * (IDo >= 0).sum()
+        # rays that are not the grid's: shifted by a pixel, another origin, a tiny rotation of every direction
+        bad = dn.copy(); bad[:-1] = dn[1:]
+        hostsim.hs_verify_rays(model.ctypes.data, on.ctypes.data, bad.ctypes.data, w, h, flags.ctypes.data)
+        assert flags.mean() < 0.02
+        off = on.copy(); off[:, 1] += 1e-9
+        hostsim.hs_verify_rays(model.ctypes.data, off.ctypes.data, dn.ctypes.data, w, h, flags.ctypes.data)
+        assert not flags.any()
+        th = 3e-5                                   # ~0.03 px at these focal lengths: above the 1e-3 px tolerance
+        rot = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+        hostsim.hs_verify_rays(model.ctypes.data, on.ctypes.data, np.ascontiguousarray(dn @ rot.T).ctypes.data, w, h, flags.ctypes.data)
+        assert flags.mean() < 0.5
+    # a "camera" inside the object: some triangle has no projection bound
+    Kin = np.array([[40.0, 0, 32], [0, 40.0, 32], [0, 0, 1]])
+    Rin = np.eye(4); Rin[:3, 3] = c
+    o, d = views.generate_ray(64, 64, np.linalg.inv(Kin), Rin)
+    on, dn = np.ascontiguousarray(o.numpy()), np.ascontiguousarray(d.numpy())
+    model = np.zeros(14)
+    assert hostsim.hs_fit_view(on.ctypes.data, dn.ctypes.data, 64, 64, model.ctypes.data) == 1
+    T = np.zeros(64 * 64, np.float32); ID = np.zeros(64 * 64, np.int32)
+    assert hostsim.hs_raster(s.h, model.ctypes.data, on.ctypes.data, dn.ctypes.data, 64, 64, T.ctypes.data, ID.ctypes.data) == -1
