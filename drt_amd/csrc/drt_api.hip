@@ -35,12 +35,15 @@ int drt_create(int device, drt_scene_t** out) {
     if (const char* ev = getenv("DRT_ASYNC_BUILD")) s->async_build = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_STREAMS")) { const int v = atoi(ev); if (v >= 1 && v <= drt_scene::kMaxSub) s->n_sub = v; }
     if (const char* ev = getenv("DRT_RASTER")) s->use_raster = atoi(ev) != 0;
+    if (const char* ev = getenv("DRT_FILL_OVERLAP")) s->fill_overlap = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_SUB_PER_STREAM")) { const int v = atoi(ev); if (v >= 1 && v <= 16) s->sub_per_stream = v; }
     if (const char* ev = getenv("DRT_MIN_SUB_LOG2")) { const int v = atoi(ev); if (v >= 12 && v <= 30) s->min_sub_rays = (int64_t)1 << v; }
     for (int k = 0; k < s->n_sub && e == hipSuccess; ++k) {
         drt_scene::Sub& w = s->sub[k];
         e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.fill_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.fill_join, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * 8);
         if (e == hipSuccess) e = hipMalloc(&w.slow_stack, sizeof(int32_t) * (size_t)kRedoGrid * kTraceBlock * kStackSlowDev);
     }
@@ -86,6 +89,8 @@ void drt_destroy(drt_scene_t* s) {
         (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2); (void)hipFree(w.qcount); (void)hipFree(w.slow_stack); (void)hipFree(w.redo);
         (void)hipFree(w.zbuf); (void)hipFree(w.zmask); (void)hipFree(w.vmodel); (void)hipFree(w.big); (void)hipFree(w.big_count); (void)hipFree(w.gen_list);
         if (w.done) (void)hipEventDestroy(w.done);
+        if (w.fill_fork) (void)hipEventDestroy(w.fill_fork);
+        if (w.fill_join) (void)hipEventDestroy(w.fill_join);
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     (void)hipFree(s->vcount);

@@ -388,7 +388,8 @@ __global__ void __launch_bounds__(kPathBlock) k_patch_list(unsigned n_patches, i
 template <bool FUSED>
 __global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                        int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
+                                                        int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p,
+                                                        bool prefilled /* the dense outputs hold (or are being filled with) the dead values */) {
     __shared__ StageMem stage;
     stage_init(stage);
     const unsigned n0 = p.count[0];
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* 
                 ok = !b.tir;
                 o2 = to_f32(b.new_o); d2 = to_f32(b.wt);
             }
-            if (!ok && !FUSED) write_dead(i, out_ori, out_dir, mask, face2);
+            if (!ok && !FUSED) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
         }
         stage_push(stage, ok, (int32_t)i, o2, d2, p.r1, &p.count[1]);
     }
@@ -904,6 +905,10 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
     RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
+    bool late_fill = false;
+    // the scene's build stream is idle once the tree is built (before the cull stage): it carries the late fills, so that the
+    // library stays within the four hardware queues a process gets by default (more streams would share queues with these)
+    hipStream_t fs = s->prof_serial ? st : s->build_stream;
     const int64_t image = (int64_t)tile_w * tile_h;
     if (raster_on(s, n, tile_w, tile_h)) {
         const int n_views = (int)(n / image);
@@ -911,11 +916,16 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         if (rc) return rc;
         if (!grid_cache) grid_mode = DRT_GRID_NONE;
         if (!FUSED && grid_mode == DRT_GRID_TRUST) {
-            // dead values into every dense output first (plain memsets run at the full write rate); k_cull_listed then only
-            // visits the patches that matter.  Together with the projection pass this needs no tree: it overlaps the build.
-            StageTimer t(s, st, kStageFill);
-            (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
-            (void)hipMemsetAsync(mask, 0, 3 * n, st);
+            // dead values into every dense output (plain memsets run at the full write rate); k_cull_listed then only visits
+            // the patches that matter.  Nothing writes a row of out_ori / out_dir / mask before k_shade2, so with
+            // `fill_overlap` these three memsets are issued later, on the sub-batch's fill stream, beside the VALU-bound
+            // traversal of the refracted rays (see below); the face-id arrays (written by k_shade1) are filled here.
+            late_fill = s->fill_overlap;
+            if (!late_fill) {
+                StageTimer t(s, st, kStageFill);
+                (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
+                (void)hipMemsetAsync(mask, 0, 3 * n, st);
+            }
             if (!sparse_faces) { (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st); }
         }
         StageTimer t(s, st, kStageRaster);
@@ -935,6 +945,13 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
       } else {
           k_cull<FUSED><<<n_patches, kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
       } }
+    if (late_fill) {      // (StageTimer scopes must not nest: this one follows the cull stage's)
+        if (fs != st) { HIP_TRY(hipEventRecord(w.fill_fork, st)); HIP_TRY(hipStreamWaitEvent(fs, w.fill_fork, 0)); }
+        { StageTimer tf(s, fs, kStageFill);
+          (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, fs); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, fs);
+          (void)hipMemsetAsync(mask, 0, 3 * n, fs); }
+        if (fs != st) HIP_TRY(hipEventRecord(w.fill_join, fs));
+    }
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
     { StageTimer t(s, st, kStageTrace1);
@@ -947,10 +964,11 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
           k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, TraceOut{p.r0.face, nullptr, nullptr, nullptr});
       } }
     { StageTimer t(s, st, kStageShade1);
-      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
+      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill); }
     { StageTimer t(s, st, kStageTrace2);
       k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
       k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, TraceOut{p.r1.face, nullptr, nullptr, nullptr}); }
+    if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));     // k_shade2 is the first kernel that writes rows of the dense outputs
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);

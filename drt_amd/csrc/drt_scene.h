@@ -100,6 +100,7 @@ struct drt_scene {
     struct Sub {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        hipEvent_t fill_fork = nullptr, fill_join = nullptr; // around the dense-output memsets of a DRT_GRID_TRUST call, issued beside the traversal
         int32_t* q_idx[3] = {nullptr, nullptr, nullptr};     // ray lists R0..R2: index,
         float* q_ray[3] = {nullptr, nullptr, nullptr};       //   float32 ray [cap,6],
         int32_t* q_face[3] = {nullptr, nullptr, nullptr};    //   traversal result
@@ -147,6 +148,7 @@ struct drt_scene {
     int inner_min = 16;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
     int64_t chunk_rays = kChunkRays;
 
+    bool fill_overlap = true;      // DRT_FILL_OVERLAP=0: the dense-output memsets of a DRT_GRID_TRUST call stay in front of the projection pass
     bool use_raster = true;        // DRT_RASTER=0: every primary ray takes the BVH path (A/B measurement)
     bool built = false;
 };

@@ -27,7 +27,9 @@ static Box refit(Tree& t, int32_t c, const std::vector<Box>& leaf) {      // ret
     return box_union(a, b);
 }
 
+static int32_t* g_per_ray = nullptr;
 extern "C" {
+void bvhq_per_ray(int32_t* out) { g_per_ray = out; }      // optional: visits of every ray of the next calls
 // order[k] = face in slot k; child0/child1[i] for inner node i (root 0): >= 0 inner, < 0 leaf ~slot.  When child0 == nullptr the
 // tree is the product's: Morton order (order is then an OUTPUT) + Karras hierarchy.
 double bvhq_visits(const int32_t* faces, int64_t n_faces, const float* verts, int64_t n_verts, int32_t* order,
@@ -77,6 +79,7 @@ double bvhq_visits(const int32_t* faces, int64_t n_faces, const float* verts, in
         }
         total += (double)vis; leafs += (double)lv;
         ID_out[r] = s.best_face;
+        if (g_per_ray) g_per_ray[r] = (int32_t)vis;
     }
     if (leaf_visits_out) *leaf_visits_out = leafs / (double)n_rays;
     return total / (double)n_rays;

@@ -14,5 +14,5 @@ sel = rows[-int(sys.argv[2]):]
 t0 = int(sel[0]["Start_Timestamp"])
 for r in sel:
     st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print("%-44s start %9.1f us  dur %8.1f us  grid %s wg %s stream %s" % (r["Kernel_Name"].split("(")[0][:44], (st - t0) / 1e3, (en - st) / 1e3, r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("Stream_Id", r.get("Queue_Id"))))
+    print("%-44s start %9.1f us  dur %8.1f us  grid %s wg %s stream %s" % (r["Kernel_Name"].split("(")[0][:44], (st - t0) / 1e3, (en - st) / 1e3, r.get("Grid_Size"), r.get("Workgroup_Size"), str(r.get("Stream_Id")) + " queue " + str(r.get("Queue_Id"))))
 PY
