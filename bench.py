@@ -75,7 +75,7 @@ def _pmc(mode, workload):
         return {}
 
 
-def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None):
+def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None, live=None):
     """Per-kernel live timing (hipEvents on the launch streams, drt_profile_*) -> the kernel that takes the most time, BY
     KERNEL NAME (the two closest-hit traversals are one kernel), with the bound that applies to it, and the HBM-streaming
     stage beside it.
@@ -178,7 +178,9 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
                 "traversal": {k: issue_entry(k) for k in ("k_trace<closest>", "k_trace<any>") if k in by_kernel},
                 "stages": stages, "stages_alone_avg_launch_ms": {k: v["avg_launch_ms"] for k, v in alone.items()} if alone else None,
                 "whole_step_alg_GBps_per_gpu": round(step_alg / (elapsed / args.steps) / 1e9 / world, 1),
-                "note": "times are hipEvent pairs on the launch streams over the timed region; sub-batches run on two internal streams, so stage "
+                "live_stages": list(live) if live else None,
+                "note": "k_trace times (stages trace1..3) are hipEvent pairs on the launch streams INSIDE the timed region (N = 1); the other stages are "
+                        "timed in an immediate repeat of the same steps with every stage's events on; sub-batches run on two internal streams, so stage "
                         "durations overlap (`alone`: the same steps, untimed, with the streams serialised). The kernel that takes the most time is "
                         "the closest-hit traversal: VALU-issue bound on an L2-resident tree (see node_visits_per_ray, lane_utilisation); the HBM "
                         "stage is the fill of the dense outputs + k_cull."})
@@ -368,8 +370,10 @@ def main():
     # N = 1: the per-kernel hipEvent pairs are recorded live inside the timed region (the roofline contract).  N > 1: they
     # are recorded in an eager repeat right after it, so that ~120 event records per step do not sit in a 1.7 ms step.
     live_profile = not args.graph and world == 1 and not os.environ.get('DRT_BENCH_NOPROF')
+    LIVE = ("trace1", "trace2", "trace3")       # every k_trace launch: the kernel the roofline is about
     if live_profile:
-        scene.optix_mesh.profile_enable(True)   # hipEvent pairs around every pipeline kernel, on the launch stream
+        scene.optix_mesh.profile_select(LIVE)   # hipEvent pairs around the traversal kernels only (the other stages are
+        scene.optix_mesh.profile_enable(True)   # timed in the repeat below: ~50 more event records per step cost 0.15 ms of 3.3)
         scene.optix_mesh.profile_read()
     ddist.barrier()
     torch.cuda.synchronize()
@@ -392,7 +396,8 @@ def main():
                    "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4),
                    "final_loss": float(loss.item())},
     }
-    prof_timed = scene.optix_mesh.profile_read() if live_profile else None
+    prof_live = scene.optix_mesh.profile_read() if live_profile else None
+    scene.optix_mesh.profile_select(None)
     fused_extra = None
     if args.mode == "dropin" and not args.graph and not args.no_extras:   # (N = 1 and N > 1 alike)
         # same K steps through the one-pass API (Scene.ray_loss_fused: no dense out_ori/out_dir/mask, rays of
@@ -445,15 +450,16 @@ def main():
         route_b = {"M_rays_per_s": round(P / tb / 1e6, 3), "ms_per_view": round(1e3 * tb, 3),
                    "what": f"one {res}x{res} view per call: update_vert + Scene.trace2 (stepwise float64 torch ops, autograd) + occlusion query + ray loss + "
                            "backward, all traversals through optix_mesh.intersect (drt_intersect) -- the reference's DiffRender.py shape on the HIP tracer"}
-    if not live_profile:
-        # (events cannot be recorded inside a replayed graph either:) repeat the same K steps eagerly, right after the
-        # timed region, with the per-kernel event pairs on (same kernels, same inputs, same launch stream)
-        scene.optix_mesh.profile_enable(1)
-        scene.optix_mesh.profile_read()
-        for _ in range(args.steps):
-            step(True)
-        prof_timed = scene.optix_mesh.profile_read()
-    prof = prof_timed
+    # every stage's event pairs: the same K steps repeated eagerly right after the timed region (same kernels, same inputs, same
+    # launch streams).  N = 1: the traversal kernels' rows are then replaced by the ones recorded live INSIDE the timed region;
+    # N > 1 and graph replay (no events inside a replayed graph): all rows come from this repeat.
+    scene.optix_mesh.profile_enable(1)
+    scene.optix_mesh.profile_read()
+    for _ in range(args.steps):
+        step(True)
+    prof = scene.optix_mesh.profile_read()
+    if prof_live:
+        prof.update({k: prof_live[k] for k in LIVE if prof_live[k][1] > 0})
     # one extra, untimed step (on every rank: it contains the all-reduce) with the traversal statistics
     # switched on -- they cost contended atomics, so they are kept out of the timed region
     tstats, prof2 = {}, None
@@ -475,7 +481,7 @@ def main():
         prof_iso = scene.optix_mesh.profile_read()
     scene.optix_mesh.profile_enable(0)
     if rank == 0:
-        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso)
+        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso, LIVE if prof_live else None)
         for k, (ws, ls, rf, mx) in tstats.items():
             if ws and k in out["roofline"]["stages"]:
                 out["roofline"]["stages"][k].update({"node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),

@@ -55,6 +55,7 @@ SIGNATURES = {
     "drt_mesh_buf_copy": (_c.c_int, [_P, _P, _P]),
     "drt_mesh_buf_free": (None, [_P]),
     "drt_profile_enable": (_c.c_int, [_P, _c.c_int]),
+    "drt_profile_select": (_c.c_int, [_P, _c.c_uint32]),
     "drt_profile_read": (_c.c_int, [_P, _P, _P, _P]),
     "drt_profile_trace_stats": (_c.c_int, [_P, _P]),
 }

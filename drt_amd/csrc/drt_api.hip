@@ -116,6 +116,12 @@ int drt_profile_enable(drt_scene_t* s, int on) {
     return DRT_OK;
 }
 
+int drt_profile_select(drt_scene_t* s, uint32_t stage_mask) {
+    CHECK_SCENE(s);
+    s->prof_mask = stage_mask;
+    return DRT_OK;
+}
+
 int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out) {
     CHECK_SCENE(s);
     if (!ms_out || !launches_out || !items_out) return fail(DRT_E_INVALID, "null pointer argument");

@@ -901,6 +901,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h,
                         int grid_mode, ViewModel* grid_cache /* models of the images of THIS sub-batch */) {
     const bool sparse_faces = (grid_mode & DRT_GRID_SPARSE_FACES) != 0;
+    const bool all_verified = (grid_mode & DRT_GRID_ALL_VERIFIED) != 0 && (grid_mode & 3) == DRT_GRID_TRUST && grid_cache;
     grid_mode &= 3;
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
@@ -955,7 +956,9 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
     { StageTimer t(s, st, kStageTrace1);
-      if (rz.views) {       // only the R0 slots listed by k_cull (rays that are not grid rays)
+      if (rz.views && all_verified) {
+          // every ray of every image is a verified grid ray (the caller read that off the cache): nothing was listed
+      } else if (rz.views) {       // only the R0 slots listed by k_cull (rays that are not grid rays)
           const TraceOut out{p.r0.face, nullptr, nullptr, w.gen_list};
           k_trace<false, 2><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 3, out, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
           k_trace_redo<false, 2><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, out);

@@ -132,6 +132,7 @@ struct drt_scene {
     int64_t vh_cap = 0;            //   another stream than a pipeline call (which owns the Sub workspaces)
     // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream
     bool prof_on = false;
+    uint32_t prof_mask = ~0u;                 // stages that are timed while prof_on (drt_profile_select)
     bool prof_stats = false;                  // level 2: k_trace also accumulates visit statistics (adds contended atomics)
     bool prof_serial = false;                 // level 3: sub-batches run on ONE internal stream, so that each kernel is timed alone
     std::vector<hipEvent_t> prof_ev;          // pool, used pairwise
@@ -196,7 +197,7 @@ inline PathCtx path_ctx(const drt_scene* s, const double* d_verts, double ior_in
 struct StageTimer {
     drt_scene* s; hipStream_t st; bool on;
     StageTimer(drt_scene* s_, hipStream_t st_, int stage) : s(s_), st(st_), on(false) {
-        if (!s->prof_on) return;
+        if (!s->prof_on || !((s->prof_mask >> stage) & 1u)) return;
         if (s->prof_used + 2 > s->prof_ev.size() && !grow()) { ++s->prof_dropped; return; }
         on = true;
         s->prof_stage[s->prof_used / 2] = stage;

@@ -207,16 +207,34 @@ def local_loss_backward(scene, local_views, init_vertices, parameter, ray_w, fus
     parameter in ``parameter.grad`` (None for a rank without views) and returns the unweighted loss."""
     vertices = init_vertices + parameter
     scene.update_verticex(vertices)
-    loss = torch.zeros((), dtype=Float, device=vertices.device)
+    parts = []
     for target, valid, origin, ray_dir in local_views:
         if fused:
-            loss = loss + scene.ray_loss_fused(origin, ray_dir, target, valid)
+            parts.append(scene.ray_loss_fused(origin, ray_dir, target, valid))
         else:
             out_ori, out_dir, mask = scene.render_transparent(origin, ray_dir)
-            loss = loss + Render.ray_loss(out_ori, out_dir, mask, target, valid)
+            parts.append(Render.ray_loss(out_ori, out_dir, mask, target, valid))
+    if not parts:
+        return torch.zeros((), dtype=Float, device=vertices.device)
+    loss = parts[0] if len(parts) == 1 else torch.stack(parts).sum()
     if loss.requires_grad:
-        (ray_w * loss).backward()
+        # d(ray_w * loss): the weight goes in as the seed of the backward pass (one cached scalar) instead of a multiplication
+        # node -- the step is a chain of small launches, and each elementwise kernel of the loss arithmetic is ~5 us of it
+        loss.backward(_seed(ray_w, loss))
     return loss
+
+
+_SEEDS = {}
+
+
+def _seed(w, like):
+    key = (float(w), like.dtype, like.device)
+    t = _SEEDS.get(key)
+    if t is None:
+        if len(_SEEDS) > 64:
+            _SEEDS.clear()
+        t = _SEEDS[key] = torch.full((), float(w), dtype=like.dtype, device=like.device)
+    return t
 
 
 def full_batch_step(scene, local_views, init_vertices, parameter, opt, ray_w, fused=False):

@@ -164,6 +164,11 @@ class optix_mesh:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().drt_profile_enable(self._h, int(on)))
 
+    def profile_select(self, stages=None):
+        """Time only the named stages (``STAGES`` entries) while the profile is on; None: all of them."""
+        mask = 0xFFFFFFFF if stages is None else sum(1 << self.STAGES.index(k) for k in stages)
+        _lib.check(_lib.lib().drt_profile_select(self._h, mask))
+
     def profile_read(self):
         """{stage: (total_ms, launches, items)} since the previous read; synchronises the stream."""
         n = len(self.STAGES)

@@ -100,6 +100,10 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
 /* OR-ed into grid_mode: d_face1 / d_face2 are only guaranteed for the rays with mask = 1 (what drt_render_backward* read);
  * in DRT_GRID_TRUST mode the -1 entries of all other rays are then not written (8 bytes per ray less to fill). */
 #define DRT_GRID_SPARSE_FACES 16
+/* OR-ed into DRT_GRID_TRUST: the caller has read the cache back after the establishing call and EVERY image in it is recorded
+ * as a pinhole grid in all of its rays (int32 `ok` and `all` at byte offsets 96 and 100 of each DRT_GRID_CACHE_BYTES record
+ * both non-zero).  No ray can then need the tree for its primary hit, and the two launches that serve such rays are not issued. */
+#define DRT_GRID_ALL_VERIFIED 32
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
                        double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
@@ -274,6 +278,10 @@ int drt_subdivide_midpoint(const int64_t* d_faces, int64_t n_faces, const double
  * of returning under-reported stage times. */
 #define DRT_PROFILE_STAGES 13
 int drt_profile_enable(drt_scene_t* s, int on);
+/* Which stages are timed while the profile is on: bit k = stage k of the list above (default: all).  Every timed launch costs
+ * two event records on its stream (~1.5 us each inside a step of ~100 launches): a measurement that only needs the traversal
+ * kernels' launch times -- bench.py's timed region -- selects those and leaves the rest of the step undisturbed. */
+int drt_profile_select(drt_scene_t* s, uint32_t stage_mask);
 int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out);
 /* Traversal diagnostics of the last drt_profile_read interval, 4 values for each of the three
  * k_trace stages: node visits summed over wavefronts ("wave-steps"), over lanes ("lane-steps";

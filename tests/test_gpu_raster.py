@@ -182,7 +182,7 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     sp = torch.randn(o.shape, dtype=torch.float64, device="cuda"); valid = torch.rand(len(o), device="cuda") < 0.6
 
     def run(expect_mode):
-        assert diffrender._grid_cache(o, d, len(o), res, res)[0] == expect_mode or expect_mode is None
+        assert (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == expect_mode or expect_mode is None
         tr.profile_enable(1); tr.profile_read()
         with torch.no_grad():
             oo, od, mk = scene.render_transparent(o, d)
@@ -198,7 +198,7 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
         prof, out = run(None)
         assert prof["trace1"][2] > 0                       # the distorted image takes the tree, every time
         if it > 0:
-            assert diffrender._grid_cache(o, d, len(o), res, res)[0] == 2
+            assert (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == 2
         # the fused loss on the same tensors shares the verdict
         V = scene.vertices.detach().clone().requires_grad_(True)
         scene.update_verticex(V)
@@ -221,7 +221,7 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     # in-place writes: image 0 loses a few grid rays (and its trust), image 2 keeps it
     ver = d._version
     d[1000:1010] = d[5000:5010].clone()
-    assert d._version > ver and diffrender._grid_cache(o, d, len(o), res, res)[0] == 1
+    assert d._version > ver and (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == 1
     del d._drt_grid
     prof, _ = run(None)
     prof2, _ = run(None)                                   # trusted call after the re-establishment
