@@ -338,6 +338,7 @@ int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
 static int rebuild_impl(drt_scene* s, hipStream_t st) {
     const int n = (int)s->n_faces;
     s->built = true;
+    s->order_valid = false;
     if (n == 0) return DRT_OK;
     const int tiles = (n + kSortTile - 1) / kSortTile;
     const bool fused_sort = tiles <= kSortFusedTiles;
@@ -363,15 +364,22 @@ static int rebuild_impl(drt_scene* s, hipStream_t st) {
                                              s->parent_inner, s->parent_leaf, s->flags);
     k_collapse4<<<(inner + 255) / 256, 256, 0, st>>>(s->nodes, s->parent_inner, s->range_lo, s->range_hi, n, s->wide);
     HIP_TRY(hipGetLastError());
+    s->order_valid = cur == 0;       // idx[0] = the face ids in Morton order, kept until the next build starts
     return DRT_OK;
 }
 
 // Triangle records in FACE order: what the projected primary-visibility pass reads (it needs no tree), so that it can run
 // while the tree is still being built.
-__global__ void k_tri_flat(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n, TriRec* __restrict__ tris) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    tris[f] = make_tri(ld_vert(verts, faces[3 * f]), ld_vert(verts, faces[3 * f + 1]), ld_vert(verts, faces[3 * f + 2]), f);
+// `order`: the Morton order of the PREVIOUS build over the same faces (null right after a topology change: face order).
+// The records carry their face id, so any order gives the same result; a spatially coherent one lets the wave-aggregated
+// tile binning of the projection pass (drt_raster.hip) issue a few list atomics per wave instead of one per triangle --
+// and the vertices move little between two steps of an optimisation.
+__global__ void k_tri_flat(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n, TriRec* __restrict__ tris,
+                           const uint32_t* __restrict__ order) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int f = order ? (int)order[k] : k;
+    tris[k] = make_tri(ld_vert(verts, faces[3 * f]), ld_vert(verts, faces[3 * f + 1]), ld_vert(verts, faces[3 * f + 2]), f);
 }
 
 // The LBVH build is ten small dependent launches (~0.17 ms at 50 k triangles, launch-latency bound).  It runs on the
@@ -380,7 +388,9 @@ __global__ void k_tri_flat(const int32_t* __restrict__ faces, const float* __res
 // records written here, overlap it.
 int rebuild(drt_scene* s, hipStream_t st) {
     const int n = (int)s->n_faces;
-    if (n > 0) k_tri_flat<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->tris_flat);
+    // (the previous build's sorted ids are still in idx[0]: this launch precedes the fork of the build stream, whose k_morton
+    // overwrites them)
+    if (n > 0) k_tri_flat<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->tris_flat, s->order_valid ? s->idx[0] : nullptr);
     hipStream_t bs = s->async_build ? s->build_stream : st;
     if (bs != st) {
         HIP_TRY(hipEventRecord(s->build_fork, st));
@@ -420,6 +430,7 @@ int drt_update_mesh(drt_scene_t* s, const int32_t* d_faces, int64_t n_faces, con
     if (rc) return rc;
     s->n_faces = n_faces;
     s->n_verts = n_verts;
+    s->order_valid = false;          // new topology: the previous build's order is not a permutation of these faces
     if (n_faces) HIP_TRY(hipMemcpyAsync(s->faces, d_faces, sizeof(int32_t) * 3 * n_faces, hipMemcpyDeviceToDevice, st));
     if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
     return rebuild(s, st);

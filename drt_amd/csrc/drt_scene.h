@@ -82,6 +82,7 @@ struct drt_scene {
     hipStream_t build_stream = nullptr;   // the LBVH build runs here, beside the caller's next fills / projection pass
     hipEvent_t build_fork = nullptr, build_done = nullptr;
     bool build_pending = false;    // a build was enqueued on build_stream: consumers of the tree wait for build_done
+    bool order_valid = false;      // idx[0] holds the Morton order of the last build over the CURRENT faces (k_tri_flat's order)
     bool async_build = true;       // DRT_ASYNC_BUILD=0: build on the caller's stream
     uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
     uint32_t* hist = nullptr;      // [kRadix * tiles]
@@ -119,6 +120,10 @@ struct drt_scene {
         void* big = nullptr;
         unsigned* big_count = nullptr;
         int32_t* gen_list = nullptr;                         // [q_cap] R0 slots whose ray did not verify as a grid ray: traced like before
+        uint32_t* tile_words = nullptr;                      // tiled pass: counters, offsets, kept counts, ids [tile_cap each] + control words
+        int64_t tile_cap = 0;
+        uint32_t* bin_list = nullptr;                        //   triangle ids binned per 64x16 tile [bin_cap]
+        int64_t bin_cap = 0;
     };
     static constexpr unsigned kBigCap = 1u << 20;
     static constexpr int kMaxSub = 4;
@@ -150,6 +155,7 @@ struct drt_scene {
     int64_t chunk_rays = kChunkRays;
 
     bool fill_overlap = true;      // DRT_FILL_OVERLAP=0: the dense-output memsets of a DRT_GRID_TRUST call stay in front of the projection pass
+    bool raster_tiles = false;     // DRT_RASTER_TILES=1: the tiled projection pass (experiment: slower than the untiled one, see drt_raster.hip)
     bool use_raster = true;        // DRT_RASTER=0: every primary ray takes the BVH path (A/B measurement)
     bool built = false;
 };

@@ -62,6 +62,12 @@ def test_grid_rays_are_decided_by_projection_and_equal_bruteforce(Render):
     o2, d2 = views.generate_ray(192, 320, cams[7][3], cams[7][2], device="cuda")
     prof, _ = _check(Render, scene, o2, d2, 320, 192)
     assert prof["raster"][2] == len(o2) and prof["trace1"][2] == 0
+    # a height that is not a multiple of the 16-row tiles of the projection pass (its last tile row is cut), two images
+    cams = views.turntable_cameras(c, ext, 72, 128, 200)
+    rays = [views.generate_ray(200, 128, cams[k][3], cams[k][2], device="cuda") for k in (3, 40)]
+    o3 = torch.cat([r[0] for r in rays]).contiguous(); d3 = torch.cat([r[1] for r in rays]).contiguous()
+    prof, f3 = _check(Render, scene, o3, d3, 128, 200)
+    assert prof["raster"][2] == len(o3) and prof["trace1"][2] == 0 and (f3 >= 0).any()
 
 
 def test_rays_outside_the_grid_fall_back_to_the_tree(Render):
@@ -182,7 +188,8 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     sp = torch.randn(o.shape, dtype=torch.float64, device="cuda"); valid = torch.rand(len(o), device="cuda") < 0.6
 
     def run(expect_mode):
-        assert (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == expect_mode or expect_mode is None
+        if expect_mode is not None:     # (peeking creates the record: only where the test means to)
+            assert (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == expect_mode
         tr.profile_enable(1); tr.profile_read()
         with torch.no_grad():
             oo, od, mk = scene.render_transparent(o, d)
@@ -197,6 +204,7 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
             del d._drt_grid
         prof, out = run(None)
         assert prof["trace1"][2] > 0                       # the distorted image takes the tree, every time
+        assert prof["trace1"][2] < 0.6 * prof["shade1"][2]  # ... and the two grid images do not
         if it > 0:
             assert (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == 2
         # the fused loss on the same tensors shares the verdict
@@ -225,7 +233,9 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     del d._drt_grid
     prof, _ = run(None)
     prof2, _ = run(None)                                   # trusted call after the re-establishment
-    assert prof2["trace1"][2] == prof["trace1"][2] > 0
+    # (the establishing call sends image 0's ten foreign rays to the tree; a trusting call sends ALL of image 0 there: only
+    # images verified in every ray are recorded as grids -- k_store_models)
+    assert prof2["trace1"][2] > prof["trace1"][2] > 0
     o[2 * P + 5] += 1.0                                    # and an origin write
     prof3, _ = run(None)
     assert prof3["trace1"][2] >= prof2["trace1"][2]
