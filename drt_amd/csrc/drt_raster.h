@@ -17,9 +17,12 @@
 // Nothing is assumed about the caller's rays: the model (origin, M^-1) of every image is FITTED on the device from four
 // of its rays, every single ray is then VERIFIED against it in k_cull (origin bit-equal, pixel position within
 // kRasterVerifyTol), and a ray that does not verify -- calibrated per-pixel rays of a real capture, arbitrary ray
-// lists -- takes the BVH path as before.  Conservative by construction: the box is grown by kRasterPad pixels, two
-// orders above what the float32 test's rounding, the float32 cast of the ray and the verification tolerance add up to
-// (the BVH's own leaf padding, 2^-13 of the scene extent, is ~0.06 px in the benchmark geometry).
+// lists -- takes the BVH path as before.  Conservative by construction: the box is grown by kRasterPad = 1/16 pixel.  What
+// it has to cover, in pixels of a 1024-wide image of a ~500 mm distant object: the float32 projection of the vertices
+// (~2e-4), the distance a verified ray may be from its pixel centre (kRasterVerifyTol = 1e-3) and how far outside a
+// triangle the float32 test can still accept a ray (rounding of dot(s, p) against the pixel pitch, ~3e-4) -- together
+// ~1.5e-3 px, ~3e-3 px at 4096 wide: a factor 20-40 below the pad.  (It was 1/4 px at first: the boxes of 2-3 pixel
+// triangles then held a third more pixel centres, all of them misses.)
 #pragma once
 #include "drt_common.h"
 #include "drt_tri.h"
@@ -35,7 +38,7 @@ struct ViewModel {
 
 static_assert(sizeof(ViewModel) == 104, "DRT_GRID_CACHE_BYTES of include/drt_hip.h");
 
-constexpr double kRasterPad = 0.25;          // pixels added on every side of a projected triangle's bounding box
+constexpr double kRasterPad = 0.0625;         // pixels added on every side of a projected triangle's bounding box
 constexpr double kRasterVerifyTol = 1e-3;    // a ray belongs to the grid if its direction projects within this of its pixel
 constexpr int kRasterMaxPerLane = 48;        // larger boxes are handed to k_raster_big (one block per triangle)
 
@@ -84,7 +87,7 @@ struct PixelBox {
 };
 
 // Padded pixel bounding box of the triangle record `t` seen from the image's origin, in float32 (|error| ~1e-4 px at these
-// magnitudes; the pad is 0.25 px).  Used by k_raster and by the host-side unit test alike.
+// magnitudes; the pad is 1/16 px).  Used by k_raster and by the host-side unit test alike.
 DRT_HD PixelBox project_tri_box(const ViewModel& vm, f3 o32, const TriRec& t, int w, int h) {
     PixelBox r{0, -1, 0, -1, false};
     const f3 a{t.v0x - o32.x, t.v0y - o32.y, t.v0z - o32.z};

@@ -50,7 +50,7 @@ __device__ __forceinline__ void raster_test(const TriRec& t, f3 o32, const doubl
 struct BigItem { int32_t view, tri, x0, y0, nx, ny; };
 
 // grid (ceil(F / 256), n_views): one thread per (image, triangle in Morton order) projects its triangle (float32 is
-// ample: the box is padded by a quarter of a pixel) and counts the pixel centres inside the padded box -- 0 for most
+// ample: the box is padded by 1/16 pixel) and counts the pixel centres inside the padded box -- 0 for most
 // sub-pixel triangles, a handful typically, dozens for a few.  The (triangle, pixel) tests of a wave are then dealt to its
 // lanes 64 at a time (wave prefix sum of the counts, owner found by bisection in LDS), so that one fat triangle does not
 // hold 63 idle lanes.

@@ -237,8 +237,8 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     # images verified in every ray are recorded as grids -- k_store_models)
     assert prof2["trace1"][2] > prof["trace1"][2] > 0
     o[2 * P + 5] += 1.0                                    # and an origin write
-    prof3, _ = run(None)
-    assert prof3["trace1"][2] >= prof2["trace1"][2]
+    prof3, _ = run(None)                                   # establishes again: per-ray verdicts, one more ray for the tree
+    assert prof2["trace1"][2] > prof3["trace1"][2] >= prof["trace1"][2]
 
 
 def test_sparse_face_ids_leave_results_unchanged(Render):
