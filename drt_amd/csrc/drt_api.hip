@@ -35,7 +35,6 @@ int drt_create(int device, drt_scene_t** out) {
     if (const char* ev = getenv("DRT_ASYNC_BUILD")) s->async_build = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_STREAMS")) { const int v = atoi(ev); if (v >= 1 && v <= drt_scene::kMaxSub) s->n_sub = v; }
     if (const char* ev = getenv("DRT_RASTER")) s->use_raster = atoi(ev) != 0;
-    if (const char* ev = getenv("DRT_RASTER_TILES")) s->raster_tiles = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_FILL_OVERLAP")) s->fill_overlap = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_SUB_PER_STREAM")) { const int v = atoi(ev); if (v >= 1 && v <= 16) s->sub_per_stream = v; }
     if (const char* ev = getenv("DRT_MIN_SUB_LOG2")) { const int v = atoi(ev); if (v >= 12 && v <= 30) s->min_sub_rays = (int64_t)1 << v; }
@@ -88,7 +87,7 @@ void drt_destroy(drt_scene_t* s) {
         drt_scene::Sub& w = s->sub[j];
         for (int k = 0; k < 3; ++k) { (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]); }
         (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2); (void)hipFree(w.qcount); (void)hipFree(w.slow_stack); (void)hipFree(w.redo);
-        (void)hipFree(w.zbuf); (void)hipFree(w.zmask); (void)hipFree(w.vmodel); (void)hipFree(w.big); (void)hipFree(w.big_count); (void)hipFree(w.gen_list); (void)hipFree(w.tile_words); (void)hipFree(w.bin_list);
+        (void)hipFree(w.zbuf); (void)hipFree(w.zmask); (void)hipFree(w.vmodel); (void)hipFree(w.big); (void)hipFree(w.big_count); (void)hipFree(w.gen_list);
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.fill_fork) (void)hipEventDestroy(w.fill_fork);
         if (w.fill_join) (void)hipEventDestroy(w.fill_join);

@@ -120,10 +120,6 @@ struct drt_scene {
         void* big = nullptr;
         unsigned* big_count = nullptr;
         int32_t* gen_list = nullptr;                         // [q_cap] R0 slots whose ray did not verify as a grid ray: traced like before
-        uint32_t* tile_words = nullptr;                      // tiled pass: counters, offsets, kept counts, ids [tile_cap each] + control words
-        int64_t tile_cap = 0;
-        uint32_t* bin_list = nullptr;                        //   triangle ids binned per 64x16 tile [bin_cap]
-        int64_t bin_cap = 0;
     };
     static constexpr unsigned kBigCap = 1u << 20;
     static constexpr int kMaxSub = 4;
@@ -155,7 +151,6 @@ struct drt_scene {
     int64_t chunk_rays = kChunkRays;
 
     bool fill_overlap = true;      // DRT_FILL_OVERLAP=0: the dense-output memsets of a DRT_GRID_TRUST call stay in front of the projection pass
-    bool raster_tiles = false;     // DRT_RASTER_TILES=1: the tiled projection pass (experiment: slower than the untiled one, see drt_raster.hip)
     bool use_raster = true;        // DRT_RASTER=0: every primary ray takes the BVH path (A/B measurement)
     bool built = false;
 };
