@@ -14,8 +14,9 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg ::', d['ms_
   done
 } > $O/configs.txt 2>&1
 {
+  # (DRT_BENCH_NOPROF: no event pairs inside the timed region, as in a run with more than one rank)
   for v in 72 36 18 9; do
-    python bench.py --views $v --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
+    DRT_BENCH_NOPROF=1 python bench.py --views $v --no-cpu-baseline --no-extras --steps 40 --warmup 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
   done
@@ -23,6 +24,8 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager',
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views 9 whole-step hipGraph', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
 } > $O/scaling_proxy.txt 2>&1
+# the launch line of the driver's multi-GPU runs, two ranks on this box's one GPU (gloo instead of RCCL): functional check of bench.py's N > 1 path
+DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
 bash tools/profile.sh $P > $O/profile.log 2>&1
 PROFILE_SKIP_PMC=1 DRT_STREAMS=1 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
