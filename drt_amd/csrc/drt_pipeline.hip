@@ -910,6 +910,11 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     // the scene's build stream is idle once the tree is built (before the cull stage): it carries the late fills, so that the
     // library stays within the four hardware queues a process gets by default (more streams would share queues with these)
     hipStream_t fs = s->prof_serial ? st : s->build_stream;
+    {   // under stream capture (a whole step recorded as a hipGraph) the fills stay on the sub-batch's own stream: re-entering the build
+        // stream after it has joined faults inside the capture of ROCm 7.2, and a replayed graph has no launch gaps to hide anyway
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (fs != st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) fs = st;
+    }
     const int64_t image = (int64_t)tile_w * tile_h;
     if (raster_on(s, n, tile_w, tile_h)) {
         const int n_views = (int)(n / image);
