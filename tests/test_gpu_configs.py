@@ -357,3 +357,31 @@ def test_stage_timer_pool_grows_instead_of_dropping(Render):
     prof = tr.profile_read()
     assert prof["build"][1] == n and prof["build"][0] > 0
     tr.profile_enable(0)
+
+
+def test_profile_select_times_only_the_named_stages(Render):
+    """drt_profile_select: bench.py brackets only the traversal kernels inside its timed region; item counts are kept for every stage."""
+    hand = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(hand, 0)
+    c, ext = views.mesh_frame(hand.vertices)
+    cams = views.turntable_cameras(c, ext, 72, 128, 128)
+    o, d = views.generate_ray(128, 128, cams[9][3], cams[9][2], device="cuda")
+    Render.resx = Render.resy = 128
+    tr = scene.optix_mesh
+    tr.profile_enable(1)
+    try:
+        seen = {}
+        for sel in (("trace2", "trace3"), None):
+            tr.profile_select(sel)
+            tr.profile_read()
+            tr.update_vert_f64(scene.vertices.detach().clone())
+            with torch.no_grad():
+                scene.render_transparent(o, d)
+            seen[sel] = tr.profile_read()
+        lite, full = seen[("trace2", "trace3")], seen[None]
+        assert {k for k, v in lite.items() if v[1] > 0} == {"trace2", "trace3"}
+        assert {"build", "cull", "shade1", "trace2", "shade2", "trace3", "finish", "raster"} <= {k for k, v in full.items() if v[1] > 0}
+        assert lite["trace2"][2] == full["trace2"][2] > 0 and lite["shade1"][2] == full["shade1"][2] > 0
+    finally:
+        tr.profile_select(None)
+        tr.profile_enable(0)
