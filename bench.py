@@ -492,8 +492,16 @@ def main():
             out["route_b"] = route_b
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mesh, center, extent)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    # RCCL writes its version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe: every rank
+    # flushes it now and rank 0 prints after a barrier, so that the JSON line is the LAST line of the job's stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    ddist.barrier()
+    if rank == 0:
+        print(line, flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -18,6 +18,15 @@ import torch
 import torch.distributed as dist
 
 
+# DRT_DIST_FORCE=1: create the process group and issue the collectives even with ONE rank -- the RCCL path of a step
+# (communicator, its streams, the all-reduce launch) exercised on a one-GPU box
+_FORCE = os.environ.get("DRT_DIST_FORCE", "") not in ("", "0")
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
 def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -25,7 +34,7 @@ def env_world():
 def init(backend=None):
     """Initialise the default process group from the torchrun environment (no-op for world 1)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -43,18 +52,18 @@ def shard_views(n_views, rank, world):
 
 def allreduce_sum_(t):
     """In-place sum over ranks; identity for a single process."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def allreduce_max_float(x, device):
     t = torch.tensor([x], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
