@@ -263,8 +263,8 @@ def cpu_baseline(mesh, center, extent):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["dropin", "fused"], default="dropin")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--views", type=int, default=72)
