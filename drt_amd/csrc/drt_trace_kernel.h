@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             ++wave_steps;
             lane_steps += (unsigned long long)__popcll(mi);
             if (at_inner) {
-                const bool done = trav_inner(c.nodes, s, st);
+                const bool done = trav_inner<ANY>(c.nodes, s, st);
                 if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to k_trace_redo
                     redo_list[atomicAdd(redo_count, 1u)] = slot;
                     slot = -1;
