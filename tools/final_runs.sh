@@ -29,4 +29,4 @@ DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --n
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
 bash tools/profile.sh $P > $O/profile.log 2>&1
 PROFILE_SKIP_PMC=1 DRT_STREAMS=1 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
-tail -3 $O/configs.txt $O/scaling_proxy.txt $O/iter_bench.txt; python tools/benchsum.py $O/bench.json | head -3
+tail -n 3 $O/configs.txt $O/scaling_proxy.txt $O/iter_bench.txt; python tools/benchsum.py $O/bench.json | head -3
