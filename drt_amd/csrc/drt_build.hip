@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(1024) k_bounds(const float* __restrict__ verts
         out->iz = ez > 0.f ? 1.0f / ez : 0.f;
         out->pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
         out->reserved = 0;
+        out->plan = morton_plan(ex, ey, ez);
     }
 }
 
@@ -73,7 +74,7 @@ __global__ void k_morton(const int32_t* __restrict__ faces, const float* __restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const f3 a = ld_vert(verts, faces[3 * i]), b = ld_vert(verts, faces[3 * i + 1]), c = ld_vert(verts, faces[3 * i + 2]);
-    const uint32_t key = morton30(a, b, c, f3{bp->lox, bp->loy, bp->loz}, f3{bp->ix, bp->iy, bp->iz});
+    const uint32_t key = morton_key(a, b, c, f3{bp->lox, bp->loy, bp->loz}, f3{bp->ix, bp->iy, bp->iz}, bp->plan);
     keys[i] = key;
     idx[i] = (uint32_t)i;
     if (hist0) atomicAdd(&hist0[(key & (kRadix - 1)) * tiles + i / kSortTile], 1u);   // first pass of the fused sort

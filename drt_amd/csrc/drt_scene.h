@@ -66,6 +66,7 @@ struct BuildParams {   // written by k_bounds, read by the later build kernels
     float ix, iy, iz;   // 1 / extent per axis (0 extent -> 0)
     float pad;
     int32_t reserved;
+    MortonPlan plan;    // axis of every key bit (drt_lbvh.h)
 };
 
 struct drt_scene {

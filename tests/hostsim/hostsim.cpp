@@ -46,8 +46,9 @@ static void build(HsScene& s) {
     const f3 inv{ex > 0 ? 1.0f / ex : 0.f, ey > 0 ? 1.0f / ey : 0.f, ez > 0 ? 1.0f / ez : 0.f};
     s.pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
     std::vector<uint32_t> key(n);
+    const MortonPlan plan = morton_plan(ex, ey, ez);
     for (int i = 0; i < n; ++i)
-        key[i] = morton30(vert(s, s.faces[3 * i]), vert(s, s.faces[3 * i + 1]), vert(s, s.faces[3 * i + 2]), f3{lo[0], lo[1], lo[2]}, inv);
+        key[i] = morton_key(vert(s, s.faces[3 * i]), vert(s, s.faces[3 * i + 1]), vert(s, s.faces[3 * i + 2]), f3{lo[0], lo[1], lo[2]}, inv, plan);
     s.idx.resize(n);
     std::iota(s.idx.begin(), s.idx.end(), 0u);
     std::stable_sort(s.idx.begin(), s.idx.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });

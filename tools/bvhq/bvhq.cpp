@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -45,7 +46,10 @@ double bvhq_visits(const int32_t* faces, int64_t n_faces, const float* verts, in
     if (!child0) {
         const f3 inv{1.0f / ex, 1.0f / ey, 1.0f / ez};
         std::vector<uint32_t> key(n), idx(n), keys(n);
-        for (int i = 0; i < n; ++i) key[i] = morton30(V(faces[3 * i]), V(faces[3 * i + 1]), V(faces[3 * i + 2]), f3{lo[0], lo[1], lo[2]}, inv);
+        const MortonPlan plan = morton_plan(ex, ey, ez);
+        for (int i = 0; i < n; ++i)
+            key[i] = getenv("BVHQ_PLAIN_MORTON") ? morton30(V(faces[3 * i]), V(faces[3 * i + 1]), V(faces[3 * i + 2]), f3{lo[0], lo[1], lo[2]}, inv)
+                                                 : morton_key(V(faces[3 * i]), V(faces[3 * i + 1]), V(faces[3 * i + 2]), f3{lo[0], lo[1], lo[2]}, inv, plan);
         std::iota(idx.begin(), idx.end(), 0u);
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         for (int k = 0; k < n; ++k) { keys[k] = key[idx[k]]; order[k] = (int32_t)idx[k]; }
