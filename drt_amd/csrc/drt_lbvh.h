@@ -113,12 +113,14 @@ DRT_HD MortonPlan morton_plan(float ex, float ey, float ez) {
     for (int k = 0; k < 30; ++k) { const int a = p.axis[k]; p.pos[k] = (uint8_t)(p.bits[a] - 1 - used[a]); ++used[a]; }
     return p;
 }
-// Key of the triangle centroid inside the scene box [lo, lo + 1/inv_ext] under `plan`.
+// Key of the centre of the triangle's BOUNDING BOX inside the scene box [lo, lo + 1/inv_ext] under `plan`.  (Not the vertex
+// centroid: the two triangles of a quad -- the meshes here come from marching-cubes-like extractions and midpoint subdivision --
+// have different centroids but the same box centre, get the same key and end up in the same <= 4-triangle leaf.  Measured with
+// tools/bvhq on hand / mouse x4 / horse x4 / monkey: 5-8 % fewer node visits on top of the axis order's 1-10 %.)
 DRT_HD uint32_t morton_key(f3 a, f3 b, f3 c, f3 lo, f3 inv_ext, const MortonPlan& plan) {
-    const float third = 1.0f / 3.0f;
-    const float x = (((a.x + b.x) + c.x) * third - lo.x) * inv_ext.x;
-    const float y = (((a.y + b.y) + c.y) * third - lo.y) * inv_ext.y;
-    const float z = (((a.z + b.z) + c.z) * third - lo.z) * inv_ext.z;
+    const float x = (0.5f * (fminf(a.x, fminf(b.x, c.x)) + fmaxf(a.x, fmaxf(b.x, c.x))) - lo.x) * inv_ext.x;
+    const float y = (0.5f * (fminf(a.y, fminf(b.y, c.y)) + fmaxf(a.y, fmaxf(b.y, c.y))) - lo.y) * inv_ext.y;
+    const float z = (0.5f * (fminf(a.z, fminf(b.z, c.z)) + fmaxf(a.z, fmaxf(b.z, c.z))) - lo.z) * inv_ext.z;
     const float sx = (float)(1u << plan.bits[0]), sy = (float)(1u << plan.bits[1]), sz = (float)(1u << plan.bits[2]);
     const uint32_t qx = (uint32_t)fminf(fmaxf(x * sx, 0.0f), sx - 1.0f);
     const uint32_t qy = (uint32_t)fminf(fmaxf(y * sy, 0.0f), sy - 1.0f);
