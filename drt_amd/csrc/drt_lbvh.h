@@ -183,8 +183,10 @@ DRT_HD void lbvh_children(const uint32_t* keys, int n, int i, int32_t& left, int
 // Fewer, fatter steps: traversal on MI355X is bound by the latency of the dependent node
 // fetches, not by ALU or bytes.  One node = 128 bytes = one L2 line, SoA so that each 16-byte
 // load brings one bound of all four children.
+// Leaf size: <= 2 triangles.  With keys taken at the box centre a leaf of two is typically the two halves of one quad (same key);
+// measured per step on MI355X (horse x4): 8 -> 3.08 ms, 4 -> 2.96, 2 -> 2.91, 1 -> 2.92 (with the round-1 centroid keys 4 was best).
 #ifndef DRT_LEAF_BITS
-#define DRT_LEAF_BITS 2
+#define DRT_LEAF_BITS 1
 #endif
 constexpr int kLeafBits = DRT_LEAF_BITS, kLeafMax = 1 << kLeafBits;
 
