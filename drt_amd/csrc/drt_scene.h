@@ -147,8 +147,8 @@ struct drt_scene {
     int grid_trace = 2048;         // resident blocks of the pure-traversal kernels
     int grid_path = 2048;          // resident 256-thread blocks of k_trace
     int64_t trace_stats[12] = {0};  // per k_trace stage: wave-steps, lane-steps, refills, max wave-steps (last profile read)
-    int refill_min = 16;           // k_trace refills a wave once this many lanes are idle
-    int inner_min = 16;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
+    int refill_min = 32;           // k_trace refills a wave once this many lanes are idle
+    int inner_min = 24;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
     int64_t chunk_rays = kChunkRays;
 
     bool fill_overlap = true;      // DRT_FILL_OVERLAP=0: the dense-output memsets of a DRT_GRID_TRUST call stay in front of the projection pass
