@@ -84,6 +84,9 @@ def hostsim():
     hs.hs_edge_sample_backward.argtypes = [_P, _P, _I64, _P, _P, _P, ctypes.c_int, _P]
     hs.hs_fit_view.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, _P]
     hs.hs_verify_rays.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P]
+    hs.hs_morton_plan.argtypes = [_P, _P, _P, _P]
+    hs.hs_morton_key.restype = ctypes.c_uint32
+    hs.hs_morton_key.argtypes = [_P, _P]
     hs.hs_raster.restype = _I64
     hs.hs_raster.argtypes = [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
     return hs

@@ -426,4 +426,18 @@ int64_t hs_raster(void* hnd, const double* model14, const double* origin, const 
     return tests;
 }
 
+// drt_lbvh.h::morton_plan / morton_key: axis[30], pos[30], bits[3] of the plan for a scene box of the given extents, and the key of a
+// degenerate "triangle" at point p inside the box [0, ext].
+void hs_morton_plan(const float* ext3, uint8_t* axis30, uint8_t* pos30, uint8_t* bits3) {
+    const MortonPlan p = morton_plan(ext3[0], ext3[1], ext3[2]);
+    for (int k = 0; k < 30; ++k) { axis30[k] = p.axis[k]; pos30[k] = p.pos[k]; }
+    for (int a = 0; a < 3; ++a) bits3[a] = p.bits[a];
+}
+uint32_t hs_morton_key(const float* ext3, const float* p3) {
+    const MortonPlan p = morton_plan(ext3[0], ext3[1], ext3[2]);
+    const f3 v{p3[0], p3[1], p3[2]};
+    const f3 inv{ext3[0] > 0 ? 1.0f / ext3[0] : 0.f, ext3[1] > 0 ? 1.0f / ext3[1] : 0.f, ext3[2] > 0 ? 1.0f / ext3[2] : 0.f};
+    return morton_key(v, v, v, f3{0.f, 0.f, 0.f}, inv, p);
+}
+
 }  // extern "C"

@@ -369,3 +369,30 @@ def test_projected_primary_visibility_math(hostsim, hand):
     assert hostsim.hs_fit_view(on.ctypes.data, dn.ctypes.data, 64, 64, model.ctypes.data) == 1
     T = np.zeros(64 * 64, np.float32); ID = np.zeros(64 * 64, np.int32)
     assert hostsim.hs_raster(s.h, model.ctypes.data, on.ctypes.data, dn.ctypes.data, 64, 64, T.ctypes.data, ID.ctypes.data) == -1
+
+
+def test_morton_plan_splits_the_longest_cell_axis_first(hostsim):
+    """drt_lbvh.h::morton_plan: every key bit halves the axis along which the cells are longest (ties: x, y, z), 30 bits in all,
+    at most 20 per axis; keys order points first by the most significant split."""
+    def plan(ext):
+        e = np.asarray(ext, np.float32); ax = np.zeros(30, np.uint8); pos = np.zeros(30, np.uint8); bits = np.zeros(3, np.uint8)
+        hostsim.hs_morton_plan(e.ctypes.data, ax.ctypes.data, pos.ctypes.data, bits.ctypes.data)
+        return ax, pos, bits
+    ax, pos, bits = plan([159.4, 211.8, 67.9])                     # horse_vh.ply x4
+    assert list(bits) == [10, 11, 9] and list(ax[:5]) == [1, 0, 1, 0, 2]
+    cell = np.array([159.4, 211.8, 67.9])
+    for k in range(30):                                            # the rule itself
+        assert ax[k] == int(np.argmax(cell)); cell[ax[k]] /= 2
+    for a in range(3):                                             # bit positions of an axis run from its top bit down to 0
+        assert list(pos[ax == a]) == list(range(bits[a] - 1, -1, -1))
+    ax, _, bits = plan([1.0, 1.0, 1.0])
+    assert list(bits) == [10, 10, 10] and list(ax[:6]) == [0, 1, 2, 0, 1, 2]      # a cube: the plain interleave
+    _, _, bits = plan([1000.0, 1.0, 0.0])
+    assert list(bits) == [20, 10, 0]                               # needle / flat boxes: capped, a zero extent gets no bit
+    _, _, bits = plan([0.0, 0.0, 0.0])
+    assert bits.sum() == 30 and bits.max() <= 20
+    ext = np.array([4.0, 2.0, 1.0], np.float32)
+    key = lambda p: hostsim.hs_morton_key(ext.ctypes.data, np.asarray(p, np.float32).ctypes.data)
+    assert key([0.1, 1.9, 0.9]) < key([2.1, 0.1, 0.1])             # the first bit splits x (the longest side) ...
+    assert key([0.1, 0.1, 0.9]) < key([0.1, 1.1, 0.1]) < key([1.1, 0.1, 0.1])     # ... the second x again (cells 2 x 2 x 1), then y
+    assert key([3.999, 1.999, 0.999]) == (1 << 30) - 1 and key([0.0, 0.0, 0.0]) == 0
