@@ -72,22 +72,33 @@ __global__ void __launch_bounds__(256) k_silhouette_flags(const double* __restri
 // endpoints, probe one pixel either side of the edge midpoint with any-hit rays, f = hit+ - hit-.
 __global__ void __launch_bounds__(kTraceBlock) k_edge_sample_fwd(TraceCtx c, const double* __restrict__ verts, const int64_t* __restrict__ edges,
                                                                   int64_t n, const Camera* __restrict__ cam, const double* __restrict__ origin3,
-                                                                  int64_t* __restrict__ index, float* __restrict__ f_out) {
+                                                                  int64_t* __restrict__ index, float* __restrict__ f_out,
+                                                                  uint8_t* __restrict__ keep, int resx, int resy) {
     __shared__ int32_t lds[kStackFast][kTraceBlock];
     Stack st = make_stack(lds, c);
     const Camera cm = *cam;
     const d3 o{origin3[0], origin3[1], origin3[2]};
-    for (int64_t e = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kTraceBlock) {
+    // two lanes per edge, one probe ray each (see k_vh_fused: a launch over a few thousand edges lasts as long as its longest lane)
+    constexpr int64_t kPairs = kTraceBlock / 2;
+    const int side = threadIdx.x & 1;
+    for (int64_t base = blockIdx.x * kPairs; base < n; base += (int64_t)gridDim.x * kPairs) {     // block-uniform trip count (shuffle below)
+        const int64_t e = base + (threadIdx.x >> 1);
+        const bool live = e < n;
+        const int64_t el = live ? e : 0;
         Projected pa, pb;
-        project_endpoint(cm, load_d3(verts, edges[2 * e]), pa);
-        project_endpoint(cm, load_d3(verts, edges[2 * e + 1]), pb);
+        project_endpoint(cm, load_d3(verts, edges[2 * el]), pa);
+        project_endpoint(cm, load_d3(verts, edges[2 * el + 1]), pb);
         EdgeSample s;
         edge_sample(cm, pa, pb, o, s);
-        const bool hu = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_up), st).face >= 0;
-        const bool hl = traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(s.dir_lo), st).face >= 0;
-        f_out[e] = (hu ? 1.0f : 0.0f) - (hl ? 1.0f : 0.0f);
-        index[2 * e] = (int64_t)s.midx;       // truncation toward zero, like Tensor.to(torch.long)
-        index[2 * e + 1] = (int64_t)s.midy;
+        const int mine = live && traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(side == 0 ? s.dir_up : s.dir_lo), st).face >= 0 ? 1 : 0;
+        const int other = __shfl_xor(mine, 1);
+        if (!live || side != 0) continue;
+        f_out[e] = (float)mine - (float)other;        // hit(up) - hit(lo)
+        const int64_t x = (int64_t)s.midx, y = (int64_t)s.midy;       // truncation toward zero, like Tensor.to(torch.long)
+        index[2 * e] = x;
+        index[2 * e + 1] = y;
+        // |f| > 1e-5 (DiffRender.py:244) and inside the view (DiffRender.py:478): what the caller keeps
+        if (keep) keep[e] = (mine != other && x < resx - 1 && y < resy - 1 && x >= 0 && y >= 0) ? 1 : 0;
     }
 }
 
@@ -255,14 +266,14 @@ int drt_silhouette_flags(const double* d_verts, const int64_t* d_e2f, int64_t n_
 }
 
 int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera,
-                            const double* d_origin3, int64_t* d_index, float* d_f, void* stream) {
+                            const double* d_origin3, int64_t* d_index, float* d_f, uint8_t* d_keep, int resx, int resy, void* stream) {
     CHECK_BUILT(s);
     if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
     if (n_edges == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_camera || !d_origin3 || !d_index || !d_f) return fail(DRT_E_INVALID, "null pointer argument");
     { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
-    k_edge_sample_fwd<<<grid_for(n_edges, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(
-        trace_ctx(s), d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_origin3, d_index, d_f);
+    k_edge_sample_fwd<<<grid_for(2 * n_edges, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(
+        trace_ctx(s), d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_origin3, d_index, d_f, d_keep, resx, resy);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

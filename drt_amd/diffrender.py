@@ -534,23 +534,24 @@ class _EdgeSample(torch.autograd.Function):
         n = edges.shape[0]
         index = torch.empty((n, 2), dtype=torch.long, device=v.device)
         f = torch.empty(n, dtype=torch.float32, device=v.device)
+        keep = torch.empty(n, dtype=torch.uint8, device=v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), n, cam.data_ptr(),
-                                                          o.data_ptr(), index.data_ptr(), f.data_ptr(), _stream()))
-        # |f| > 1e-5 (DiffRender.py:244) and inside the view (DiffRender.py:478) in ONE boolean index: one host sync
-        valid_edge = (f.abs() > 1e-5) & (index[:, 0] < res_x - 1) & (index[:, 1] < res_y - 1) & (index[:, 0] >= 0) & (index[:, 1] >= 0)
-        index = index[valid_edge]
-        output = 0.5 * torch.ones(len(index), device=v.device)       # float32, like the reference (DiffRender.py:251)
+                                                          o.data_ptr(), index.data_ptr(), f.data_ptr(), keep.data_ptr(), int(res_x), int(res_y), _stream()))
+        # |f| > 1e-5 (DiffRender.py:244) and inside the view (DiffRender.py:478), decided by the kernel: ONE boolean index, one host sync
+        sel = torch.nonzero(keep).squeeze(1)             # (the host sync; the row numbers also serve the backward, which then needs none)
+        index = index.index_select(0, sel)
+        output = torch.full((sel.shape[0],), 0.5, device=v.device)   # float32, like the reference (DiffRender.py:251)
         ctx.mark_non_differentiable(index)
-        ctx.save_for_backward(v, edges, cam, f, valid_edge)
+        ctx.save_for_backward(v, edges, cam, f, sel)
         ctx.detach_depth = detach_depth
         return index, output
 
     @staticmethod
     def backward(ctx, grad_index, grad_output):
-        v, edges, cam, f, valid_edge = ctx.saved_tensors
+        v, edges, cam, f, sel = ctx.saved_tensors
         coef = torch.zeros(edges.shape[0], dtype=torch.float64, device=v.device)
-        coef[valid_edge] = grad_output.to(torch.float64)
+        coef.index_copy_(0, sel, grad_output.to(torch.float64))
         grad_v = torch.zeros_like(v)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().drt_edge_sample_backward(v.data_ptr(), edges.data_ptr(), edges.shape[0], cam.data_ptr(), f.data_ptr(),
