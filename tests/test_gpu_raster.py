@@ -271,16 +271,18 @@ def test_sparse_face_ids_leave_results_unchanged(Render):
         assert torch.equal(a[5][m], b[5][m]) and torch.equal(a[6][m], b[6][m])
 
 
-def test_many_sub_batches_on_two_streams():
+@pytest.mark.parametrize("extra", [{}, {"DRT_FILL_OVERLAP": "0"}], ids=["late-fills", "front-fills"])
+def test_many_sub_batches_on_two_streams(extra):
     """Force every call to be cut into sub-batches of one or two images dealt to the two internal streams (the benchmark's 72 x 1024^2
     calls are cut like that; the tests' calls are normally one sub-batch): the projection pass, the verdict cache (indexed by global
     image), the key buffers and the lists of each stream must give the same results.  Re-runs this file and the multi-image tests
-    of the other files in a subprocess with the sub-batch knobs set."""
+    of the other files in a subprocess with the sub-batch knobs set -- with the output fills issued beside the traversal (default: every
+    sub-batch's memsets go through the build stream, one after the other) and in front of the projection pass."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, DRT_MIN_SUB_LOG2="16", DRT_CHUNK_LOG2="18", DRT_SUB_PER_STREAM="8")
+    env = dict(os.environ, DRT_MIN_SUB_LOG2="16", DRT_CHUNK_LOG2="18", DRT_SUB_PER_STREAM="8", **extra)
     sel = ("test_grid_rays_are_decided or test_rays_outside_the_grid or test_grid_verdict_is_cached or test_key_buffer_is_clean or "
            "test_properties_at_full_size or test_render_transparent_vs_golden or test_two_optimisation_steps")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_raster.py"), os.path.join(here, "test_gpu_parity.py"),
