@@ -95,8 +95,8 @@ def _grid_cache(origin, ray_dir, n, w, h):
     rec = getattr(ray_dir, "_drt_grid", None)
     key = (n, w, h, origin._version, ray_dir._version, origin.data_ptr(), ray_dir.data_ptr())
     if rec is not None and rec[0] == key and rec[1]() is origin:
-        if rec[3][0] is None:
-            # first call after the establishing one: read the verdicts back once (one host sync per ray tensor, not per step).
+        if rec[3][0] is None and not torch.cuda.is_current_stream_capturing():
+            # first call after the establishing one (not while a graph is being captured: the read-back synchronises): read the verdicts back once (one host sync per ray tensor, not per step).
             # All images verified in all rays -> DRT_GRID_ALL_VERIFIED: the launches that serve other rays are not issued.
             flags = rec[2].view(-1, _GRID_BYTES)[:, 96:104].contiguous().view(torch.int32)
             rec[3][0] = bool((flags != 0).all().item())
