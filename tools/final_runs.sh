@@ -28,5 +28,5 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views 9 whole-st
 DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
 bash tools/profile.sh $P > $O/profile.log 2>&1
-PROFILE_SKIP_PMC=1 DRT_STREAMS=1 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
+PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
 tail -n 3 $O/configs.txt $O/scaling_proxy.txt $O/iter_bench.txt; python tools/benchsum.py $O/bench.json | head -3

@@ -11,7 +11,7 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 W=/tmp/prof_$TAG; rm -rf "$W"; mkdir -p "$W"
 cd "$R"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$W/kt" -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$O/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$W/kt" -o kt -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-extras "$@" > "$O/bench_under_rocprof.log" 2>&1
 find "$W/kt" -name '*kernel_stats.csv' -exec cp {} "$O/kernel_stats.csv" \;
 python - "$W/kt" "$O" <<'PY'
 import csv, glob, sys, collections
