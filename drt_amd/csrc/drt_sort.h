@@ -29,7 +29,7 @@ static __global__ void __launch_bounds__(1024) k_sort_scan(uint32_t* __restrict_
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        uint32_t v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
         __syncthreads();
         part[threadIdx.x] += v;
         __syncthreads();

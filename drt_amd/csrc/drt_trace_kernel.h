@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
     unsigned long long wave_steps = 0, lane_steps = 0, refills = 0;   // wave-uniform diagnostics (scalar registers)
     for (;;) {
         const unsigned long long idle = __ballot(slot < 0);
-        if (idle != 0 && taken < my_rays && (__popcll(idle) >= refill_min || idle == ~0ull)) {
+        if (idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull)) {
             if (slot < 0) {
                 const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
                 const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             const bool at_inner = slot >= 0 && s.cur >= 0;
             const unsigned long long mi = __ballot(at_inner);
             if (mi == 0) break;
-            if (__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
+            if ((int)__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
             ++wave_steps;
             lane_steps += (unsigned long long)__popcll(mi);
             if (at_inner) {
