@@ -225,18 +225,22 @@ DRT_HD Box node4_box(const Node4& o, int k) { return Box{o.lox[k], o.loy[k], o.l
 // load of a wave touches 64 different lines), not by ALU: child bounds are therefore quantised to
 // 8 bits on the grid (origin, scale) of the node's own box, rounded OUTWARDS, and decoded with spare
 // ALU (lo = origin + q * scale).  Boxes only steer the traversal; results are defined by drt_tri.h.
+// The three scales are stored multiplied by 2^24 (kQScaleUp): the traversal feeds the bound bytes to v_fma_mix_f32 as float16
+// subnormals (byte * 2^-24, exact), one instruction per plane instead of a convert and an fma, and the factor cancels exactly.
 struct alignas(16) Node4Q {
-    float ox, oy, oz, sx;                     // chunk 0: grid origin, x scale
-    float sy, sz;                             // chunk 1: y, z scale,
+    float ox, oy, oz, sx;                     // chunk 0: grid origin, x scale * 2^24
+    float sy, sz;                             // chunk 1: y, z scale * 2^24,
     uint32_t qlox, qloy;                      //          byte k of each q word = child k
     uint32_t qloz, qhix, qhiy, qhiz;          // chunk 2
     int32_t child[4];                         // chunk 3: as Node4
 };
 
+constexpr float kQScaleUp = 16777216.0f, kQScaleDown = 1.0f / 16777216.0f;   // 2^24, 2^-24
 DRT_HD float q_byte(uint32_t word, int k) { return (float)((word >> (8 * k)) & 255u); }
 DRT_HD Box node4q_box(const Node4Q& n, int k) {
-    return Box{fmaf(q_byte(n.qlox, k), n.sx, n.ox), fmaf(q_byte(n.qloy, k), n.sy, n.oy), fmaf(q_byte(n.qloz, k), n.sz, n.oz),
-               fmaf(q_byte(n.qhix, k), n.sx, n.ox), fmaf(q_byte(n.qhiy, k), n.sy, n.oy), fmaf(q_byte(n.qhiz, k), n.sz, n.oz)};
+    const float sx = n.sx * kQScaleDown, sy = n.sy * kQScaleDown, sz = n.sz * kQScaleDown;   // exact
+    return Box{fmaf(q_byte(n.qlox, k), sx, n.ox), fmaf(q_byte(n.qloy, k), sy, n.oy), fmaf(q_byte(n.qloz, k), sz, n.oz),
+               fmaf(q_byte(n.qhix, k), sx, n.ox), fmaf(q_byte(n.qhiy, k), sy, n.oy), fmaf(q_byte(n.qhiz, k), sz, n.oz)};
 }
 
 // One axis: grid (origin strictly below every child's lo, 253 steps up to the largest hi) and the
@@ -272,6 +276,7 @@ DRT_HD Node4Q node4_quantize(const Node4& f) {
     quantize_axis(f.lox, f.hix, valid, q.ox, q.sx, q.qlox, q.qhix);
     quantize_axis(f.loy, f.hiy, valid, q.oy, q.sy, q.qloy, q.qhiy);
     quantize_axis(f.loz, f.hiz, valid, q.oz, q.sz, q.qloz, q.qhiz);
+    q.sx *= kQScaleUp; q.sy *= kQScaleUp; q.sz *= kQScaleUp;
     return q;
 }
 

@@ -44,6 +44,7 @@ struct Stack {
         if (sp < depth_fast) fast[sp * stride] = v; else if (pred) slow[sp - depth_fast] = v;
         sp += pred ? 1 : 0;
     }
+    DRT_HD void after_pushes() {}
     DRT_HD int32_t pop() {
         --sp;
         return sp < depth_fast ? fast[sp * stride] : slow[sp - depth_fast];
@@ -53,24 +54,25 @@ struct Stack {
 constexpr int kStackSlow = 192;
 
 // Stack of the persistent GPU traversal: fast memory only, no overflow area and therefore no
-// divergent slow path (and no flat loads) in the hot loop.  A push beyond `depth` sets `overflow`;
-// the kernel then abandons that ray and a second pass re-traces it with the spilling Stack above.
+// divergent slow path (and no flat loads) in the hot loop.  A node visit pushes at most three entries, so
+// three spare entries above `depth` take the stores of a visit that starts with a legal stack (sp <= depth)
+// without a bound check per push (two VALU instructions per push: address, predicated increment); ONE check
+// per visit (`after_pushes`) sets `overflow`, the kernel then abandons that ray and a second pass re-traces
+// it with the spilling Stack above.
 struct FastStack {
-    int32_t* fast;      // &fast_mem[lane], entry k at fast[k * stride]; depth + 1 entries allocated
+    int32_t* fast;      // &fast_mem[lane], entry k at fast[k * stride]; depth + 3 entries allocated
     int stride;
-    int depth;          // usable entries [0, depth); entry `depth` is a dump slot for stores beyond the top
+    int depth;          // usable entries [0, depth); entries depth .. depth + 2 only ever hold the pushes of an overflowing visit
     int sp;
     bool overflow;
     DRT_HD void push_if(int32_t v, bool pred) {
-        const int k = sp < depth ? sp : depth;          // a store at a full stack must not clobber a live entry
-        fast[k * stride] = v;
-        overflow |= pred & (sp >= depth);
+        fast[sp * stride] = v;
         sp += pred ? 1 : 0;
     }
+    DRT_HD void after_pushes() { overflow |= sp > depth; }
     DRT_HD int32_t pop() {
         --sp;
-        const int k = sp < depth ? sp : depth;
-        return fast[k * stride];
+        return fast[sp * stride];
     }
     DRT_HD bool empty() const { return sp == 0; }
 };
@@ -139,9 +141,23 @@ DRT_HD bool trav_pop(TravState& s, STACK& st) {
 
 // Slab tests of the four children of a quantised node given its three bound chunks: entry distances
 // t[k] (>= 0) and hit flags against [0, best_t].  The decode lo = origin + q * scale is folded into the
-// slab: t = q * (scale * inv) + (origin * inv - o * inv).
+// slab: t = q * (scale * inv) + (origin * inv - o * inv).  On the device a bound byte reaches the fma as a float16
+// SUBNORMAL (two bytes of a bound word spread into the halves of a register by one v_perm_b32: byte * 2^-24 exactly) and
+// v_fma_mix_f32 multiplies it by the node's stored scale * 2^24 times inv: the same product, sum and single rounding as
+// the host form fmaf((float)byte, scale * inv, b) -- 12 permutes + 24 mixed fmas per node instead of 24 converts + 24 fmas.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+struct QPair { half2_t lo, hi; };            // children 0, 1 and 2, 3 of one bound word as float16 subnormals
+__device__ __forceinline__ QPair q_spread(uint32_t word) {
+    QPair r;
+    r.lo = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0u, word, 0x0c010c00u));
+    r.hi = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0u, word, 0x0c030c02u));
+    return r;
+}
+__device__ __forceinline__ float q_half(const QPair& p, int k) { return (float)(k == 0 ? p.lo.x : k == 1 ? p.lo.y : k == 2 ? p.hi.x : p.hi.y); }
+#endif
 DRT_HD void slab_node4q(F4 c0, F4 c1, F4 c2, f3 inv, f3 oi, float best_t, float (&t)[4], bool (&h)[4]) {
-    const float ax = c0.w * inv.x, ay = c1.x * inv.y, az = c1.y * inv.z;
+    const float ax = c0.w * inv.x, ay = c1.x * inv.y, az = c1.y * inv.z;      // scale * 2^24 * inv
     const float bx = fmaf(c0.x, inv.x, oi.x), by = fmaf(c0.y, inv.y, oi.y), bz = fmaf(c0.z, inv.z, oi.z);
     const uint32_t qlox = f32_bits(c1.z), qloy = f32_bits(c1.w), qloz = f32_bits(c2.x);
     const uint32_t qhix = f32_bits(c2.y), qhiy = f32_bits(c2.z), qhiz = f32_bits(c2.w);
@@ -151,14 +167,23 @@ DRT_HD void slab_node4q(F4 c0, F4 c1, F4 c2, f3 inv, f3 oi, float best_t, float 
     const uint32_t ny = ay >= 0.0f ? qloy : qhiy, fy = ay >= 0.0f ? qhiy : qloy;
     const uint32_t nz = az >= 0.0f ? qloz : qhiz, fz = az >= 0.0f ? qhiz : qloz;
 #if defined(__HIP_DEVICE_COMPILE__)
+    const QPair pnx = q_spread(nx), pny = q_spread(ny), pnz = q_spread(nz), pfx = q_spread(fx), pfy = q_spread(fy), pfz = q_spread(fz);
 #pragma unroll
-#endif
     for (int k = 0; k < 4; ++k) {
-        const float tn = fmaxf(fmaxf(fmaf(q_byte(nx, k), ax, bx), fmaf(q_byte(ny, k), ay, by)), fmaxf(fmaf(q_byte(nz, k), az, bz), 0.0f));
-        const float tf = fminf(fminf(fmaf(q_byte(fx, k), ax, bx), fmaf(q_byte(fy, k), ay, by)), fminf(fmaf(q_byte(fz, k), az, bz), best_t));
+        const float tn = fmaxf(fmaxf(fmaf(q_half(pnx, k), ax, bx), fmaf(q_half(pny, k), ay, by)), fmaxf(fmaf(q_half(pnz, k), az, bz), 0.0f));
+        const float tf = fminf(fminf(fmaf(q_half(pfx, k), ax, bx), fmaf(q_half(pfy, k), ay, by)), fminf(fmaf(q_half(pfz, k), az, bz), best_t));
         t[k] = tn;
         h[k] = tn <= tf;
     }
+#else
+    const float hx = ax * kQScaleDown, hy = ay * kQScaleDown, hz = az * kQScaleDown;     // exact: = scale * inv as the device multiplies it
+    for (int k = 0; k < 4; ++k) {
+        const float tn = fmaxf(fmaxf(fmaf(q_byte(nx, k), hx, bx), fmaf(q_byte(ny, k), hy, by)), fmaxf(fmaf(q_byte(nz, k), hz, bz), 0.0f));
+        const float tf = fminf(fminf(fmaf(q_byte(fx, k), hx, bx), fmaf(q_byte(fy, k), hy, by)), fminf(fmaf(q_byte(fz, k), hz, bz), best_t));
+        t[k] = tn;
+        h[k] = tn <= tf;
+    }
+#endif
 }
 
 // Visit the inner node s.cur (>= 0).  Returns true when the ray is finished.  ANY: an occlusion query visits the same set
@@ -167,9 +192,10 @@ DRT_HD void slab_node4q(F4 c0, F4 c1, F4 c2, f3 inv, f3 oi, float best_t, float 
 template <bool ANY = false, class STACK>
 DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st) {
     const F4* np = reinterpret_cast<const F4*>(nodes + s.cur);
-    const F4 q0 = np[0], q1 = np[1], q2 = np[2], chf = np[3];
-    int32_t c0, c1, c2, c3;
-    memcpy(&c0, &chf.x, 4); memcpy(&c1, &chf.y, 4); memcpy(&c2, &chf.z, 4); memcpy(&c3, &chf.w, 4);
+    const F4 q0 = np[0], q1 = np[1], q2 = np[2];
+    struct alignas(16) I4 { int32_t x, y, z, w; };
+    const I4 ch = *reinterpret_cast<const I4*>(nodes[s.cur].child);        // one 16-byte load of the child references
+    const int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
     float t[4];
     bool h[4];
     slab_node4q(q0, q1, q2, s.inv, s.oi, s.best_t, t, h);
@@ -189,6 +215,7 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
         st.push_if(c1, h1 & e1);
         st.push_if(c2, h2 & e2);
         st.push_if(c3, h3 & e3);
+        st.after_pushes();
         s.cur = h0 ? c0 : (h1 ? c1 : (h2 ? c2 : c3));
         return false;
     }
@@ -206,6 +233,7 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
         st.push_if(pick4(k3, c0, c1, c2, c3), k3 < kMiss);
         st.push_if(pick4(k2, c0, c1, c2, c3), k2 < kMiss);
         st.push_if(pick4(k1, c0, c1, c2, c3), k1 < kMiss);
+        st.after_pushes();
         s.cur = pick4(k0, c0, c1, c2, c3);
         return false;
     }
