@@ -195,7 +195,7 @@ struct alignas(16) Node4 {
     int32_t child[4];   // >= 0: Node4 index; < 0: leaf, ~child = (first_slot << kLeafBits) | (count - 1); kEmptyChild: none
     int32_t pad[4];
 };
-constexpr int32_t kEmptyChild = INT32_MIN;   // an inverted box still passes a slab test (inf - inf), so empties are flagged
+constexpr int32_t kEmptyChild = INT32_MIN;   // flagged in the child reference (an inverted float box still passes a slab test: inf - inf); the QUANTISED form of an empty slot is an inverted byte interval (quantize_axis)
 
 DRT_HD int32_t leaf_ref(int first, int count) { return ~((first << kLeafBits) | (count - 1)); }
 
@@ -255,7 +255,7 @@ DRT_HD void quantize_axis(const float lo[4], const float hi[4], const bool valid
     if (!(s > 0.0f)) s = 1e-30f;
     qlo = 0; qhi = 0;
     for (int k = 0; k < 4; ++k) {
-        int a = 0, b = 255;
+        int a = 255, b = 0;      // no child: an INVERTED interval on every axis -- near plane beyond far plane for any direction, so the slab test itself rejects the slot
         if (valid[k]) {
             a = (int)floorf((lo[k] - o) / s);
             a = a < 0 ? 0 : (a > 255 ? 255 : a);

@@ -45,6 +45,7 @@ struct Stack {
         sp += pred ? 1 : 0;
     }
     DRT_HD void after_pushes() {}
+    DRT_HD void reset() { sp = 0; }
     DRT_HD int32_t pop() {
         --sp;
         return sp < depth_fast ? fast[sp * stride] : slow[sp - depth_fast];
@@ -59,22 +60,28 @@ constexpr int kStackSlow = 192;
 // without a bound check per push (two VALU instructions per push: address, predicated increment); ONE check
 // per visit (`after_pushes`) sets `overflow`, the kernel then abandons that ray and a second pass re-traces
 // it with the spilling Stack above.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) int32_t* FastPtr;      // 32-bit LDS address arithmetic
+#else
+typedef int32_t* FastPtr;
+#endif
 struct FastStack {
-    int32_t* fast;      // &fast_mem[lane], entry k at fast[k * stride]; depth + 3 entries allocated
+    FastPtr base;       // &fast_mem[lane]; entry k at base[k * stride]; depth + 3 entries allocated
+    FastPtr top;        // next free entry (the stack pointer IS the address: no shift-and-or per push)
     int stride;
     int depth;          // usable entries [0, depth); entries depth .. depth + 2 only ever hold the pushes of an overflowing visit
-    int sp;
     bool overflow;
+    DRT_HD void reset() { top = base; }
     DRT_HD void push_if(int32_t v, bool pred) {
-        fast[sp * stride] = v;
-        sp += pred ? 1 : 0;
+        *top = v;
+        top += pred ? stride : 0;
     }
-    DRT_HD void after_pushes() { overflow |= sp > depth; }
+    DRT_HD void after_pushes() { overflow |= top > base + depth * stride; }
     DRT_HD int32_t pop() {
-        --sp;
-        return fast[sp * stride];
+        top -= stride;
+        return *top;
     }
-    DRT_HD bool empty() const { return sp == 0; }
+    DRT_HD bool empty() const { return top == base; }
 };
 
 // Reciprocal direction for the slab test only.  A zero (or denormal-small) component would
@@ -128,7 +135,7 @@ DRT_HD void trav_init(TravState& s, STACK& st, f3 o, f3 d) {
     s.cur = 0;
     s.best_t = INFINITY;
     s.best_face = -1;
-    st.sp = 0;
+    st.reset();
 }
 
 // Pop the next node; returns true when the stack is empty (ray finished).
@@ -195,7 +202,7 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
     const F4 q0 = np[0], q1 = np[1], q2 = np[2];
     struct alignas(16) I4 { int32_t x, y, z, w; };
     const I4 ch = *reinterpret_cast<const I4*>(nodes[s.cur].child);        // one 16-byte load of the child references
-    const int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+    int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
     float t[4];
     bool h[4];
     slab_node4q(q0, q1, q2, s.inv, s.oi, s.best_t, t, h);
@@ -208,7 +215,15 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
         for (int k = 0; k < 4; ++k) { h[k] = h[k] & h2[k]; t[k] = fminf(t[k], t2[k]); }
     }
 #endif
-    const bool h0 = h[0] & (c0 != kEmptyChild), h1 = h[1] & (c1 != kEmptyChild), h2 = h[2] & (c2 != kEmptyChild), h3 = h[3] & (c3 != kEmptyChild);
+    // Empty slots need no test here: their quantised interval is inverted on all three axes (quantize_axis), so tn > tf whenever one of
+    // scale * inv is non-zero -- always, short of an underflow on all three axes for directions of absurd length, and then the reference that
+    // gets pushed, kEmptyChild, is a "leaf" that trav_leaf skips.
+    const bool h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the load of the child references beside the three bound loads: left alone the compiler sinks it into the "some child was
+    // hit" branch, where it becomes a second, dependent memory round trip of the visit
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+#endif
     if (ANY) {
         const bool e1 = h0, e2 = h0 | h1, e3 = e2 | h2;          // "an earlier child was hit"
         if (!(e3 | h3)) return trav_pop(s, st);
@@ -227,6 +242,7 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
     uint32_t k1 = (h1 ? (f32_bits(t[1]) & ~3u) : kMiss) | 1u;
     uint32_t k2 = (h2 ? (f32_bits(t[2]) & ~3u) : kMiss) | 2u;
     uint32_t k3 = (h3 ? (f32_bits(t[3]) & ~3u) : kMiss) | 3u;
+#ifdef DRT_FULL_SORT
     cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
     if (k0 < kMiss) {
         // visit the nearest, push the others far-first (dead stores for misses: they sort last)
@@ -237,12 +253,28 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
         s.cur = pick4(k0, c0, c1, c2, c3);
         return false;
     }
+#else
+    // Only the NEAREST child is singled out (keys are distinct: the slot is part of them); the other hit children are pushed
+    // in slot order.
+    const uint32_t ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3, kn = ka < kb ? ka : kb;
+    if (kn < kMiss) {
+        const bool n0 = k0 == kn, n1 = k1 == kn, n2 = k2 == kn;      // one-hot with "slot 3 otherwise"
+        st.push_if(c0, h0 & !n0);
+        st.push_if(c1, h1 & !n1);
+        st.push_if(c2, h2 & !n2);
+        st.push_if(c3, h3 & (k3 != kn));
+        st.after_pushes();
+        s.cur = n0 ? c0 : (n1 ? c1 : (n2 ? c2 : c3));
+        return false;
+    }
+#endif
     return trav_pop(s, st);
 }
 
 // Test the triangles of the leaf s.cur (< 0).  Returns true when the ray is finished.
 template <bool ANY, class STACK>
 DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, STACK& st) {
+    if (s.cur == kEmptyChild) return trav_pop(s, st);      // see trav_inner
     const int32_t ref = ~s.cur;
     const int first = ref >> kLeafBits, count = (ref & (kLeafMax - 1)) + 1;
     for (int j = 0; j < count; ++j) {
