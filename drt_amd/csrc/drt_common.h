@@ -19,6 +19,11 @@
 #define DRT_HD inline
 #define DRT_D inline
 #endif
+#if defined(__clang__)
+#define DRT_UNROLL _Pragma("unroll")
+#else
+#define DRT_UNROLL
+#endif
 
 namespace drt {
 

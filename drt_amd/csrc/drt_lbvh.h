@@ -207,6 +207,7 @@ DRT_HD bool wide_leaf_of(int32_t c, const int32_t* range_lo, const int32_t* rang
 }
 
 DRT_HD void node4_clear(Node4& o) {
+    DRT_UNROLL
     for (int k = 0; k < 4; ++k) {
         o.lox[k] = o.loy[k] = o.loz[k] = INFINITY;
         o.hix[k] = o.hiy[k] = o.hiz[k] = -INFINITY;
@@ -247,6 +248,7 @@ DRT_HD Box node4q_box(const Node4Q& n, int k) {
 // outward-rounded bytes of the four children.
 DRT_HD void quantize_axis(const float lo[4], const float hi[4], const bool valid[4], float& o, float& s, uint32_t& qlo, uint32_t& qhi) {
     float mn = INFINITY, mx = -INFINITY;
+    DRT_UNROLL
     for (int k = 0; k < 4; ++k)
         if (valid[k]) { mn = fminf(mn, lo[k]); mx = fmaxf(mx, hi[k]); }
     if (!(mn <= mx)) { mn = 0.0f; mx = 0.0f; }
@@ -254,6 +256,7 @@ DRT_HD void quantize_axis(const float lo[4], const float hi[4], const bool valid
     s = ((mx - o) / 253.0f) * 1.00000095367431640625f;
     if (!(s > 0.0f)) s = 1e-30f;
     qlo = 0; qhi = 0;
+    DRT_UNROLL
     for (int k = 0; k < 4; ++k) {
         int a = 255, b = 0;      // no child: an INVERTED interval on every axis -- near plane beyond far plane for any direction, so the slab test itself rejects the slot
         if (valid[k]) {
@@ -272,6 +275,7 @@ DRT_HD void quantize_axis(const float lo[4], const float hi[4], const bool valid
 DRT_HD Node4Q node4_quantize(const Node4& f) {
     Node4Q q;
     bool valid[4];
+    DRT_UNROLL
     for (int k = 0; k < 4; ++k) { valid[k] = f.child[k] != kEmptyChild; q.child[k] = f.child[k]; }
     quantize_axis(f.lox, f.hix, valid, q.ox, q.sx, q.qlox, q.qhix);
     quantize_axis(f.loy, f.hiy, valid, q.oy, q.sy, q.qloy, q.qhiy);
@@ -293,44 +297,68 @@ DRT_HD float box_area(const Box& b) {
 #ifndef DRT_GREEDY_COLLAPSE
 #define DRT_GREEDY_COLLAPSE 1
 #endif
+// (The four slots are named members, not arrays, and every pick or placement is a compare-and-select chain: with indexed arrays
+// the device kernel kept them in scratch memory.)
+// (value selects, field by field: `cond ? box_x : box_y` on structs selects an ADDRESS and keeps both in memory)
+DRT_HD int32_t sel(bool c, int32_t x, int32_t y) { return c ? x : y; }
+DRT_HD bool sel(bool c, bool x, bool y) { return c ? x : y; }
+DRT_HD Box sel(bool c, const Box& x, const Box& y) {
+    return Box{c ? x.lox : y.lox, c ? x.loy : y.loy, c ? x.loz : y.loz, c ? x.hix : y.hix, c ? x.hiy : y.hiy, c ? x.hiz : y.hiz};
+}
+template <class T>
+struct Slots4 {
+    T a, b, c, d;
+    DRT_HD T get(int i) const { return sel(i == 0, a, sel(i == 1, b, sel(i == 2, c, d))); }
+    DRT_HD void put(int i, const T& v) {
+        a = sel(i == 0, v, a);
+        b = sel(i == 1, v, b);
+        c = sel(i == 2, v, c);
+        d = sel(i == 3, v, d);
+    }
+};
 DRT_HD void collapse4(const Node* bin, const int32_t* range_lo, const int32_t* range_hi, int n_tris, int i, Node4& out) {
     node4_clear(out);
     if (n_tris <= kLeafMax) {   // whole mesh in one leaf under the root
         node4_set(out, 0, box_union(node_child_box(bin[0], 0), node_child_box(bin[0], 1)), leaf_ref(0, n_tris));
         return;
     }
-    int32_t ref[4];     // >= 0: binary node to descend into; < 0: finished leaf reference
-    Box box[4];
-    bool open[4];
-    int k = 0, first, count;
-    for (int s = 0; s < 2; ++s) {
-        const int32_t c = s == 0 ? bin[i].child0 : bin[i].child1;
-        box[k] = node_child_box(bin[i], s);
-        open[k] = !wide_leaf_of(c, range_lo, range_hi, first, count);
-        ref[k] = open[k] ? c : leaf_ref(first, count);
-        ++k;
+    Slots4<int32_t> ref{0, 0, 0, 0};     // >= 0: binary node to descend into; < 0: finished leaf reference
+    Slots4<Box> box{box_empty(), box_empty(), box_empty(), box_empty()};
+    Slots4<bool> open{false, false, false, false};
+    int k = 2, first, count;
+    const Node root = bin[i];
+    {
+        bool op = !wide_leaf_of(root.child0, range_lo, range_hi, first, count);
+        box.a = node_child_box(root, 0); open.a = op; ref.a = op ? root.child0 : leaf_ref(first, count);
+        op = !wide_leaf_of(root.child1, range_lo, range_hi, first, count);
+        box.b = node_child_box(root, 1); open.b = op; ref.b = op ? root.child1 : leaf_ref(first, count);
     }
+    DRT_UNROLL
     for (int round = 0; round < 2; ++round) {
         int pick = -1;
 #if DRT_GREEDY_COLLAPSE
         float best = -1.0f;
-        for (int j = 0; j < k; ++j)
-            if (open[j]) { const float a = box_area(box[j]); if (a > best) { best = a; pick = j; } }
+        DRT_UNROLL
+        for (int j = 0; j < 4; ++j)
+            if (j < k && open.get(j)) { const float a = box_area(box.get(j)); if (a > best) { best = a; pick = j; } }
 #else
-        for (int j = 0; j < 2 && pick < 0; ++j) if (open[j] && ref[j] == (j == 0 ? bin[i].child0 : bin[i].child1)) pick = j;
+        if (open.a && ref.a == root.child0) pick = 0;
+        else if (open.b && ref.b == root.child1) pick = 1;
 #endif
-        if (pick < 0) break;
-        const int32_t c = ref[pick];
-        // the opened child's two children take its slot and the next free one
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int32_t g = s2 == 0 ? bin[c].child0 : bin[c].child1;
-            const int slot = s2 == 0 ? pick : k++;
-            box[slot] = node_child_box(bin[c], s2);
-            open[slot] = !wide_leaf_of(g, range_lo, range_hi, first, count);
-            ref[slot] = open[slot] ? g : leaf_ref(first, count);
+        if (pick >= 0) {
+            const Node opened = bin[ref.get(pick)];
+            // the opened child's two children take its slot and the next free one
+            bool op = !wide_leaf_of(opened.child0, range_lo, range_hi, first, count);
+            box.put(pick, node_child_box(opened, 0)); open.put(pick, op); ref.put(pick, op ? opened.child0 : leaf_ref(first, count));
+            op = !wide_leaf_of(opened.child1, range_lo, range_hi, first, count);
+            box.put(k, node_child_box(opened, 1)); open.put(k, op); ref.put(k, op ? opened.child1 : leaf_ref(first, count));
+            ++k;
         }
     }
-    for (int j = 0; j < k; ++j) node4_set(out, j, box[j], ref[j]);
+    node4_set(out, 0, box.a, ref.a);
+    node4_set(out, 1, box.b, ref.b);
+    if (k > 2) node4_set(out, 2, box.c, ref.c);
+    if (k > 3) node4_set(out, 3, box.d, ref.d);
 }
 
 }  // namespace drt
