@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned hit_mask4(const Node4Q* __restrict__ node, f
     const int32_t* ch = node->child;
     float t[4];
     bool h[4];
-    slab_node4q(np[0], np[1], np[2], inv, oi, INFINITY, t, h);
+    slab_node4q(np[0], np[1], np[2], inv, oi, inv.x >= 0.0f, inv.y >= 0.0f, inv.z >= 0.0f, INFINITY, t, h);
     return (unsigned)(h[0] & (ch[0] != kEmptyChild)) | ((unsigned)(h[1] & (ch[1] != kEmptyChild)) << 1) |
            ((unsigned)(h[2] & (ch[2] != kEmptyChild)) << 2) | ((unsigned)(h[3] & (ch[3] != kEmptyChild)) << 3);
 }
