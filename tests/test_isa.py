@@ -63,3 +63,25 @@ def test_traversal_kernels_fit_eight_waves_per_simd():
     for name, scratch, vgprs in meta:
         assert int(vgprs) <= 64, (name, vgprs)
         assert int(scratch) == 0, (name, scratch)
+
+
+def test_inner_visit_reads_bounds_as_float16_subnormals_and_issues_four_loads():
+    """The slab test of k_trace feeds the quantised bounds to v_fma_mix_f32 as float16 SUBNORMALS (byte * 2^-24): that is only
+    the fma of drt_traverse.h's host form if the kernel runs with float16 denormals enabled (descriptor mode 3), and it is only
+    worth it while no byte->float converts are left.  The child references must be loaded beside the three bound chunks (four
+    16-byte loads of one node in a row), not inside the "a child was hit" branch as a second, dependent round trip."""
+    out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + build.FLAGS + ["-S", "--cuda-device-only", "-o", "-",
+                         os.path.join(build.CSRC, "drt_pipeline.hip")], check=True, capture_output=True, text=True).stdout
+    kernels = re.findall(r"^(_Z7k_trace\w+):.*?\n(.*?)s_endpgm", out, re.S | re.M)
+    assert len(kernels) >= 2
+    for name, text in kernels:
+        body = [ln.split(";")[0].strip() for ln in text.splitlines() if ln.strip() and not ln.strip().startswith((";", "."))]
+        assert sum(ln.startswith("v_fma_mix_f32") for ln in body) >= 24, name
+        assert sum(ln.startswith("v_perm_b32") for ln in body) >= 12, name
+        assert not any(ln.startswith("v_cvt_f32_ubyte") for ln in body), name
+        loads = [k for k, ln in enumerate(body) if ln.startswith("global_load_dwordx4")]
+        runs = [k for k in loads if all(body[k + j].startswith("global_load_dwordx4") for j in range(4) if k + j < len(body)) and k + 3 < len(body)]
+        assert runs, (name, "the four node loads are not issued together")
+        desc = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\b(.*?)\.end_amdhsa_kernel", out, re.S).group(1)
+        assert re.search(r"\.amdhsa_float_denorm_mode_16_64\s+3", desc), name
+        assert re.search(r"\.amdhsa_float_denorm_mode_32\s+3", desc), name
