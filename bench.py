@@ -58,6 +58,10 @@ def per_view_mesh_bytes(V, F):
 
 
 VALU_PEAK = 256 * 4 * 2.4e9 / 2     # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32 units, two cycles per wave-instruction (MI355X_MICROARCH.md)
+# What this chip sustains on streams of ONE instruction at 8 waves per SIMD (tools/ubench/valu_rate.hip, G wave-instructions/s): only the
+# fma class comes near the two-cycle figure; compares, selects, min/max, permutes -- three quarters of an inner visit -- take four cycles,
+# and packed float32 fmas are slower per fma than plain ones.  `frac` is priced against VALU_PEAK all the same.
+VALU_MEASURED = {"v_fma_f32": 834.0, "v_max_f32": 563.8, "v_pk_fma_f32 (x2 fmas)": 246.6, "source": "tools/ubench/valu_rate.hip"}
 # which bench.py stage is which kernel(s) in a rocprofv3 trace
 KERNELS = {"k_trace<closest>": ("trace1", "trace2"), "k_trace<any>": ("trace3",), "fill + k_cull": ("fill", "cull"), "k_raster": ("raster",),
            "k_shade1": ("shade1",), "k_shade2": ("shade2",), "k_finish": ("finish",), "k_render_bwd": ("backward", "collect"),
@@ -144,6 +148,12 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
                        valu_busy_quadcycles_per_launch=rec.get("SQ_ACTIVE_INST_VALU"), salu_instr_per_launch=rec.get("SQ_INSTS_SALU"),
                        l2_hit=round(rec["TCC_HIT_sum"] / (rec["TCC_HIT_sum"] + rec["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in rec and "TCC_MISS_sum" in rec else None,
                        hbm_bytes_per_launch=rec.get("hbm_bytes_per_launch"))
+            if rec.get("SQ_ACTIVE_INST_VALU") and rec.get("GRBM_GUI_ACTIVE"):
+                # share of the launch during which a SIMD's vector ALU is occupied: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
+                # 1024 SIMDs, GRBM_GUI_ACTIVE the launch's cycles summed over the 8 XCDs (both from the serialised PMC passes)
+                out["valu_pipe_busy"] = round(rec["SQ_ACTIVE_INST_VALU"] * 4 * 8 / (1024 * rec["GRBM_GUI_ACTIVE"]), 3)
+                out["valu_lanes_useful"] = round(rec["SQ_THREAD_CYCLES_VALU"] / (64 * rec["SQ_ACTIVE_INST_VALU"]), 3) if rec.get("SQ_THREAD_CYCLES_VALU") else None
+            out["measured_issue_rates"] = VALU_MEASURED
             if alone:
                 ms_a = sum(alone[m]["ms_per_step"] for m in members if m in alone) * args.steps
                 out["alone"] = {"avg_launch_ms": round(ms_a / launches, 4), "achieved": round(rec["SQ_INSTS_VALU"] / (ms_a / launches * 1e-3) / 1e9, 1),
