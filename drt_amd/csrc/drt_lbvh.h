@@ -183,10 +183,13 @@ DRT_HD void lbvh_children(const uint32_t* keys, int n, int i, int32_t& left, int
 // Fewer, fatter steps: traversal on MI355X is bound by the latency of the dependent node
 // fetches, not by ALU or bytes.  One node = 128 bytes = one L2 line, SoA so that each 16-byte
 // load brings one bound of all four children.
-// Leaf size: <= 2 triangles.  With keys taken at the box centre a leaf of two is typically the two halves of one quad (same key);
-// measured per step on MI355X (horse x4): 8 -> 3.08 ms, 4 -> 2.96, 2 -> 2.91, 1 -> 2.92 (with the round-1 centroid keys 4 was best).
+// Leaf size: ONE triangle.  The best size follows the price of an inner visit: per step on MI355X (horse x4) 8 -> 3.08 ms, 4 -> 2.96,
+// 2 -> 2.91, 1 -> 2.92 while an inner visit was ~158 vector instructions (with the round-1 centroid keys 4 was best); at 97 instructions
+// a visit is cheaper than the second triangle test a two-triangle leaf makes most rays pay for: k_trace<closest> 0.379 -> 0.364 ms per
+// launch, k_trace<any> 0.182 -> 0.171, fused step -2.2 %, drop-in step -0.6 % (mouse -1.5 %, monkey and hand unchanged).  With keys taken
+// at the box centre the two halves of a quad still share a key and therefore a parent.  (-DDRT_LEAF_BITS=1, 2: leaves of <= 2, <= 4.)
 #ifndef DRT_LEAF_BITS
-#define DRT_LEAF_BITS 1
+#define DRT_LEAF_BITS 0
 #endif
 constexpr int kLeafBits = DRT_LEAF_BITS, kLeafMax = 1 << kLeafBits;
 
