@@ -798,6 +798,50 @@ __global__ void __launch_bounds__(256) k_render_bwd_rows(PathCtx c, const double
     }
 }
 
+// ray_loss AND its vertex gradient over the forward's list of completed paths, in one pass: what k_ray_loss_listed (loss, row list)
+// and, one autograd hop later, k_render_bwd_rows (recompute the listed paths, adjoint, scatter) did in two -- the second already
+// recomputed every path and its loss term.  The gradient is accumulated with a UNIT seed into a stash the caller scales by the
+// incoming d / d loss when (if) the backward pass arrives; the loss term of a path recomputed from its face ids is the term of
+// the stored out_ori / out_dir rows bit for bit (same code).
+__global__ void __launch_bounds__(256) k_loss_bwd_listed(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                         const double* __restrict__ screen_pixel, const uint8_t* __restrict__ valid,
+                                                         const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
+                                                         const int32_t* __restrict__ paths, const int64_t* __restrict__ n_paths,
+                                                         double* loss, double* grad_verts) {
+    __shared__ int32_t hkeys[kHashSize];
+    __shared__ double hsums[3 * kHashSize];
+    const int64_t n = *n_paths;
+    const HashAdd3 add{hkeys, hsums, grad_verts};
+    double acc = 0.0;
+    for (int64_t base = blockIdx.x * (int64_t)kBwdBatch; base < n; base += (int64_t)gridDim.x * kBwdBatch) {
+        hash_clear(hkeys, hsums);
+        const int64_t end = base + kBwdBatch < n ? base + kBwdBatch : n;
+        for (int64_t k = base + threadIdx.x; k < end; k += blockDim.x) {
+            const int64_t i = paths[k];
+            if (!valid[i]) continue;
+            d3 v0, v1, v2;
+            int32_t vid1[3], vid2[3];
+            Bounce b1, b2;
+            load_tri64(c, face1[i], v0, v1, v2, vid1);
+            bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b1);
+            load_tri64(c, face2[i], v0, v1, v2, vid2);
+            bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
+            d3 g_dir;
+            acc += ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
+            const d3 z{0.0, 0.0, 0.0};
+            d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
+            bounce_backward(b2, z, g_dir, ga, gb, gc, g_o, g_d);
+            add(vid2[0], ga); add(vid2[1], gb); add(vid2[2], gc);
+            ga = z; gb = z; gc = z;
+            bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
+            add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
+        }
+        hash_flush(hkeys, hsums, grad_verts);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+}
+
 __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused, int raster) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // sub-batches on different streams may report concurrently: atomics
@@ -1139,6 +1183,24 @@ int drt_ray_loss_listed(const double* d_out_ori, const double* d_out_dir, const 
     if (!d_out_ori || !d_out_dir || !d_screen_pixel || !d_valid || !d_paths || !d_n_paths || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_rows == nullptr) != (d_n_rows == nullptr)) return fail(DRT_E_INVALID, "d_rows and d_n_rows go together");
     k_ray_loss_listed<<<1024, 256, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_screen_pixel, d_valid, d_paths, d_n_paths, d_loss, d_rows, d_n_rows);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_ray_loss_listed_grad(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                             double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                             const double* d_screen_pixel, const uint8_t* d_valid, const int32_t* d_paths, const int64_t* d_n_paths,
+                             double* d_loss, double* d_grad_verts, void* stream) {
+    CHECK_BUILT(s);
+    if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (n_rays == 0) return DRT_OK;
+    if (!d_verts || !d_origin || !d_dir || !d_face1 || !d_face2 || !d_screen_pixel || !d_valid || !d_paths || !d_n_paths || !d_loss || !d_grad_verts)
+        return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    { StageTimer t(s, st, kStageBackward);
+      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, d_loss, d_grad_verts); }
+    if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -125,6 +125,12 @@ def _f64c(t, name):
 # The values are identical.  What it cannot serve is a caller who asks autograd for d loss / d out_dir ITSELF
 # (torch.autograd.grad(loss, out_dir), out_dir.retain_grad()): set SPARSE_LOSS_GRAD = False for that.
 SPARSE_LOSS_GRAD = True
+# On top of that: when ray_loss is given render_transparent's own, untouched (out_ori, out_dir, mask), its forward pass already computes
+# d loss / d vertices with a unit seed next to the loss (ONE pass over the completed paths: drt_ray_loss_listed_grad) and the backward pass
+# only scales that stash by the incoming gradient -- instead of a loss pass now and a second pass over the same paths (recompute,
+# adjoint, scatter) in render_transparent's backward.  Costs the gradient's work to a caller who needs grad mode on but never calls
+# backward(); set EAGER_LOSS_GRAD = False for that.
+EAGER_LOSS_GRAD = True
 
 
 class _GradLink:
@@ -133,6 +139,8 @@ class _GradLink:
         self._token = None
         self.paths = None
         self.mask = None
+        self.out_ori = None
+        self.render = None      # (scene handle owner, vertices, origin, ray_dir, face1, face2, (ior_int, ior_ext)) of the forward call
 
     def token(self, n, device):
         if self._token is None or self._token.shape[0] != n:
@@ -172,6 +180,7 @@ class _RenderTransparent(torch.autograd.Function):
         ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)
         if link is not None:
             link.paths = (valid_idx, n_valid)        # the rays with mask = 1: ray_loss walks this list instead of all N rays
+            link.render = (scene, v, o, d, face1, face2, ctx.ior) if need_bwd else None
         # an output the loss does not use must reach backward() as None, not as a materialised [N,3] float64 zero tensor:
         # the reference's ray_loss detaches out_ori (optim.py:100), and filling 1.8 GB of zeros per step cost 0.3 ms
         ctx.set_materialize_grads(False)
@@ -183,11 +192,12 @@ class _RenderTransparent(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_ori, g_dir, g_mask):
         v, o, d, face1, face2, valid_idx, n_valid = ctx.saved_tensors
-        grad_v = torch.zeros_like(v)
         link = ctx.link
         pending, link.pending = link.pending, []
         if g_dir is not None and link.is_token(g_dir):
             g_dir = None                        # ray_loss's placeholder: its gradient is in `pending`
+        # (the usual step -- one ray_loss, eager stash, nothing dense -- is ONE small launch: stash * scale)
+        grad_v = None if (g_ori is None and g_dir is None and pending and all(e[0] is None for e in pending)) else torch.zeros_like(v)
         h = ctx.scene.optix_mesh._h
         with torch.cuda.device(o.device):
             if g_ori is not None or g_dir is not None:
@@ -198,9 +208,14 @@ class _RenderTransparent(torch.autograd.Function):
                     face1.data_ptr(), face2.data_ptr(), _lib.ptr(valid_idx), _lib.ptr(n_valid),
                     _lib.ptr(g_ori), _lib.ptr(g_dir), grad_v.data_ptr(), _stream()))
             for rows, n_rows, sp, scale in pending:
+                if rows is None:                # eager entry: n_rows is the unit-seed vertex gradient ray_loss's forward left
+                    continue
                 _lib.check(_lib.lib().drt_render_backward_ray_loss(
                     h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1], face1.data_ptr(), face2.data_ptr(),
                     rows.data_ptr(), n_rows.data_ptr(), sp.data_ptr(), scale.data_ptr(), grad_v.data_ptr(), _stream()))
+        for rows, stash, _, scale in pending:
+            if rows is None:
+                grad_v = torch.addcmul(grad_v, stash, scale) if grad_v is not None else stash * scale
         return grad_v, None, None, None, None, None, None, None
 
 
@@ -221,9 +236,20 @@ class _RayLoss(torch.autograd.Function):
         g = torch.empty_like(od) if need and link is None else None      # dense d loss / d out_dir only without a link
         rows = torch.empty(n, dtype=torch.int32, device=oo.device) if need else None
         n_rows = torch.zeros(1, dtype=torch.int32, device=oo.device) if need else None
+        ctx.stash = None
+        own = (link is not None and link.paths is not None and link.paths[0] is not None and link.mask is not None
+               and link.mask() is mask and mask._version == 0)           # the forward's own mask, untouched: its list of set rows is exact
         with torch.cuda.device(oo.device):
-            if (link is not None and link.paths is not None and link.paths[0] is not None and link.mask is not None
-                    and link.mask() is mask and mask._version == 0):     # the forward's own mask, untouched: its list of set rows is exact
+            if (own and need and EAGER_LOSS_GRAD and link.render is not None and link.out_ori is not None and link.out_ori() is out_ori
+                    and out_ori._version == 0 and out_dir._version == 0):
+                # loss + unit-seed vertex gradient in one pass over the completed paths (see EAGER_LOSS_GRAD)
+                scene, v, o, d, face1, face2, ior = link.render
+                ctx.stash = torch.zeros_like(v)
+                _lib.check(_lib.lib().drt_ray_loss_listed_grad(
+                    scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, ior[0], ior[1], face1.data_ptr(), face2.data_ptr(),
+                    sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(), link.paths[1].data_ptr(), loss.data_ptr(), ctx.stash.data_ptr(), _stream()))
+                rows = n_rows = None
+            elif own:
                 _lib.check(_lib.lib().drt_ray_loss_listed(oo.data_ptr(), od.data_ptr(), sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(),
                                                           link.paths[1].data_ptr(), n, loss.data_ptr(), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
             else:
@@ -240,7 +266,11 @@ class _RayLoss(torch.autograd.Function):
         if ctx.link is not None:                 # row-list hand-off to render_transparent's backward (see _GradLink)
             if ctx.n_rays == 0:
                 return None, None, None, None, None, None
-            ctx.link.pending.append((rows, n_rows, sp, g_loss.detach().to(torch.float64).reshape(1).contiguous()))
+            scale = g_loss.detach().to(torch.float64).reshape(1).contiguous()
+            if ctx.stash is not None:
+                ctx.link.pending.append((None, ctx.stash, None, scale))
+                return None, ctx.link.token(ctx.n_rays, ctx.stash.device), None, None, None, None
+            ctx.link.pending.append((rows, n_rows, sp, scale))
             return None, ctx.link.token(ctx.n_rays, rows.device), None, None, None, None
         if g is None:
             return None, None, None, None, None, None
@@ -414,6 +444,7 @@ class Scene(StepwiseMixin):
         out_ori, out_dir, mask = _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR, link, grid)
         out_dir._drt_link = link            # lets ray_loss hand its gradient over as a row list (see _GradLink)
         link.mask = weakref.ref(mask)
+        link.out_ori = weakref.ref(out_ori)
         return out_ori, out_dir, mask
 
     def ray_loss_fused(self, origin, ray_dir, screen_pixel, valid):

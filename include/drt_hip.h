@@ -141,6 +141,15 @@ int drt_ray_loss_listed(const double* d_out_ori, const double* d_out_dir, const 
 int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list,
                     const double* d_scale, void* stream);
 
+/* ray_loss (reference optim.py:91-108) AND its vertex gradient in one pass over the forward's list of completed paths
+ * (drt_render_forward's d_valid_idx / d_n_valid, face ids from the same call): *d_loss += the loss (float64 scalar, zero it first)
+ * and d_grad_verts float64 [V,3] += d loss / d vertices with a UNIT seed (the caller scales it by the incoming gradient of the loss:
+ * the loss is a scalar, its backward through render_transparent is linear in that seed).  Replaces drt_ray_loss_listed followed,
+ * in the backward pass, by drt_render_backward_ray_loss when out_dir is the tensor drt_render_forward produced. */
+int drt_ray_loss_listed_grad(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                             double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                             const double* d_screen_pixel, const uint8_t* d_valid, const int32_t* d_paths, const int64_t* d_n_paths,
+                             double* d_loss, double* d_grad_verts, void* stream);
 /* Adjoint of drt_render_forward followed by drt_ray_loss, for the rays drt_ray_loss listed (d_rows / *d_n_rows):
  * grad_verts [V,3] += *d_scale * d ray_loss / d vertices.  Equivalent to drt_scale_rows3 + drt_render_backward with the
  * dense d loss / d out_dir, without that [N,3] tensor (zero in all but the listed rows) ever being written or read:
