@@ -765,6 +765,47 @@ def test_ray_loss_gradient_as_row_list_equals_the_dense_tensor(Render, hand):
     np.testing.assert_allclose(a[0].cpu().numpy(), 2.5 * ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
 
 
+def test_eager_loss_gradient_equals_the_two_pass_form(Render, hand):
+    """ray_loss on render_transparent's own outputs leaves d loss / d vertices (unit seed) in its forward pass
+    (drt_ray_loss_listed_grad); EAGER_LOSS_GRAD = False, an output that is not the forward's own tensor, or a modified one, take
+    the two-pass form (loss pass + recompute in the backward).  Same loss, same vertex gradient; no stash without grad mode."""
+    g = golden("hand_r128_v41")
+    o, d, sp, valid = fixture_view(g)
+    o, d, sp, valid = o.cuda(), d.cuda(), sp.cuda(), valid.cuda()
+    Render.resx = Render.resy = int(g["res"])
+    scene = Render.Scene(data_path("hand_vh.ply"), 0)
+
+    def run(eager, touch=None):
+        Render.EAGER_LOSS_GRAD = eager
+        try:
+            V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+            scene.update_verticex(V)
+            oo, od, mk = scene.render_transparent(o, d)
+            if touch == "clone_ori":
+                oo = oo.clone()                       # not the forward's own out_ori any more
+            node = Render.ray_loss(oo, od, mk, sp, valid)
+            had_stash = node.grad_fn.stash is not None
+            gv, = torch.autograd.grad(1.75 * node, V, retain_graph=True)
+            gv2, = torch.autograd.grad(node, V)                     # again on the same graph, another seed
+            return float(node), gv, gv2, had_stash
+        finally:
+            Render.EAGER_LOSS_GRAD = True
+
+    la, ga, ga2, sa = run(True)
+    lb, gb, gb2, sb = run(False)
+    lc, gc, gc2, sc = run(True, touch="clone_ori")
+    assert sa and not sb and not sc
+    assert la == pytest.approx(float(g["ray_loss"]), rel=1e-10) and lb == pytest.approx(la, rel=1e-12) and lc == pytest.approx(la, rel=1e-12)
+    for x, y in ((ga, gb), (ga2, gb2), (gc, gb), (gc2, gb2)):
+        assert torch.allclose(x, y, rtol=1e-11, atol=1e-13 * y.abs().max().item())
+    assert torch.allclose(ga, 1.75 * ga2, rtol=1e-12, atol=0.0)
+    ref = g["grad_ray_loss"]
+    np.testing.assert_allclose(ga2.cpu().numpy(), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    with torch.no_grad():                                           # no gradient asked for: the cheap loss pass, no stash
+        oo, od, mk = scene.render_transparent(o, d)
+        assert float(Render.ray_loss(oo, od, mk, sp, valid)) == pytest.approx(la, rel=1e-12)
+
+
 def test_fused_limit_sgd_equals_hook_plus_torch_sgd():
     """drt_amd.optim.FusedLimitSGD (one kernel) against limit_hook + torch.optim.SGD(momentum, nesterov) over five steps with NaN,
     inf and out-of-range gradient entries (reference optim.py:155-171, 215)."""

@@ -4,8 +4,6 @@
 set -u
 P=${1:-r02}
 O=gpurun_out/final_$P; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --mode fused --no-cpu-baseline > $O/bench_fused.json 2> /dev/null
 {
   for cfg in "--mesh hand --res 512 --views 72" "--mesh mouse --res 1024 --views 72" "--mesh horse --res 1024 --views 72" "--mesh monkey --res 1024 --views 72" "--mesh monkey --res 1024 --views 144"; do
     python bench.py $cfg --no-cpu-baseline --no-extras --steps 10 --warmup 3 2>/dev/null | python -c "
@@ -29,4 +27,8 @@ DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --n
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
 bash tools/profile.sh $P > $O/profile.log 2>&1
 PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
+# the bench lines LAST, with this build's own counters: bench.py prices k_trace's live launch time against SQ_INSTS_VALU of profiles/pmc.json
+python tools/make_pmc_json.py gpurun_out/$P profiles/pmc.json dropin > /dev/null && cp profiles/pmc.json $O/pmc.json
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --mode fused --no-cpu-baseline > $O/bench_fused.json 2> /dev/null
 tail -n 3 $O/configs.txt $O/scaling_proxy.txt $O/iter_bench.txt; python tools/benchsum.py $O/bench.json | head -3
