@@ -787,7 +787,7 @@ def test_eager_loss_gradient_equals_the_two_pass_form(Render, hand):
             had_stash = node.grad_fn.stash is not None
             gv, = torch.autograd.grad(1.75 * node, V, retain_graph=True)
             gv2, = torch.autograd.grad(node, V)                     # again on the same graph, another seed
-            return float(node), gv, gv2, had_stash
+            return float(node.detach()), gv, gv2, had_stash
         finally:
             Render.EAGER_LOSS_GRAD = True
 
