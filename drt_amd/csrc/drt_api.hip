@@ -30,6 +30,8 @@ int drt_create(int device, drt_scene_t** out) {
     if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->build_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->prefill_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->prefill_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->build_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->build_done, hipEventDisableTiming);
     if (const char* ev = getenv("DRT_ASYNC_BUILD")) s->async_build = atoi(ev) != 0;
@@ -96,6 +98,8 @@ void drt_destroy(drt_scene_t* s) {
     (void)hipFree(s->vcount);
     (void)hipFree(s->vh_list);
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+    if (s->prefill_fork) (void)hipEventDestroy(s->prefill_fork);
+    if (s->prefill_done) (void)hipEventDestroy(s->prefill_done);
     for (auto& e : s->prof_ev) (void)hipEventDestroy(e);
     (void)hipFree(s->prof_counts);
     delete s;

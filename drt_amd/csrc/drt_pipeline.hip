@@ -937,6 +937,8 @@ static bool raster_on(const drt_scene* s, int64_t n, int tile_w, int tile_h) {
 }
 
 // cull -> trace -> shade1 -> trace -> shade2 -> trace(any) for one sub-batch; the caller appends the last stage.
+// internal bits of launch_chunk's grid_mode (above the public DRT_GRID_* ones): which dense outputs the caller zeroed ahead of time
+constexpr int kIntPreOri = 1 << 16, kIntPreDir = 1 << 17, kIntPreMask = 1 << 18, kIntMask = kIntPreOri | kIntPreDir | kIntPreMask;
 // `w` non-null and whole images (tile_w x tile_h) of a multiple-of-64 width: primary visibility by projection
 // (drt_raster.h), k_trace #1 then only sees the rays that are not grid rays (normally none).
 extern "C++" {
@@ -945,6 +947,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h,
                         int grid_mode, ViewModel* grid_cache /* models of the images of THIS sub-batch */) {
     const bool sparse_faces = (grid_mode & DRT_GRID_SPARSE_FACES) != 0;
+    const bool pre_ori = (grid_mode & kIntPreOri) != 0, pre_dir = (grid_mode & kIntPreDir) != 0, pre_mask = (grid_mode & kIntPreMask) != 0;   // zeroed ahead of time (drt_prefill_zero)
     const bool all_verified = (grid_mode & DRT_GRID_ALL_VERIFIED) != 0 && (grid_mode & 3) == DRT_GRID_TRUST && grid_cache;
     grid_mode &= 3;
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
@@ -973,8 +976,9 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
             late_fill = s->fill_overlap;
             if (!late_fill) {
                 StageTimer t(s, st, kStageFill);
-                (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
-                (void)hipMemsetAsync(mask, 0, 3 * n, st);
+                if (!pre_ori) (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, st);
+                if (!pre_dir) (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, st);
+                if (!pre_mask) (void)hipMemsetAsync(mask, 0, 3 * n, st);
             }
             if (!sparse_faces) { (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st); }
         }
@@ -987,6 +991,10 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     // beside the projection pass above).  When the caller vouches that every ray of every image is a verified grid ray, nothing before
     // the traversal of the refracted rays touches the tree -- the wait moves there, and at small per-GPU shares (9 views: build 0.19 ms,
     // projection + cull + first shading 0.17 ms) the build leaves the critical path.
+    // outputs zeroed ahead of time: the zeroing must have finished before anything writes them -- k_shade2 when the fills of this call are
+    // the late ones (k_shade1 then leaves the dense outputs alone), the cull stage otherwise
+    const bool pre_any = pre_ori || pre_dir || pre_mask;
+    if (pre_any && !late_fill) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     const bool tree_late = all_verified && rz.views != nullptr;
     if (!tree_late) { int rc = wait_build(s, st); if (rc) return rc; }
     { StageTimer t(s, st, kStageCull);
@@ -1002,8 +1010,9 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     if (late_fill) {      // (StageTimer scopes must not nest: this one follows the cull stage's)
         if (fs != st) { HIP_TRY(hipEventRecord(w.fill_fork, st)); HIP_TRY(hipStreamWaitEvent(fs, w.fill_fork, 0)); }
         { StageTimer tf(s, fs, kStageFill);
-          (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, fs); (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, fs);
-          (void)hipMemsetAsync(mask, 0, 3 * n, fs); }
+          if (!pre_ori) (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, fs);
+          if (!pre_dir) (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, fs);
+          if (!pre_mask) (void)hipMemsetAsync(mask, 0, 3 * n, fs); }
         if (fs != st) HIP_TRY(hipEventRecord(w.fill_join, fs));
     }
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
@@ -1026,6 +1035,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
       k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
       k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, TraceOut{p.r1.face, nullptr, nullptr, nullptr}); }
     if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));     // k_shade2 is the first kernel that writes rows of the dense outputs
+    if (late_fill && pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);
@@ -1086,6 +1096,16 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
     int rc = fork_streams(s, st, pl.streams);
     if (rc) return rc;
+    grid_mode &= ~kIntMask;
+    if (s->n_prefill) {       // buffers zeroed ahead of time (drt_prefill_zero): which of this call's outputs are they?
+        for (int k = 0; k < s->n_prefill; ++k) {
+            const drt_scene::Prefill& f = s->prefill[k];
+            if (f.ptr == d_out_ori && f.bytes == (int64_t)sizeof(double) * 3 * n_rays) grid_mode |= kIntPreOri;
+            if (f.ptr == d_out_dir && f.bytes == (int64_t)sizeof(double) * 3 * n_rays) grid_mode |= kIntPreDir;
+            if (f.ptr == d_mask && f.bytes == 3 * n_rays) grid_mode |= kIntPreMask;
+        }
+        s->n_prefill = 0;     // one shot (launch_chunk waits for prefill_done in front of the first kernel that writes those outputs)
+    }
     for (int j = 0; j < pl.count; ++j) {
         drt_scene::Sub& w = s->sub[j % pl.streams];
         const int64_t b = j * pl.size;
@@ -1105,6 +1125,30 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     if (d_n_valid) k_store_count<<<1, 64, 0, st>>>(s->vcount, d_n_valid);
     if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_prefill_zero(drt_scene_t* s, void* d_buf, int64_t bytes, void* stream) {
+    CHECK_SCENE(s);
+    if (!d_buf || bytes <= 0) return fail(DRT_E_INVALID, "bad buffer");
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return fail(DRT_E_INVALID, "drt_prefill_zero: not while a graph is being captured");
+    if (s->n_prefill >= 3) s->n_prefill = 0;      // stale entries of a caller that never rendered into them
+    hipStream_t bs = s->build_stream;
+    HIP_TRY(hipEventRecord(s->prefill_fork, st));
+    HIP_TRY(hipStreamWaitEvent(bs, s->prefill_fork, 0));
+    { StageTimer t(s, bs, kStageFill);
+      HIP_TRY(hipMemsetAsync(d_buf, 0, (size_t)bytes, bs)); }
+    HIP_TRY(hipEventRecord(s->prefill_done, bs));
+    s->prefill[s->n_prefill].ptr = d_buf; s->prefill[s->n_prefill].bytes = bytes; ++s->n_prefill;
+    return DRT_OK;
+}
+
+int drt_prefill_wait(drt_scene_t* s, void* stream) {
+    CHECK_SCENE(s);
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->prefill_done, 0));
+    s->n_prefill = 0;
     return DRT_OK;
 }
 

@@ -130,6 +130,12 @@ struct drt_scene {
     int sub_per_stream = 1;        // sub-batches dealt to each stream (when the call is large enough)
     int64_t min_sub_rays = 1 << 24;   // do not cut a call into sub-batches smaller than this
     hipEvent_t fork_ev = nullptr;
+    // drt_prefill_zero: dense outputs of the NEXT drt_render_forward zeroed ahead of time on the build stream (idle after a forward's
+    // join, i.e. during the caller's loss / backward / optimiser tail); a forward whose out_ori / out_dir / mask IS such a buffer skips that fill
+    struct Prefill { const void* ptr = nullptr; int64_t bytes = 0; };
+    Prefill prefill[3];
+    int n_prefill = 0;
+    hipEvent_t prefill_fork = nullptr, prefill_done = nullptr;
     unsigned* vcount = nullptr;    // [0] valid rays of the whole call, [1] silhouette items of drt_vh_loss_fused
     uint32_t* vh_list = nullptr;   // (view, edge) items of drt_vh_loss_fused: its own buffer, so that the call may run on
     int64_t vh_cap = 0;            //   another stream than a pipeline call (which owns the Sub workspaces)

@@ -20,6 +20,7 @@ PyTorch only owns the tensors and the autograd plumbing.  Gradients reach
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -131,6 +132,13 @@ SPARSE_LOSS_GRAD = True
 # adjoint, scatter) in render_transparent's backward.  Costs the gradient's work to a caller who needs grad mode on but never calls
 # backward(); set EAGER_LOSS_GRAD = False for that.
 EAGER_LOSS_GRAD = True
+# The dense outputs are zeros in all but a few per cent of the rows, and writing those zeros (51 B per ray) is the one HBM-bound stage of a
+# render_transparent call.  With PREFILL_NEXT a call in trusted-grid mode allocates the out_ori and mask of the NEXT call of the same size
+# right away and has the library zero them on its idle stream (drt_prefill_zero) -- i.e. while the caller's loss, backward and optimiser
+# kernels run, which leave the memory system idle -- instead of beside the next call's traversal.  The tensors a call returns are its own
+# fresh allocations either way (nothing is ever handed out twice); the price is one extra out_ori + mask (27 B per ray) held between calls.
+PREFILL_NEXT = os.environ.get("DRT_PREFILL_NEXT", "1") != "0"
+PREFILL_MIN_RAYS = 1 << 25          # below this the two extra allocations and calls cost the host more than the earlier fill saves the GPU (18 views x 1024^2: +3 %, 9 views: +4 %)
 
 
 class _GradLink:
@@ -162,9 +170,18 @@ class _RenderTransparent(torch.autograd.Function):
         o = _f64c(origin.detach(), "origin")
         d = _f64c(ray_dir.detach(), "ray_dir")
         n = o.shape[0]
-        out_ori = torch.empty((n, 3), dtype=torch.float64, device=o.device)
+        om = scene.optix_mesh            # owns the buffers zeroed ahead of time: its drt_destroy waits for the zeroing before they are released
+        pre, om._prefilled = getattr(om, "_prefilled", None), None
+        if pre is not None and pre[0] == n and pre[1] == o.device:
+            out_ori, mask = pre[2], pre[3]
+        else:
+            if pre is not None:          # another size: let the zeroing finish (on this stream's timeline) before the memory goes back to the allocator
+                with torch.cuda.device(o.device):
+                    _lib.check(_lib.lib().drt_prefill_wait(om._h, _stream()))
+            out_ori = torch.empty((n, 3), dtype=torch.float64, device=o.device)
+            mask = torch.empty((n, 3), dtype=torch.uint8, device=o.device)
+        pre = None
         out_dir = torch.empty((n, 3), dtype=torch.float64, device=o.device)
-        mask = torch.empty((n, 3), dtype=torch.uint8, device=o.device)
         face1 = torch.empty(n, dtype=torch.int32, device=o.device)
         face2 = torch.empty(n, dtype=torch.int32, device=o.device)
         need_bwd = ctx.needs_input_grad[0]
@@ -175,6 +192,14 @@ class _RenderTransparent(torch.autograd.Function):
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
                 out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
                 _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0] | (0 if DENSE_FACE_IDS else 16), _lib.ptr(grid[1]), _stream()))
+            if PREFILL_NEXT and (grid[0] & 3) == 2 and n >= PREFILL_MIN_RAYS and not torch.cuda.is_current_stream_capturing():
+                # outputs of the next call of this size: allocated now, zeroed on the library's idle stream behind this forward pass
+                h = scene.optix_mesh._h
+                nxt_ori = torch.empty((n, 3), dtype=torch.float64, device=o.device)
+                nxt_mask = torch.empty((n, 3), dtype=torch.uint8, device=o.device)
+                _lib.check(_lib.lib().drt_prefill_zero(h, nxt_ori.data_ptr(), nxt_ori.numel() * 8, _stream()))
+                _lib.check(_lib.lib().drt_prefill_zero(h, nxt_mask.data_ptr(), nxt_mask.numel(), _stream()))
+                om._prefilled = (n, o.device, nxt_ori, nxt_mask)
         ctx.scene = scene
         ctx.ior = (float(ior_int), float(ior_ext))
         ctx.save_for_backward(v, o, d, face1, face2, valid_idx, n_valid)

@@ -141,6 +141,15 @@ int drt_ray_loss_listed(const double* d_out_ori, const double* d_out_dir, const 
 int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list,
                     const double* d_scale, void* stream);
 
+/* Zero `bytes` bytes at d_buf on the library's idle stream (the build stream: free between a forward's join and the next build), after
+ * everything already enqueued on `stream`.  A later drt_render_forward on this scene whose d_out_ori, d_out_dir or d_mask IS d_buf (same
+ * pointer, the matching size) does not fill that output again -- the fill of the NEXT step's outputs then runs beside the caller's loss /
+ * backward / optimiser kernels instead of beside the next forward.  Up to three buffers may be pending; entries are forgotten at the next
+ * drt_render_forward.  The reference has no counterpart: its outputs are torch.zeros of every call (DiffRender.py:421-423).
+ * drt_prefill_wait: `stream` waits for every zeroing enqueued so far and the pending entries are forgotten -- what a caller does before it
+ * releases such a buffer WITHOUT rendering into it (its allocator may hand the memory to work on `stream`); drt_destroy waits by itself. */
+int drt_prefill_zero(drt_scene_t* s, void* d_buf, int64_t bytes, void* stream);
+int drt_prefill_wait(drt_scene_t* s, void* stream);
 /* ray_loss (reference optim.py:91-108) AND its vertex gradient in one pass over the forward's list of completed paths
  * (drt_render_forward's d_valid_idx / d_n_valid, face ids from the same call): *d_loss += the loss (float64 scalar, zero it first)
  * and d_grad_verts float64 [V,3] += d loss / d vertices with a UNIT seed (the caller scales it by the incoming gradient of the loss:
