@@ -483,12 +483,16 @@ def main():
     # other, which makes the step faster and each of the two kernels look slower.
     prof_iso = None
     if not args.no_extras:
+        # (the next call's out_ori / mask are zeroed beside THIS call's loss + backward kernel by default, diffrender.PREFILL_NEXT: off
+        # here, so that the fills and that kernel are each timed with the GPU to themselves like every other stage)
+        prefill, Render.PREFILL_NEXT = Render.PREFILL_NEXT, False
         scene.optix_mesh.profile_enable(3)
         step(False)
         scene.optix_mesh.profile_read()
         for _ in range(args.steps):
             step(False)
         prof_iso = scene.optix_mesh.profile_read()
+        Render.PREFILL_NEXT = prefill
     scene.optix_mesh.profile_enable(0)
     if rank == 0:
         out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso, LIVE if prof_live else None)

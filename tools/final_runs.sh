@@ -26,7 +26,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views 9 whole-st
 DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
 bash tools/profile.sh $P > $O/profile.log 2>&1
-PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
+PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 DRT_PREFILL_NEXT=0 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
 # the bench lines LAST, with this build's own counters: bench.py prices k_trace's live launch time against SQ_INSTS_VALU of profiles/pmc.json
 python tools/make_pmc_json.py gpurun_out/$P profiles/pmc.json dropin > /dev/null && cp profiles/pmc.json $O/pmc.json
 python bench.py > $O/bench.json 2> $O/bench.err

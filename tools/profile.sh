@@ -50,7 +50,8 @@ with open(out + '/kernel_summary.txt', 'w') as o:
 PY
 run_pmc () {  # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
+  # (DRT_PREFILL_NEXT=0: counters are per-kernel properties; without it the last step leaves one more set of output fills than patch lists)
+  DRT_PREFILL_NEXT=0 rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
   local f=$(find "$W/$name" -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then python tools/pmc_summary.py "$f" > "$O/$name.txt"; else echo "no counter file" > "$O/$name.txt"; fi
 }
