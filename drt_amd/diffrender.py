@@ -171,7 +171,14 @@ class _RenderTransparent(torch.autograd.Function):
         d = _f64c(ray_dir.detach(), "ray_dir")
         n = o.shape[0]
         om = scene.optix_mesh            # owns the buffers zeroed ahead of time: its drt_destroy waits for the zeroing before they are released
-        pre, om._prefilled = getattr(om, "_prefilled", None), None
+        capturing = torch.cuda.is_current_stream_capturing()
+        pre = getattr(om, "_prefilled", None)
+        if capturing:
+            # a graph replays THESE launches on THESE buffers: the fills must be part of it, and nothing outside the capture may be waited
+            # for inside it -- the buffers zeroed ahead of time stay where they are until the next call outside a capture
+            pre = None
+        else:
+            om._prefilled = None
         if pre is not None and pre[0] == n and pre[1] == o.device:
             out_ori, mask = pre[2], pre[3]
         else:
@@ -192,7 +199,7 @@ class _RenderTransparent(torch.autograd.Function):
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
                 out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
                 _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0] | (0 if DENSE_FACE_IDS else 16), _lib.ptr(grid[1]), _stream()))
-            if PREFILL_NEXT and (grid[0] & 3) == 2 and n >= PREFILL_MIN_RAYS and not torch.cuda.is_current_stream_capturing():
+            if PREFILL_NEXT and (grid[0] & 3) == 2 and n >= PREFILL_MIN_RAYS and not capturing and getattr(om, "_prefilled", None) is None:
                 # outputs of the next call of this size: allocated now, zeroed on the library's idle stream behind this forward pass
                 h = scene.optix_mesh._h
                 nxt_ori = torch.empty((n, 3), dtype=torch.float64, device=o.device)

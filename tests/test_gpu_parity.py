@@ -806,6 +806,73 @@ def test_eager_loss_gradient_equals_the_two_pass_form(Render, hand):
         assert float(Render.ray_loss(oo, od, mk, sp, valid)) == pytest.approx(la, rel=1e-12)
 
 
+def test_outputs_zeroed_ahead_of_time_equal_outputs_filled_in_the_call(Render, hand):
+    """PREFILL_NEXT: a trusted-grid call allocates the out_ori / mask of the next call of its size and has them zeroed on the library's idle
+    stream (drt_prefill_zero); the next call renders into them without filling them again.  Same outputs as with the fills inside the call,
+    every row outside the mask exactly zero, over several steps with moving vertices; a call of another size in between, a scene dropped
+    with buffers pending, and a graph capture after eager calls (which must not consume buffers zeroed outside the capture)."""
+    g = golden("hand_r128_v41")
+    o, d, sp, valid = fixture_view(g)
+    o, d = o.cuda(), d.cuda()
+    Render.resx = Render.resy = int(g["res"])
+    n = o.shape[0]
+    V0 = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    moves = [1e-3 * torch.randn(V0.shape, dtype=torch.float64, device="cuda", generator=gen) for _ in range(5)]
+
+    def run(prefill):
+        old = Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS
+        Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS = prefill, 0
+        try:
+            scene = Render.Scene(data_path("hand_vh.ply"), 0)
+            outs, used = [], []
+            for k, mv in enumerate(moves):
+                scene.update_verticex(V0 + mv)
+                if k == 3:                       # a call of another size in between: the pending buffers are dropped, not used
+                    scene.render_transparent(o[: n // 2].contiguous(), d[: n // 2].contiguous())
+                pending = getattr(scene.optix_mesh, "_prefilled", None)
+                oo, od, mk = scene.render_transparent(o, d)
+                used.append(pending is not None and pending[0] == n and oo.data_ptr() == pending[2].data_ptr())
+                outs.append((oo.clone(), od.clone(), mk.clone()))
+            return outs, used, scene
+        finally:
+            Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS = old
+
+    a, used, scene_a = run(True)
+    b, unused, _ = run(False)
+    assert used[2] and used[4] and not used[0] and not any(unused)      # (the first two calls establish / read back the grid verdict)
+    for (oo, od, mk), (oo2, od2, mk2) in zip(a, b):
+        assert torch.equal(mk, mk2) and torch.equal(oo, oo2) and torch.equal(od, od2)
+        dead = ~mk[:, 0]
+        assert int(mk.sum()) > 300 and float(oo[dead].abs().sum()) == 0.0 and float(od[dead].abs().sum()) == 0.0 and not mk[dead].any()
+    assert getattr(scene_a.optix_mesh, "_prefilled", None) is not None
+    del scene_a                                   # buffers pending: drt_destroy waits for the zeroing before they are released
+    torch.cuda.synchronize()
+    # capture after eager calls: the captured call allocates and fills its own outputs; replays give the eager result
+    Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS, keep = True, 0, (Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS)
+    try:
+        scene = Render.Scene(data_path("hand_vh.ply"), 0)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                scene.update_verticex(V0)
+                ref = scene.render_transparent(o, d)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert getattr(scene.optix_mesh, "_prefilled", None) is not None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            scene.update_verticex(V0)
+            got = scene.render_transparent(o, d)
+        for _ in range(2):
+            got[0].fill_(7.0); got[2].fill_(True)          # what a missing fill inside the graph would leave behind
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(got[2], ref[2]) and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    finally:
+        Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS = keep
+
+
 def test_fused_limit_sgd_equals_hook_plus_torch_sgd():
     """drt_amd.optim.FusedLimitSGD (one kernel) against limit_hook + torch.optim.SGD(momentum, nesterov) over five steps with NaN,
     inf and out-of-range gradient entries (reference optim.py:155-171, 215)."""
