@@ -189,7 +189,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
                 "stages": stages, "stages_alone_avg_launch_ms": {k: v["avg_launch_ms"] for k, v in alone.items()} if alone else None,
                 "whole_step_alg_GBps_per_gpu": round(step_alg / (elapsed / args.steps) / 1e9 / world, 1),
                 "live_stages": list(live) if live else None,
-                "note": "k_trace times (stages trace1..3) are hipEvent pairs on the launch streams INSIDE the timed region (N = 1); the other stages are "
+                "note": "the closest-hit traversal of the refracted rays (stage trace2 = every launch of the dominant kernel) is timed by hipEvent pairs on its launch streams INSIDE the timed region (N = 1); the other stages are "
                         "timed in an immediate repeat of the same steps with every stage's events on; sub-batches run on two internal streams, so stage "
                         "durations overlap (`alone`: the same steps, untimed, with the streams serialised). The kernel that takes the most time is "
                         "the closest-hit traversal: VALU-issue bound on an L2-resident tree (see node_visits_per_ray, lane_utilisation); the HBM "
@@ -380,7 +380,11 @@ def main():
     # N = 1: the per-kernel hipEvent pairs are recorded live inside the timed region (the roofline contract).  N > 1: they
     # are recorded in an eager repeat right after it, so that ~120 event records per step do not sit in a 1.7 ms step.
     live_profile = not args.graph and world == 1 and not os.environ.get('DRT_BENCH_NOPROF')
-    LIVE = ("trace1", "trace2", "trace3")       # every k_trace launch: the kernel the roofline is about
+    # the launches of the kernel the roofline is about (k_trace<closest> on the refracted rays: the closest-hit launch on rays outside the grid
+    # is not even issued when every ray is a verified grid ray).  Every event pair is a stream marker that keeps the next kernel from
+    # starting under the previous one's tail (~8 us each): with the occlusion launches and the empty first-traversal stage timed live too,
+    # 12 records per step cost 0.1 ms of a 2.4 ms step; those rows come from the repeat below like every other stage.
+    LIVE = ("trace2",)
     if live_profile:
         scene.optix_mesh.profile_select(LIVE)   # hipEvent pairs around the traversal kernels only (the other stages are
         scene.optix_mesh.profile_enable(True)   # timed in the repeat below: ~50 more event records per step cost 0.15 ms of 3.3)
