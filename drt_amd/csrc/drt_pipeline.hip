@@ -195,8 +195,9 @@ __device__ __forceinline__ void cull_patch(unsigned patch, bool prefilled, CullS
                 // the 64 rays of a wave are one 64-aligned run: one group bit decides whether any key was written here
                 const unsigned word = rz.zmask[i >> 11], bit = 1u << ((i >> 6) & 31);
                 if (word & bit) {
-                    key = rz.zbuf[i];
-                    if (key != kRasterEmpty) rz.zbuf[i] = kRasterEmpty;          // consumed: the buffer is empty again for the next call
+                    const int64_t zs = raster_slot(x, y, (unsigned)tile_w);
+                    key = rz.zbuf[zs];
+                    if (key != kRasterEmpty) rz.zbuf[zs] = kRasterEmpty;         // consumed: the buffer is empty again for the next call
                     clear_bit = bit;                                             // (cleared after the barrier below: see there)
                 }
             }
@@ -329,8 +330,9 @@ __global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __re
         unsigned long long key = kRasterEmpty;
         const unsigned word = rz.zmask[i >> 11], bit = 1u << ((i >> 6) & 31);
         if (word & bit) {
-            key = rz.zbuf[i];
-            if (key != kRasterEmpty) rz.zbuf[i] = kRasterEmpty;            // consumed: the buffer is empty again for the next call
+            const int64_t zs = raster_slot(x, y, (unsigned)tile_w);
+            key = rz.zbuf[zs];
+            if (key != kRasterEmpty) rz.zbuf[zs] = kRasterEmpty;           // consumed: the buffer is empty again for the next call
         }
         const bool cand = key != kRasterEmpty && (!FUSED || valid[i]);
         // rank of this thread's hit among the patch's hits, in 16x4-tile order

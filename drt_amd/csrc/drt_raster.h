@@ -125,4 +125,13 @@ DRT_HD unsigned long long raster_key(float t, int32_t face) {
 }
 constexpr unsigned long long kRasterEmpty = ~0ull;
 
+// Where the key of the ray in column x of (sub-batch-global) row gy lives: 4 x 4-pixel tiles, 16 keys = one 128-byte cache line each.
+// The chip serves memory requests -- and atomics above all -- per cache line, not per lane (tools/ubench/atomic_pattern.hip); the pixels a
+// triangle of one to three pixels touches, and those of its neighbours in the wave, share a tile far more often than a 16-pixel run of
+// one image row.  A bijection of [0, rows * w) whenever w and the row count are multiples of 4 (whole 64 x 4 patches: the
+// precondition of the projection pass).
+DRT_HD int64_t raster_slot(unsigned x, unsigned gy, unsigned w) {
+    return (((int64_t)(gy >> 2) * (w >> 2) + (x >> 2)) << 4) | ((gy & 3u) << 2) | (x & 3u);
+}
+
 }  // namespace drt

@@ -33,14 +33,14 @@ __global__ void __launch_bounds__(64) k_fit_views(const double* __restrict__ ori
 // Test one (triangle, pixel) pair and fold a hit into the pixel's key.  The plain read of the current key may be stale
 // (the L1 is not coherent with the atomics at L2) but keys only ever decrease, so a stale value is >= the true one:
 // skipping when the new key is not smaller than what was read can never drop a winner.
-__device__ __forceinline__ void raster_test(const TriRec& t, f3 o32, const double* __restrict__ dir, int64_t i,
+__device__ __forceinline__ void raster_test(const TriRec& t, f3 o32, const double* __restrict__ dir, int64_t i, int64_t slot,
                                             unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask) {
     const f3 d32 = to_f32(load_d3(dir, i));
     float tt;
     if (!tri_hit(o32, d32, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) return;
     const unsigned long long key = raster_key(tt, t.face);
-    if (key >= zbuf[i]) return;
-    atomicMin(&zbuf[i], key);
+    if (key >= zbuf[slot]) return;
+    atomicMin(&zbuf[slot], key);
     // one bit per 64 consecutive rays: k_cull reads keys only there.  Thousands of hits share a word, and atomics on ONE
     // address are served one at a time: set the bit only when a (possibly stale) read does not show it yet
     const uint32_t bit = 1u << ((i >> 6) & 31);
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris,
         const int local = item - (lo == 0 ? 0 : s_lane[wbase + lo - 1].end);
         const int row = (int)(((float)local + 0.5f) / (float)ow.nx);     // exact for these small integers
         const int x = ow.x0 + (local - row * ow.nx), y = ow.y0 + row;
-        raster_test(ow.tri, o32, dir, base + (int64_t)y * w + x, zbuf, zmask);
+        raster_test(ow.tri, o32, dir, base + (int64_t)y * w + x, raster_slot((unsigned)x, (unsigned)(view * h + y), (unsigned)w), zbuf, zmask);
     }
 }
 
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) k_raster_big(const TriRec* __restrict__ t
         const int64_t cnt = (int64_t)it.nx * it.ny;
         for (int64_t p = threadIdx.x; p < cnt; p += 256) {
             const int y = it.y0 + (int)(p / it.nx), x = it.x0 + (int)(p % it.nx);
-            raster_test(t, o32, dir, base + (int64_t)y * w + x, zbuf, zmask);
+            raster_test(t, o32, dir, base + (int64_t)y * w + x, raster_slot((unsigned)x, (unsigned)(it.view * h + y), (unsigned)w), zbuf, zmask);
         }
     }
 }
