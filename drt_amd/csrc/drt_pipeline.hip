@@ -518,9 +518,12 @@ struct HashAdd3 {
     double* sums;       // LDS [kHashSize * 3]
     double* g;          // global fallback / final target
     __device__ __forceinline__ void operator()(int32_t v, d3 a) const {
-        // slot = low bits of the vertex id (linear probing): neighbouring slots then hold neighbouring ids, and the flush below walks the
+        // slot = low bits of the vertex id: neighbouring slots then hold neighbouring ids, and the flush below walks the
         // table as flat doubles, so that a wave's atomics fall on runs of consecutive addresses -- see hash_flush
         unsigned h = (unsigned)v & (kHashSize - 1);
+        // (ids come in runs of neighbours, and so do the occupied slots: a colliding id leaves the run in one odd stride that
+        // depends on its high bits instead of walking through it slot by slot)
+        const unsigned step = ((((unsigned)v >> kHashBits) << 1) + 97u) | 1u;
 #pragma unroll 1
         for (int probe = 0; probe < 24; ++probe) {
             int32_t k = keys[h];
@@ -531,7 +534,7 @@ struct HashAdd3 {
                 __hip_atomic_fetch_add(&sums[3 * h + 2], a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return;
             }
-            h = (h + 1) & (kHashSize - 1);
+            h = (h + step) & (kHashSize - 1);
         }
         AtomicAdd3{g}(v, a);     // table crowded: straight to memory
     }
