@@ -266,21 +266,21 @@ class _RayLoss(torch.autograd.Function):
         need = ctx.needs_input_grad[1]
         ctx.link = link if need else None
         g = torch.empty_like(od) if need and link is None else None      # dense d loss / d out_dir only without a link
-        rows = torch.empty(n, dtype=torch.int32, device=oo.device) if need else None
-        n_rows = torch.zeros(1, dtype=torch.int32, device=oo.device) if need else None
         ctx.stash = None
         own = (link is not None and link.paths is not None and link.paths[0] is not None and link.mask is not None
                and link.mask() is mask and mask._version == 0)           # the forward's own mask, untouched: its list of set rows is exact
+        eager = (own and need and EAGER_LOSS_GRAD and link.render is not None and link.out_ori is not None and link.out_ori() is out_ori
+                 and out_ori._version == 0 and out_dir._version == 0)
+        rows = torch.empty(n, dtype=torch.int32, device=oo.device) if need and not eager else None     # (the eager form needs no row list)
+        n_rows = torch.zeros(1, dtype=torch.int32, device=oo.device) if need and not eager else None
         with torch.cuda.device(oo.device):
-            if (own and need and EAGER_LOSS_GRAD and link.render is not None and link.out_ori is not None and link.out_ori() is out_ori
-                    and out_ori._version == 0 and out_dir._version == 0):
+            if eager:
                 # loss + unit-seed vertex gradient in one pass over the completed paths (see EAGER_LOSS_GRAD)
                 scene, v, o, d, face1, face2, ior = link.render
                 ctx.stash = torch.zeros_like(v)
                 _lib.check(_lib.lib().drt_ray_loss_listed_grad(
                     scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, ior[0], ior[1], face1.data_ptr(), face2.data_ptr(),
                     sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(), link.paths[1].data_ptr(), loss.data_ptr(), ctx.stash.data_ptr(), _stream()))
-                rows = n_rows = None
             elif own:
                 _lib.check(_lib.lib().drt_ray_loss_listed(oo.data_ptr(), od.data_ptr(), sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(),
                                                           link.paths[1].data_ptr(), n, loss.data_ptr(), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
