@@ -50,7 +50,7 @@ constexpr int kStackFast = DRT_STACK_FAST;         // LDS stack entries per lane
 // children are strict binary descendants, so wide depth <= binary height, and a Karras tree over (30-bit key, 32-bit index)
 // composites gains at least one prefix bit per level: height <= 64.  3 x 64 entries therefore ALWAYS suffice (drt_traverse.h
 // Stack has no bound check); the part beyond the LDS entries lives in a per-thread global area that is only touched on overflow.
-static_assert(kStackFast >= 3, "FastStack keeps three spare entries above its usable depth");
+static_assert(kStackFast >= 3, "FastStack keeps four spare entries (kStackFast + 1 rows) above its usable depth");
 constexpr int kStackTotal = 192;
 constexpr int kStackSlowDev = kStackTotal - kStackFast;   // global overflow entries per thread
 constexpr int kRedoGrid = 64;          // blocks of k_trace_redo (rays that overflowed the LDS-only stack of k_trace)

@@ -35,9 +35,9 @@ template <bool ANY, int MODE>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
                                                        TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count,
                                                        int refill_min, int inner_min, unsigned long long* stats) {
-    __shared__ int32_t lds[kStackFast + 1][kPathBlock];     // 20 x 1 KB x 8 blocks = the CU's 160 KB; the top three rows are FastStack's spare entries
+    __shared__ int32_t lds[kStackFast + 1][kPathBlock];     // 20 x 1 KB x 8 blocks = the CU's 160 KB; the top FOUR rows are FastStack's spare entries
     FastStack st;
-    st.base = (drt::FastPtr)&lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast - 2; st.reset(); st.overflow = false;
+    st.base = (drt::FastPtr)&lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast - 3; st.reset(); st.overflow = false;
     const unsigned n = *n_ptr;
     const int lane = threadIdx.x & 63;
     // Work assignment without atomics, XCD-aware: workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD

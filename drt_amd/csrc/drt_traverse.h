@@ -55,21 +55,21 @@ struct Stack {
 constexpr int kStackSlow = 192;
 
 // Stack of the persistent GPU traversal: fast memory only, no overflow area and therefore no
-// divergent slow path (and no flat loads) in the hot loop.  A node visit pushes at most three entries, so
-// three spare entries above `depth` take the stores of a visit that starts with a legal stack (sp <= depth)
-// without a bound check per push (two VALU instructions per push: address, predicated increment); ONE check
-// per visit (`after_pushes`) sets `overflow`, the kernel then abandons that ray and a second pass re-traces
-// it with the spilling Stack above.
+// divergent slow path (and no flat loads) in the hot loop.  A closest-hit visit issues FOUR stores (one per child slot, the stack
+// pointer advancing only past the hit children that are not the nearest: at most three), so four spare entries above `depth` take the
+// stores of a visit that starts with a legal stack (sp <= depth: the last store lands at most at depth + 3) without a bound check
+// per push (two VALU instructions per push: predicated increment, address = the stack pointer itself); ONE check per visit
+// (`after_pushes`) sets `overflow`, the kernel then abandons that ray and a second pass re-traces it with the spilling Stack above.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) int32_t* FastPtr;      // 32-bit LDS address arithmetic
 #else
 typedef int32_t* FastPtr;
 #endif
 struct FastStack {
-    FastPtr base;       // &fast_mem[lane]; entry k at base[k * stride]; depth + 3 entries allocated
+    FastPtr base;       // &fast_mem[lane]; entry k at base[k * stride]; depth + 4 entries allocated
     FastPtr top;        // next free entry (the stack pointer IS the address: no shift-and-or per push)
     int stride;
-    int depth;          // usable entries [0, depth); entries depth .. depth + 2 only ever hold the pushes of an overflowing visit
+    int depth;          // usable entries [0, depth); entries depth .. depth + 3 only ever hold the stores of an overflowing visit
     bool overflow;
     DRT_HD void reset() {
         top = base;
