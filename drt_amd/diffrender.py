@@ -138,7 +138,7 @@ EAGER_LOSS_GRAD = True
 # kernels run, which leave the memory system idle -- instead of beside the next call's traversal.  The tensors a call returns are its own
 # fresh allocations either way (nothing is ever handed out twice); the price is one extra out_ori + mask (27 B per ray) held between calls.
 PREFILL_NEXT = os.environ.get("DRT_PREFILL_NEXT", "1") != "0"
-PREFILL_MIN_RAYS = 1 << 25          # below this the two extra allocations and calls cost the host more than the earlier fill saves the GPU (18 views x 1024^2: +3 %, 9 views: +4 %)
+PREFILL_MIN_RAYS = int(os.environ.get("DRT_PREFILL_MIN_RAYS", 1 << 25))          # below this the two extra allocations and calls cost the host more than the earlier fill saves the GPU (18 views x 1024^2: +3 %, 9 views: +4 %)
 
 
 class _GradLink:
