@@ -61,6 +61,7 @@ SIGNATURES = {
     "drt_profile_select": (_c.c_int, [_P, _c.c_uint32]),
     "drt_profile_read": (_c.c_int, [_P, _P, _P, _P]),
     "drt_profile_trace_stats": (_c.c_int, [_P, _P]),
+    "drt_check_violations": (_c.c_int, [_P]),
 }
 
 _lib = None

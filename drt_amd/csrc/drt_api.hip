@@ -10,6 +10,18 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Overflow area of the one-thread-per-item queries (B1's redo pass, closest point, silhouette probes): [blocks * kTraceBlock *
+// kStackSlowDev] with blocks = the largest grid that indexes it.  0.35 GB that only those queries ever touch (and only on overflow), so
+// it is allocated by the first of them, not by drt_create: a scene that only renders (a ground-truth scene, most tests) never pays.
+int ensure_slow_stack(drt_scene* s) {
+    if (s->slow_stack) return DRT_OK;
+    int blocks = s->grid_trace;
+    if (blocks < 4 * s->n_cu) blocks = 4 * s->n_cu;
+    if (blocks < kRedoGrid) blocks = kRedoGrid;
+    HIP_TRY(hipMalloc(&s->slow_stack, sizeof(int32_t) * (size_t)blocks * kTraceBlock * kStackSlowDev));
+    return DRT_OK;
+}
+
 extern "C" {
 
 const char* drt_last_error(void) { return g_err; }
@@ -25,7 +37,6 @@ int drt_create(int device, drt_scene_t** out) {
     if (!s) return fail(DRT_E_NOMEM, "host allocation failed");
     s->device = device;
     hipError_t e = hipMalloc(&s->params, sizeof(BuildParams));
-    if (e == hipSuccess) e = hipMalloc(&s->slow_stack, sizeof(int32_t) * (size_t)kTraceGridMax * kTraceBlock * kStackSlowDev);
     if (e == hipSuccess) e = hipMalloc(&s->scratch, sizeof(unsigned long long) * 8);
     if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
@@ -151,6 +162,19 @@ int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int6
     for (int k = 0; k < 12; ++k) s->trace_stats[k] = (int64_t)h[kProfStages + k];
     HIP_TRY(hipMemset(s->prof_counts, 0, sizeof(h)));
     s->prof_used = 0;
+    return DRT_OK;
+}
+
+int drt_check_violations(int64_t* out4) {
+    if (!out4) return fail(DRT_E_INVALID, "null pointer argument");
+#if defined(DRT_CHECK)
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long tot[4] = {0, 0, 0, 0};
+    if (check_counters_pipeline(tot) || check_counters_trace(tot)) return fail(DRT_E_HIP, "could not read the check counters");
+    for (int k = 0; k < 4; ++k) out4[k] = (int64_t)tot[k];
+#else
+    for (int k = 0; k < 4; ++k) out4[k] = -1;
+#endif
     return DRT_OK;
 }
 

@@ -127,7 +127,10 @@ struct RasterIn {
     uint32_t* zmask;
     int32_t* gen_list;               // R0 slots that still need k_trace (count in p.count[3])
     int img_w, img_h;
+    int defer;                       // DRT_GRID_ALL_VERIFIED: the tree may still be under construction during the cull stage -- no top-box test, and a
+                                     // ray outside the grid is listed with face = kFacePending for k_gen_late (after the build has been waited for)
 };
+constexpr int32_t kFacePending = -2; // R0 entry whose primary hit is still to be found by the tree (k_shade1 leaves it alone)
 
 struct CullShared {
     unsigned tmp[kPathWaves + 1];
@@ -223,7 +226,7 @@ __device__ __forceinline__ void cull_patch(unsigned patch, bool prefilled, CullS
                     cand = key != kRasterEmpty;
                     face = (int32_t)(uint32_t)key;
                 } else {
-                    cand = n_tris > 0 && hits_top_boxes(nodes, o, d);
+                    cand = n_tris > 0 && (rz.defer || hits_top_boxes(nodes, o, d));
                     generic = cand;
                 }
             } else if (raster && rz.mode == DRT_GRID_ESTABLISH) {
@@ -263,7 +266,7 @@ __device__ __forceinline__ void cull_patch(unsigned patch, bool prefilled, CullS
         }
         if (slot >= 0) {
             p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d);
-            if (raster) p.r0.face[slot] = face;
+            if (raster) p.r0.face[slot] = generic && rz.defer ? kFacePending : face;
         }
         if (raster && __syncthreads_or(generic ? 1 : 0)) {       // rare: rays outside the grid model
             const int g = block_push(generic, &p.count[3], s_tmp);
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* 
         if (k < n0) {
             i = p.r0.idx[k];
             const int32_t f1 = p.r0.face[k];
-            face1[i] = f1;
+            if (f1 != kFacePending) face1[i] = f1;
             if (f1 >= 0) {
                 d3 v0, v1, v2;
                 int32_t vid[3];
@@ -416,11 +419,52 @@ __global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* 
                 ok = !b.tir;
                 o2 = to_f32(b.new_o); d2 = to_f32(b.wt);
             }
-            if (!ok && !FUSED) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
+            if (!ok && !FUSED && f1 != kFacePending) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
         }
         stage_push(stage, ok, (int32_t)i, o2, d2, p.r1, &p.count[1]);
     }
     stage_flush(stage, p.r1, &p.count[1]);
+}
+
+// DRT_GRID_ALL_VERIFIED promised that no ray would need the tree for its primary hit, so nothing traced the rays outside the grid
+// before k_shade1 -- but an image can still lose that status INSIDE a call: k_raster demotes it when a triangle reaches the camera
+// plane (vertices move every iteration) or its large-triangle list overflows, k_check_views when the rays changed behind the cache's
+// back.  k_cull_listed then lists every ray of that image in gen_list with face = kFacePending; this kernel -- a few blocks, one thread
+// per ray, normally nothing to do -- finds their primary hits in the tree once the build has been waited for, does bounce #1 like
+// k_shade1 and appends the refracted rays to R1, in front of the second traversal.  Rare path: simple, not fast.
+template <bool FUSED>
+__global__ void __launch_bounds__(kTraceBlock) k_gen_late(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                          double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                          int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p,
+                                                          const int32_t* __restrict__ gen_list, bool prefilled) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    const unsigned n = p.count[3];
+    if (n == 0) return;
+    Stack st = make_stack(lds, c.tc);
+    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
+        const int32_t slot = gen_list[k];
+        if (p.r0.face[slot] != kFacePending) continue;
+        const int64_t i = p.r0.idx[slot];
+        const float* e = p.r0.ray + 6 * (int64_t)slot;
+        const Hit h = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st);
+        p.r0.face[slot] = h.face;
+        face1[i] = h.face;
+        bool ok = false;
+        if (h.face >= 0) {
+            d3 v0, v1, v2;
+            int32_t vid[3];
+            Bounce b;
+            load_tri64(c, h.face, v0, v1, v2, vid);
+            bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+            ok = !b.tir;
+            if (ok) {
+                const unsigned s1 = atomicAdd(&p.count[1], 1u);
+                p.r1.idx[s1] = (int32_t)i;
+                store_ray32(p.r1.ray, (int)s1, to_f32(b.new_o), to_f32(b.wt));
+            }
+        }
+        if (!ok && !FUSED) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
+    }
 }
 
 // R1 -> R2: second hit -> float64 bounces #1 and #2 -> provisional exit ray
@@ -964,7 +1008,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     grid_mode &= 3;
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
-    RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
+    RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0};
     bool late_fill = false;
     // the scene's build stream is idle once the tree is built (before the cull stage): it carries the late fills, so that the
     // library stays within the four hardware queues a process gets by default (more streams would share queues with these)
@@ -997,7 +1041,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         StageTimer t(s, st, kStageRaster);
         rc = launch_raster(s, w, st, o, d, n_views, tile_w, tile_h, grid_mode == DRT_GRID_TRUST ? grid_cache : nullptr);
         if (rc) return rc;
-        rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h};
+        rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h, all_verified ? 1 : 0};
     }
     // The cull stage reads the tree for rays outside the grid (top-box test, k_trace on the listed slots): wait for the build (it ran
     // beside the projection pass above).  When the caller vouches that every ray of every image is a verified grid ray, nothing before
@@ -1031,7 +1075,8 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
     { StageTimer t(s, st, kStageTrace1);
       if (rz.views && all_verified) {
-          // every ray of every image is a verified grid ray (the caller read that off the cache): nothing was listed
+          // every ray of every image is a verified grid ray (the caller read that off the cache): normally nothing was listed, and what
+          // a demotion inside this call did list waits for k_gen_late below
       } else if (rz.views) {       // only the R0 slots listed by k_cull (rays that are not grid rays)
           const TraceOut out{p.r0.face, nullptr, nullptr, w.gen_list};
           k_trace<false, 2><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 3, out, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
@@ -1042,7 +1087,11 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
       } }
     { StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill); }
-    if (tree_late) { int rc = wait_build(s, st); if (rc) return rc; }
+    if (tree_late) {
+        int rc = wait_build(s, st); if (rc) return rc;
+        StageTimer t(s, st, kStageTrace1);
+        k_gen_late<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, w.gen_list, late_fill);
+    }
     { StageTimer t(s, st, kStageTrace2);
       k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
       k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, TraceOut{p.r1.face, nullptr, nullptr, nullptr}); }
@@ -1082,6 +1131,9 @@ static PathCtx sub_ctx(const drt_scene* s, const drt_scene::Sub& w, const double
     pc.tc.slow_stack = w.slow_stack;     // concurrent kernels must not share overflow stacks
     return pc;
 }
+#if defined(DRT_CHECK)
+int check_counters_pipeline(unsigned long long* out4) { return read_check_counters(out4); }
+#endif
 int pipeline_blocks_per_cu() {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, 0>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
@@ -1106,18 +1158,24 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, false); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
-    int rc = fork_streams(s, st, pl.streams);
-    if (rc) return rc;
     grid_mode &= ~kIntMask;
     if (s->n_prefill) {       // buffers zeroed ahead of time (drt_prefill_zero): which of this call's outputs are they?
+        int matched = 0;
         for (int k = 0; k < s->n_prefill; ++k) {
             const drt_scene::Prefill& f = s->prefill[k];
+            const int before = grid_mode;
             if (f.ptr == d_out_ori && f.bytes == (int64_t)sizeof(double) * 3 * n_rays) grid_mode |= kIntPreOri;
             if (f.ptr == d_out_dir && f.bytes == (int64_t)sizeof(double) * 3 * n_rays) grid_mode |= kIntPreDir;
             if (f.ptr == d_mask && f.bytes == 3 * n_rays) grid_mode |= kIntPreMask;
+            matched += grid_mode != before;
         }
+        // an entry that is none of this call's outputs is dropped here: whoever writes that buffer next no longer knows about its
+        // zeroing, so the zeroing is ordered in front of everything this stream does from now on
+        if (matched != s->n_prefill) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
         s->n_prefill = 0;     // one shot (launch_chunk waits for prefill_done in front of the first kernel that writes those outputs)
     }
+    int rc = fork_streams(s, st, pl.streams);
+    if (rc) return rc;
     for (int j = 0; j < pl.count; ++j) {
         drt_scene::Sub& w = s->sub[j % pl.streams];
         const int64_t b = j * pl.size;
@@ -1279,8 +1337,13 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     hipStream_t st = (hipStream_t)stream;
     const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true); if (rc) return rc; }
+    if (s->n_prefill) {            // buffers zeroed ahead of time for a drt_render_forward that did not come: forgotten, their zeroing ordered in front of this stream's future
+        HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
+        s->n_prefill = 0;
+    }
     int rc = fork_streams(s, st, pl.streams);
     if (rc) return rc;
+    grid_mode &= ~kIntMask;        // (internal bits: this entry point has no dense outputs that could have been zeroed ahead of time)
     for (int j = 0; j < pl.count; ++j) {
         drt_scene::Sub& w = s->sub[j % pl.streams];
         const int64_t b = j * pl.size;

@@ -30,6 +30,46 @@ __global__ void __launch_bounds__(64) k_fit_views(const double* __restrict__ ori
     }
 }
 
+// DRT_GRID_TRUST: the models come from the caller's cache -- but a trusted image is not taken on faith entirely: the 8x8 lattice of
+// its rays (the 64 rays k_fit_views samples) is read again and checked against the cached model, so that ray tensors that were
+// replaced wholesale behind the cache's back (a write through `.data` or a raw pointer, which no version counter sees) are caught for
+// the price of 64 ray loads per image.  An image that fails is re-fitted from its corner rays on the spot and loses `all` -- in the
+// working copy AND in the cache -- so that every one of its rays is verified individually (k_cull_listed's general path), in this
+// call and in every later one, exactly as in a call without a cache.
+__global__ void __launch_bounds__(64) k_check_views(const double* __restrict__ origin, const double* __restrict__ dir, int w, int h,
+                                                    ViewModel* __restrict__ cache, ViewModel* __restrict__ views) {
+    __shared__ ViewModel vm;
+    const int64_t base = (int64_t)blockIdx.x * w * h;
+    if (threadIdx.x == 0) vm = cache[blockIdx.x];
+    __syncthreads();
+    const bool trusted = vm.ok && vm.all;              // (k_store_models stores ok == all)
+    const int sx = (int)(threadIdx.x & 7), sy = (int)(threadIdx.x >> 3);
+    const int x = (int)(((int64_t)(w - 1) * sx) / 7), y = (int)(((int64_t)(h - 1) * sy) / 7);
+    const int64_t i = base + (int64_t)y * w + x;
+    bool good = trusted && view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)y);
+    if (__ballot(good) == ~0ull) {                     // wave-uniform: the usual case
+        if (threadIdx.x == 0) views[blockIdx.x] = vm;
+        return;
+    }
+    // not (or no longer) a trusted grid: fit it like a call without a cache would
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t i00 = base, iW0 = base + (w - 1), i0H = base + (int64_t)(h - 1) * w, iWH = i0H + (w - 1);
+        if (fit_view_model(load_d3(origin, i00), load_d3(dir, i00), load_d3(dir, iW0), load_d3(dir, i0H), load_d3(dir, iWH),
+                           (double)(w - 1), (double)(h - 1), vm))
+            vm.ok = 1;
+    }
+    __syncthreads();
+    good = vm.ok != 0 && view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)y);
+    const bool all_good = __ballot(good) == ~0ull;
+    if (threadIdx.x == 0) {
+        vm.ok = all_good ? 1 : 0;
+        vm.all = 0;                                    // never trusted again: per-ray verification from now on
+        views[blockIdx.x] = vm;
+        if (trusted) { cache[blockIdx.x].ok = 0; cache[blockIdx.x].all = 0; }
+    }
+}
+
 // Test one (triangle, pixel) pair and fold a hit into the pixel's key.  The plain read of the current key may be stale
 // (the L1 is not coherent with the atomics at L2) but keys only ever decrease, so a stale value is >= the true one:
 // skipping when the new key is not smaller than what was read can never drop a winner.
@@ -177,10 +217,10 @@ int ensure_raster(drt_scene* s, drt_scene::Sub& w, int64_t n_rays, int n_views, 
 
 // Fit the image models and rasterise every triangle into the key buffer of `w` (rays [0, n_views * w * h) of the sub-batch).
 int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih,
-                  const ViewModel* trusted) {
+                  ViewModel* trusted) {
     const int n = (int)s->n_faces;
     HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
-    if (trusted) HIP_TRY(hipMemcpyAsync(w.vmodel, trusted, sizeof(ViewModel) * n_views, hipMemcpyDeviceToDevice, st));   // models of an earlier call
+    if (trusted) k_check_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, trusted, w.vmodel);   // models of an earlier call, lattice re-checked
     else k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
     if (n > 0) {
         for (int pass = 0; pass < 2; ++pass) {

@@ -91,7 +91,7 @@ struct drt_scene {
     int32_t *parent_inner = nullptr, *parent_leaf = nullptr;
     uint32_t* flags = nullptr;
     BuildParams* params = nullptr;
-    int32_t* slow_stack = nullptr; // [kTraceGridMax * kTraceBlock * kStackSlowDev] (B1 queries and edge probes)
+    int32_t* slow_stack = nullptr; // [max(grid_trace, 4 n_cu, kRedoGrid) * kTraceBlock * kStackSlowDev] (B1 queries, closest point, edge probes): ensure_slow_stack
     unsigned long long* scratch = nullptr;  // small counters
     int32_t *b1_list = nullptr, *b1_redo = nullptr;   // B1 queries (drt_intersect*): candidate ray numbers, redo list
     unsigned* b1_count = nullptr;           // [0] candidates, [1] redo entries
@@ -171,7 +171,13 @@ int pipeline_blocks_per_cu();
 // defined in drt_raster.hip
 int ensure_raster(drt_scene* s, drt_scene::Sub& w, int64_t n_rays, int n_views, hipStream_t st);
 int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double* d_origin, const double* d_dir, int n_views, int iw, int ih,
-                  const ViewModel* trusted);
+                  ViewModel* trusted);
+
+// defined in drt_api.hip
+int ensure_slow_stack(drt_scene* s);
+// -DDRT_CHECK=1: the stack-invariant counters of the two translation units that instantiate the traversal kernels
+int check_counters_pipeline(unsigned long long* out4);
+int check_counters_trace(unsigned long long* out4);
 
 // defined in drt_build.hip
 void scene_free_mesh(drt_scene* s);

@@ -38,15 +38,19 @@ TopoWork carve(void* ws, int64_t n_faces) {
 }  // namespace
 
 // Row r = 3 f + j is the directed edge (F[f][j], F[f][(j + 1) % 3]) -- trimesh's `edges` order (faces[:, [0,1,1,2,2,0]]).
-__global__ void __launch_bounds__(256) k_edge_rows(const int64_t* __restrict__ faces, int64_t n_rows, const double* __restrict__ verts,
+__global__ void __launch_bounds__(256) k_edge_rows(const int64_t* __restrict__ faces, int64_t n_rows, const double* __restrict__ verts, int64_t n_verts,
                                                    uint32_t* __restrict__ key_hi, uint32_t* __restrict__ key_lo, uint32_t* __restrict__ idx,
-                                                   double* __restrict__ partial) {
+                                                   double* __restrict__ partial, int32_t* status) {
     __shared__ double red[4];
     double acc = 0.0;
     for (int64_t r = blockIdx.x * 256ll + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
         const int64_t f = r / 3;
         const int j = (int)(r - 3 * f);
-        const int64_t a = faces[3 * f + j], b = faces[3 * f + (j == 2 ? 0 : j + 1)];
+        int64_t a = faces[3 * f + j], b = faces[3 * f + (j == 2 ? 0 : j + 1)];
+        if (a < 0 || a >= n_verts || b < 0 || b >= n_verts) {     // a face list that points outside the vertex array: reported (status bit 2),
+            atomicOr(status, 2);                                  // never dereferenced -- torch's indexing, which this replaces, raises too
+            a = b = 0;
+        }
         key_lo[r] = (uint32_t)(a < b ? a : b);
         key_hi[r] = (uint32_t)(a < b ? b : a);
         idx[r] = (uint32_t)r;
@@ -139,9 +143,10 @@ int drt_edge_tables(const int64_t* d_faces, int64_t n_faces, const double* d_ver
     const int64_t rows = 3 * n_faces, n_edges = rows / 2;
     if (rows == 0) { HIP_TRY(hipMemsetAsync(d_mean_len, 0, sizeof(double), st)); return DRT_OK; }
     if (!d_faces || !d_verts || !d_workspace || !d_edges || !d_e2f) return fail(DRT_E_INVALID, "null pointer argument");
+    if (n_verts == 0) return fail(DRT_E_INVALID, "faces without vertices");
     const TopoWork w = carve(d_workspace, n_faces);
     const int blocks = (int)((rows + 255) / 256 < kPartials ? (rows + 255) / 256 : kPartials);
-    k_edge_rows<<<blocks, 256, 0, st>>>(d_faces, rows, d_verts, w.keys[0], w.lo, w.idx[0], w.partial);
+    k_edge_rows<<<blocks, 256, 0, st>>>(d_faces, rows, d_verts, n_verts, w.keys[0], w.lo, w.idx[0], w.partial, d_status);
     int bits = 1;
     while (((int64_t)1 << bits) < n_verts) ++bits;
     int cur = 0;

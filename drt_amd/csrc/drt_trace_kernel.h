@@ -4,6 +4,24 @@
 #pragma once
 #include "drt_device.h"
 
+// -DDRT_CHECK=1: violation counters of this translation unit's traversal kernels (see drt_traverse.h), [kCheck*]
+#if defined(DRT_CHECK)
+static __device__ unsigned g_drt_check[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline void drt::drt_check_fail(int what) { atomicAdd(&g_drt_check[what & 3], 1u); }
+#endif
+static inline int read_check_counters(unsigned long long* out4) {      // host: adds this unit's counters to out4
+    unsigned h[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_drt_check), sizeof(h)) != hipSuccess) return DRT_E_HIP;
+    for (int k = 0; k < 4; ++k) out4[k] += h[k];
+    return DRT_OK;
+}
+constexpr int kGuardRows = 2;
+constexpr int32_t kGuardPoison = 0x5A5A5A5A;
+#else
+constexpr int kGuardRows = 0;
+#endif
+
 // Where a finished ray's result goes.  Pipeline: out.face[list slot].  B1 (`idx` non-null): the list holds ray numbers;
 // the float32 ray is read from rays[idx[slot]] and T / ID (closest) or the hit flag (any) are written at that ray number.
 struct TraceOut {
@@ -35,9 +53,12 @@ template <bool ANY, int MODE>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
                                                        TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count,
                                                        int refill_min, int inner_min, unsigned long long* stats) {
-    __shared__ int32_t lds[kStackFast + 1][kPathBlock];     // 20 x 1 KB x 8 blocks = the CU's 160 KB; the top FOUR rows are FastStack's spare entries
+    __shared__ int32_t lds[kStackFast + 1 + kGuardRows][kPathBlock];     // 20 x 1 KB x 8 blocks = the CU's 160 KB; the top FOUR rows are FastStack's spare entries
     FastStack st;
     st.base = (drt::FastPtr)&lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast - 3; st.reset(); st.overflow = false;
+#if defined(DRT_CHECK)
+    for (int g = 0; g < kGuardRows; ++g) lds[kStackFast + 1 + g][threadIdx.x] = kGuardPoison;     // (per-lane columns: no barrier needed)
+#endif
     const unsigned n = *n_ptr;
     const int lane = threadIdx.x & 63;
     // Work assignment without atomics, XCD-aware: workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
@@ -109,6 +130,9 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             }
         }
     }
+#if defined(DRT_CHECK)
+    for (int g = 0; g < kGuardRows; ++g) DRT_DEV_ASSERT(lds[kStackFast + 1 + g][threadIdx.x] == kGuardPoison, drt::kCheckGuardRow);
+#endif
     if (stats && lane == 0 && wave_steps) {
         atomicAdd(stats + 0, wave_steps);
         atomicAdd(stats + 1, lane_steps);

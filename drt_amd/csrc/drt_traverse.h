@@ -65,6 +65,17 @@ typedef __attribute__((address_space(3))) int32_t* FastPtr;      // 32-bit LDS a
 #else
 typedef int32_t* FastPtr;
 #endif
+// -DDRT_CHECK=1 (a debug build of the library, tests/test_gpu_parity.py::test_lds_stack_invariants_hold_in_a_checked_build): the
+// argument above -- "a visit that starts with a legal stack stores at most at row depth + 3" -- is ASSERTED at every store, pops are
+// checked against underflow, and k_trace surrounds its stack rows with poisoned guard rows it validates before it exits.  Violations
+// are counted on the device (drt_trace_kernel.h) and read through drt_check_violations().
+#if defined(DRT_CHECK) && defined(__HIP_DEVICE_COMPILE__)
+__device__ void drt_check_fail(int what);
+#define DRT_DEV_ASSERT(cond, what) do { if (!(cond)) drt_check_fail(what); } while (0)
+#else
+#define DRT_DEV_ASSERT(cond, what) ((void)0)
+#endif
+enum { kCheckPushRow = 0, kCheckPopUnderflow = 1, kCheckGuardRow = 2, kCheckVisitStart = 3 };
 struct FastStack {
     FastPtr base;       // &fast_mem[lane]; entry k at base[k * stride]; depth + 4 entries allocated
     FastPtr top;        // next free entry (the stack pointer IS the address: no shift-and-or per push)
@@ -78,11 +89,13 @@ struct FastStack {
 #endif
     }
     DRT_HD void push_if(int32_t v, bool pred) {
+        DRT_DEV_ASSERT(top < base + (depth + 4) * stride, kCheckPushRow);        // the store lands inside the rows this lane owns
         *top = v;
         top += pred ? stride : 0;
     }
     DRT_HD void after_pushes() { overflow |= top > base + depth * stride; }
     DRT_HD int32_t pop() {
+        DRT_DEV_ASSERT(top > base, kCheckPopUnderflow);
         top -= stride;
         return *top;
     }
@@ -181,8 +194,12 @@ DRT_HD void slab_node4q(F4 c0, F4 c1, F4 c2, f3 inv, f3 oi, bool px, bool py, bo
 // Visit the inner node s.cur (>= 0).  Returns true when the ray is finished.  ANY: an occlusion query visits the same set
 // of nodes in any order when it misses (nineteen exit rays out of twenty) and needs no face id when it hits, so its children
 // are not sorted: the first hit child is next, the others are pushed as they come -- a third fewer instructions per visit.
+template <class STACK> DRT_HD void trav_check_visit_start(const STACK&) {}
+DRT_HD void trav_check_visit_start(const FastStack& st) { DRT_DEV_ASSERT(st.overflow || st.top <= st.base + st.depth * st.stride, kCheckVisitStart); (void)st; }
+
 template <bool ANY = false, class STACK>
 DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st) {
+    trav_check_visit_start(st);          // (a no-op unless -DDRT_CHECK: a visit must start with a legal stack for its <= 4 unchecked stores)
     const F4* np = reinterpret_cast<const F4*>(nodes + s.cur);
     const F4 q0 = np[0], q1 = np[1], q2 = np[2];
     struct alignas(16) I4 { int32_t x, y, z, w; };

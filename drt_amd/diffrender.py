@@ -355,6 +355,14 @@ def ray_loss(out_ori, out_dir, mask, screen_pixel, valid):
     link = getattr(out_dir, "_drt_link", None) if SPARSE_LOSS_GRAD else None
     if link is not None and not (out_dir.requires_grad and isinstance(out_dir.grad_fn, _RenderTransparent._backward_cls)):
         link = None
+    if link is not None:
+        # The row-list hand-off RECOMPUTES out_ori / out_dir of the listed rays from the forward's stored path, and lists rays by the
+        # forward's own mask: it is only the gradient of THIS call when all three tensors are the forward's own, untouched ones.  A
+        # different or modified out_ori / mask (extra rows set, a shifted origin) takes the dense gradient, which reads what was passed.
+        own = (link.mask is not None and link.mask() is mask and mask._version == 0
+               and link.out_ori is not None and link.out_ori() is out_ori and out_ori._version == 0 and out_dir._version == 0)
+        if not own:
+            link = None
     return _RayLoss.apply(out_ori, out_dir, mask, screen_pixel, valid, link)
 
 
@@ -383,6 +391,8 @@ def edge_tables(F, V, want_rows=False):
                                               rows.data_ptr(), out.data_ptr(), out[1:].data_ptr(), _stream()))
     host = out.cpu()
     status = int(host[1:].view(torch.int32)[0])
+    if status & 2:
+        raise IndexError(f"faces index vertices outside [0, {n_v}) (torch's indexing, which the reference uses here, raises as well)")
     assert status == 0, "mesh is not watertight: every edge must be shared by exactly two faces"
     mean_len = float(host[0])
     return (Edges, E2F, mean_len, rows) if want_rows else (Edges, E2F, mean_len)

@@ -90,9 +90,12 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
  *      grid_mode, d_grid_cache: DRT_GRID_NONE / NULL, or a caller-owned device buffer of DRT_GRID_CACHE_BYTES per image that
  *      belongs to THIS (origin, dir) pair with THIS tile_w x tile_h.  DRT_GRID_ESTABLISH: the call fits and verifies as
  *      above and records, per image, the model and whether every ray verified.  DRT_GRID_TRUST: the caller guarantees the
- *      ray arrays have not changed since the establishing call; images recorded as all-verified are then neither
- *      re-fitted nor re-verified, and rays of pixels that no projected triangle touches are not even loaded.  (The
- *      Python layer ties the buffer to the tensor objects and their version counters.) */
+ *      ray arrays have not changed since the establishing call; images recorded as all-verified are then not re-fitted,
+ *      only the 8x8 lattice of 64 sample rays per image is re-verified against the recorded model (an image that fails is
+ *      re-fitted, verified ray by ray like in a call without a cache, and marked untrusted IN THE CACHE for good), and rays of
+ *      pixels that no projected triangle touches are not even loaded.  The lattice check catches ray arrays that were replaced
+ *      wholesale; a change confined to rays off the lattice is the caller's responsibility.  (The Python layer ties the buffer
+ *      to the tensor objects and their version counters.) */
 #define DRT_GRID_NONE 0
 #define DRT_GRID_ESTABLISH 1
 #define DRT_GRID_TRUST 2
@@ -102,7 +105,11 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
 #define DRT_GRID_SPARSE_FACES 16
 /* OR-ed into DRT_GRID_TRUST: the caller has read the cache back after the establishing call and EVERY image in it is recorded
  * as a pinhole grid in all of its rays (int32 `ok` and `all` at byte offsets 96 and 100 of each DRT_GRID_CACHE_BYTES record
- * both non-zero).  No ray can then need the tree for its primary hit, and the two launches that serve such rays are not issued. */
+ * both non-zero).  Normally no ray then needs the tree for its primary hit: the launches that serve such rays in front of the
+ * first shading stage are not issued and the call waits for the (asynchronous) tree build only in front of the second traversal.
+ * A performance hint, not a promise the results depend on: an image can still lose its status inside the call (a triangle reaches
+ * its camera plane, its large-triangle list overflows, its rays fail the lattice re-check below); its rays are then traced through
+ * the tree by a small fallback launch behind the build (csrc/drt_pipeline.hip, k_gen_late). */
 #define DRT_GRID_ALL_VERIFIED 32
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin,
                        const double* d_dir, int64_t n_rays, double ior_int, double ior_ext,
@@ -268,8 +275,9 @@ int drt_limit_sgd_step(double* d_param, double* d_grad, double* d_buf, int64_t n
  * drt_edge_tables: d_faces int64 [F,3], d_verts float64 [V,3] -> d_edges int64 [3F/2,2] (ascending by (min, max) vertex),
  * d_e2f int64 [3F/2,2,3] (vertex ids of the two faces of every edge; first the face with the lower directed-edge row),
  * d_row2edge int32 [3F] (nullable: unique-edge id of directed edge 3f+j = (F[f][j], F[f][(j+1)%3])), *d_mean_len float64
- * (mean length of the 3F directed edges), *d_status int32: 0, or 1 when some edge is not shared by exactly two faces (the
- * mesh is not watertight, DiffRender.py:305; the tables are then unspecified).  d_workspace: drt_edge_tables_workspace(F)
+ * (mean length of the 3F directed edges), *d_status int32: 0; bit 0 set when some edge is not shared by exactly two faces (the
+ * mesh is not watertight, DiffRender.py:305), bit 1 when a face indexes a vertex outside [0, V) (never dereferenced); the tables
+ * are then unspecified.  d_workspace: drt_edge_tables_workspace(F)
  * bytes of device memory.  Everything is enqueued on `stream`; nothing synchronises for an even 3F. */
 int64_t drt_edge_tables_workspace(int64_t n_faces);
 int drt_edge_tables(const int64_t* d_faces, int64_t n_faces, const double* d_verts, int64_t n_verts,
@@ -306,6 +314,12 @@ int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int6
  * k_trace stages: node visits summed over wavefronts ("wave-steps"), over lanes ("lane-steps";
  * lane-steps / (64 * wave-steps) = SIMD lane utilisation), lane refills, longest wavefront. */
 int drt_profile_trace_stats(drt_scene_t* s, int64_t* out12);
+
+/* Debug builds (hipcc -DDRT_CHECK=1): the persistent traversal kernels assert the invariants of their bound-check-free LDS stack
+ * (csrc/drt_traverse.h FastStack) and count violations on the device.  out4 = {stores above a lane's rows, pops of an empty stack,
+ * overwritten guard rows, visits that started with an illegal stack} since the library was loaded (host-synchronising); every entry
+ * is -1 in a build without the checks. */
+int drt_check_violations(int64_t* out4);
 
 #ifdef __cplusplus
 }

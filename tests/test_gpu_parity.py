@@ -449,6 +449,29 @@ def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("flags", [("-DDRT_CHECK=1",), ("-DDRT_CHECK=1", "-DDRT_STACK_FAST=5")], ids=["default-stack", "five-entry-stack"])
+def test_lds_stack_invariants_hold_in_a_checked_build(tmp_path, flags):
+    """k_trace's LDS stack has no bound check per push: "a visit that starts with a legal stack stores at most three rows above it"
+    (drt_traverse.h FastStack).  A -DDRT_CHECK=1 build ASSERTS that at every store, checks pops against underflow and validates
+    poisoned guard rows around each block's stack; the golden, full-size brute-force and monkey (184 k triangles, deepest tree)
+    comparisons run against that build in a subprocess, which ends by reading the violation counters: all zero.  Once with the
+    default stack and once with a five-entry one (two usable rows + the spare ones: overflows on most rays, so the stores of
+    OVERFLOWING visits are what gets checked)."""
+    import subprocess
+    import sys
+    from drt_amd import build
+    so = str(tmp_path / "libdrt_hip_check.so")
+    build.build(force=True, out=so, extra_flags=flags)
+    env = dict(os.environ, DRT_HIP_LIB=so, DRT_EXPECT_CHECKED="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = ("test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or "
+           "test_silhouette_branch_vs_golden or test_two_optimisation_steps or test_zz_check_counters")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_configs.py"), os.path.join(here, "test_gpu_zz_check.py"),
+                        "-m", "gpu", "-x", "-q", "-k", sel], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "test_zz_check_counters" not in r.stdout.split("short test summary")[-1]
+
+
 def test_closest_point_and_hausdorff(Render, hand, horse50k):
     """drt_closest_point: oracle brute force on the hand; size-independent properties on the 50k mesh;
     the acceptance metric of drt_amd.metrics on a displaced copy."""
@@ -804,6 +827,26 @@ def test_eager_loss_gradient_equals_the_two_pass_form(Render, hand):
     with torch.no_grad():                                           # no gradient asked for: the cheap loss pass, no stash
         oo, od, mk = scene.render_transparent(o, d)
         assert float(Render.ray_loss(oo, od, mk, sp, valid)) == pytest.approx(la, rel=1e-12)
+    # a caller's OWN out_ori / mask (shifted origins, rows masked out, a row set that has no path): loss and gradient are those of the
+    # tensors that were passed -- the forward's stored path must not be substituted for them
+    V = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    oo, od, mk = scene.render_transparent(o, d)
+    oo2 = oo.detach() + 0.5
+    mk2 = mk.clone()
+    on = torch.nonzero(mk[:, 0]).squeeze(1)
+    off = torch.nonzero(~mk[:, 0]).squeeze(1)
+    mk2[on[::3]] = False
+    mk2[off[:5]] = True                                             # rows without a completed path: od is zero there, no gradient reaches the mesh
+    node = Render.ray_loss(oo2, od, mk2, sp, valid)
+    gv, = torch.autograd.grad(node, V, retain_graph=True)
+    sel = valid & mk2[:, 0]
+    tgt = sp[sel] - oo2[sel]
+    tgt = tgt / tgt.norm(dim=1, keepdim=True)
+    ref_loss = ((od[sel] - tgt) ** 2).sum()
+    gref, = torch.autograd.grad(ref_loss, V)
+    assert float(node.detach()) == pytest.approx(float(ref_loss.detach()), rel=1e-12)
+    assert torch.allclose(gv, gref, rtol=1e-10, atol=1e-13 * gref.abs().max().item())
 
 
 def test_outputs_zeroed_ahead_of_time_equal_outputs_filled_in_the_call(Render, hand):

@@ -233,12 +233,88 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     del d._drt_grid
     prof, _ = run(None)
     prof2, _ = run(None)                                   # trusted call after the re-establishment
-    # (the establishing call sends image 0's ten foreign rays to the tree; a trusting call sends ALL of image 0 there: only
-    # images verified in every ray are recorded as grids -- k_store_models)
-    assert prof2["trace1"][2] > prof["trace1"][2] > 0
+    # (the establishing call sends image 0's ten foreign rays to the tree; so does a trusting call: an image that is not recorded as
+    # all-verified is fitted and verified ray by ray again -- k_check_views -- instead of going to the tree wholesale)
+    assert prof2["trace1"][2] == prof["trace1"][2] > 0
     o[2 * P + 5] += 1.0                                    # and an origin write
     prof3, _ = run(None)                                   # establishes again: per-ray verdicts, one more ray for the tree
-    assert prof2["trace1"][2] > prof3["trace1"][2] >= prof["trace1"][2]
+    assert prof3["trace1"][2] >= prof["trace1"][2]
+
+
+def _trusted_pair(Render, scene, mesh, res, cam_ids):
+    """Ray tensors of `cam_ids` on which two calls have run: the second one has read the verdicts back (DRT_GRID_ALL_VERIFIED)."""
+    c, ext = views.mesh_frame(mesh.vertices)
+    cams = views.turntable_cameras(c, ext, 72, res, res)
+    rays = [views.generate_ray(res, res, cams[k][3], cams[k][2], device="cuda") for k in cam_ids]
+    o = torch.cat([r[0] for r in rays]).contiguous(); d = torch.cat([r[1] for r in rays]).contiguous()
+    Render.resx = Render.resy = res
+    with torch.no_grad():
+        for _ in range(2):
+            scene.render_transparent(o, d)
+    assert d._drt_grid[3][0] is True                       # every image verified in every ray: later calls pass DRT_GRID_ALL_VERIFIED
+    return o, d, cams
+
+
+def test_all_verified_images_can_be_demoted_inside_a_call(Render):
+    """DRT_GRID_TRUST | DRT_GRID_ALL_VERIFIED skips the launches that serve rays outside the grid and waits for the tree only in front
+    of the second traversal.  The MESH can still take an image's projection bound away in a later call (a vertex reaches the camera
+    plane: k_raster demotes the image): its rays must then get their primary hits from the tree (k_gen_late), not an all-miss image."""
+    from drt_amd import diffrender
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(mesh, 0)
+    res = 256
+    o, d, cams = _trusted_pair(Render, scene, mesh, res, (4, 22, 47))
+    V0 = scene.vertices.detach().clone()
+    c = V0.mean(dim=0, keepdim=True)
+    tr = scene.optix_mesh
+    sp = torch.randn(o.shape, dtype=torch.float64, device="cuda") * 40.0; valid = torch.rand(len(o), device="cuda") < 0.6
+    for scale, expect_tree in ((1.0, False), (7.0, True), (1.02, False), (7.5, True)):
+        scene.update_verticex((V0 - c) * scale + c)        # x7 about the centroid: the cameras (2.5 extents away) are inside the hull
+        assert (diffrender._grid_cache(o, d, len(o), res, res)[0] & (3 | 32)) == (2 | 32)
+        tr.profile_enable(1); tr.profile_read()
+        prof, f1 = _check(Render, scene, o, d, res, res)    # face ids == exhaustive test, outputs == the run without any hint
+        Render.resx = Render.resy = res
+        assert (prof["trace1"][2] > 0) == expect_tree
+        assert (f1 >= 0).any()
+        # the one-pass loss on the same tensors takes the same fallback
+        Vg = scene.vertices.detach().clone().requires_grad_(True)
+        scene.update_verticex(Vg)
+        lf = scene.ray_loss_fused(o, d, sp, valid)
+        gf, = torch.autograd.grad(lf, Vg)
+        oo, od, mk = scene.render_transparent(o, d)
+        l2 = Render.ray_loss(oo, od, mk, sp, valid)
+        g2, = torch.autograd.grad(l2, Vg)
+        assert lf.item() == pytest.approx(l2.item(), rel=1e-12, abs=1e-300)
+        assert torch.allclose(gf, g2, rtol=1e-9, atol=1e-12 * max(1e-300, g2.abs().max().item()))
+
+
+def test_trust_rechecks_the_lattice_of_every_image(Render):
+    """A write through `.data` (or a raw pointer) changes rays without bumping the version counter the verdict cache is keyed on.  A
+    trusting call re-verifies the 64 lattice rays of every image against the recorded model: wholesale-replaced rays are caught and
+    the image is fitted and verified per ray again -- the answer is that of the NEW rays."""
+    from drt_amd import diffrender
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(mesh, 0)
+    res = 256
+    o, d, cams = _trusted_pair(Render, scene, mesh, res, (4, 22, 47))
+    P = res * res
+    o_b, d_b = views.generate_ray(res, res, cams[60][3], cams[60][2], device="cuda")
+    ver = (o._version, d._version)
+    d.data[P:2 * P].copy_(d_b)                              # image 1: another camera's directions ...
+    o.data[P:2 * P].copy_(o_b)                              # ... and origin
+    d.data[2 * P:3 * P].copy_(torch.nn.functional.normalize(d_b + 0.01 * torch.sin(torch.arange(P, device="cuda", dtype=torch.float64) / 313.0).unsqueeze(1), dim=1))   # image 2: no grid at all
+    assert (o._version, d._version) == ver and (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == 2
+    for _ in range(2):                                      # the call that notices, and the one after it (cache entry now untrusted)
+        prof, f1 = _check(Render, scene, o, d, res, res)
+        Render.resx = Render.resy = res
+        assert prof["trace1"][2] > 0                        # image 2 goes through the tree
+        assert (f1[P:2 * P] >= 0).any()
+    # an untouched image is still served by the projection pass alone
+    with torch.no_grad():
+        oo, od, mk = scene.render_transparent(o[:P].clone(), d[:P].clone())
+        ref = (oo, od, mk)
+        oo, od, mk = scene.render_transparent(o, d)
+    assert torch.equal(oo[:P], ref[0]) and torch.equal(od[:P], ref[1]) and torch.equal(mk[:P], ref[2])
 
 
 def test_sparse_face_ids_leave_results_unchanged(Render):
@@ -283,7 +359,7 @@ def test_many_sub_batches_on_two_streams(extra):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, DRT_MIN_SUB_LOG2="16", DRT_CHUNK_LOG2="18", DRT_SUB_PER_STREAM="8", **extra)
-    sel = ("test_grid_rays_are_decided or test_rays_outside_the_grid or test_grid_verdict_is_cached or test_key_buffer_is_clean or "
+    sel = ("test_grid_rays_are_decided or test_rays_outside_the_grid or test_grid_verdict_is_cached or test_key_buffer_is_clean or test_all_verified_images or test_trust_rechecks or "
            "test_properties_at_full_size or test_render_transparent_vs_golden or test_two_optimisation_steps")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_raster.py"), os.path.join(here, "test_gpu_parity.py"),
                         "-m", "gpu", "-x", "-q", "-k", sel], env=env, capture_output=True, text=True, timeout=900)
