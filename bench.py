@@ -65,21 +65,35 @@ VALU_MEASURED = {"v_fma_f32": 834.0, "v_max_f32": 563.8, "v_pk_fma_f32 (x2 fmas)
 # which bench.py stage is which kernel(s) in a rocprofv3 trace
 KERNELS = {"k_trace<closest>": ("trace1", "trace2"), "k_trace<any>": ("trace3",), "fill + k_cull": ("fill", "cull"), "k_raster": ("raster",),
            "k_shade1": ("shade1",), "k_shade2": ("shade2",), "k_finish": ("finish",), "k_render_bwd": ("backward", "collect"),
-           "k_loss_bwd_fused": ("loss_bwd_fused",), "build": ("build",)}
+           "k_loss_bwd_fused": ("loss_bwd_fused",), "build": ("build",), "k_path": ("path",)}
 PMC_NAMES = {"k_trace<closest>": ("k_trace<false, 0>",), "k_trace<any>": ("k_trace<true, 0>",)}
 
 
 def _pmc(mode, workload):
-    """Per-launch PMC means of profiles/pmc.json (tools/make_pmc_json.py) -- only for the workload they were collected on."""
+    """(per-launch PMC means of profiles/pmc.json, provenance) -- only for the workload they were collected on.  The file is stamped
+    with a sha256 of the kernel sources (tools/make_pmc_json.py, drt_amd.build.source_hash): counters of OTHER kernels than the ones
+    this run timed are not mixed with its launch times -- `stale` says so and the issue-rate figures fall back to the live estimate."""
     path = os.path.join(ROOT, "profiles", "pmc.json")
+    prov = {"file": "profiles/pmc.json", "git_head": None, "source_sha256": None, "stale": True}
     try:
         rec = json.load(open(path))
-        return rec.get(mode, {}) if rec.get("workload") == workload else {}
+        from drt_amd import build as _build
+        now = _build.source_hash()
+        prov.update(git_head=rec.get("git_head"), source_sha256=rec.get("source_sha256"), sources_now_sha256=now,
+                    stale=rec.get("source_sha256") != now)
+        return (rec.get(mode, {}) if rec.get("workload") == workload else {}), prov
     except Exception:
-        return {}
+        return {}, prov
 
 
-def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None, live=None):
+# VALU wave-instructions of one wave-step of k_trace<closest> (static counts of the inner-node visit and of the one-triangle leaf visit in
+# this build's ISA, loop bookkeeping included: DESIGN.md section 6): with the wave-steps the statistics mode counts live, an estimate of
+# SQ_INSTS_VALU that does not depend on a committed counter file -- reported next to the PMC figure, and used instead of it when that
+# file was collected on other kernel sources.
+VALU_PER_INNER_STEP, VALU_PER_LEAF_STEP = 103, 72
+
+
+def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None, live=None, wave_steps=None):
     """Per-kernel live timing (hipEvents on the launch streams, drt_profile_*) -> the kernel that takes the most time, BY
     KERNEL NAME (the two closest-hit traversals are one kernel), with the bound that applies to it, and the HBM-streaming
     stage beside it.
@@ -132,7 +146,8 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
             by_kernel[name] = {"ms_per_step": round(ms, 4), "launches": sum(stages[m]["launches"] for m in members if m in stages),
                                "alone_ms_per_step": round(sum(alone[m]["ms_per_step"] for m in members if m in alone), 4) if alone else None}
     dom = max((k for k in by_kernel if k != "build"), key=lambda k: by_kernel[k]["ms_per_step"])
-    pmc = _pmc(args.mode, f"{args.mesh} res {args.res} views {n_local_views} streams default")
+    pmc, pmc_prov = _pmc(args.mode, f"{args.mesh} res {args.res} views {n_local_views} streams default")
+    pmc_fresh = bool(pmc) and not pmc_prov["stale"]
 
     def issue_entry(name):
         """VALU-issue bound of a traversal kernel: wave-instructions per launch (PMC) over the live launch time."""
@@ -141,7 +156,23 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
         ms = sum(stages[m]["ms_per_step"] for m in members) * args.steps
         rec = next((pmc[q] for q in PMC_NAMES.get(name, ()) if q in pmc), None)
         out = {"kernel": name, "bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK / 1e9, 1), "avg_launch_ms": round(ms / max(1, launches), 4),
-               "achieved": None, "frac": None, "valu_instr_per_launch": None}
+               "achieved": None, "frac": None, "valu_instr_per_launch": None, "pmc_stale": pmc_prov["stale"], "pmc": pmc_prov}
+        # live estimate: wave-steps of one (untimed, statistics-mode) step x the static instruction counts of a wave-step
+        ws = [wave_steps[m] for m in members if wave_steps and m in wave_steps]
+        est = None
+        if ws and name == "k_trace<closest>":
+            inner = sum(w["inner"] for w in ws) / max(1, sum(w["launches"] for w in ws)); leaf = sum(w["leaf"] for w in ws) / max(1, sum(w["launches"] for w in ws))
+            est = inner * VALU_PER_INNER_STEP + leaf * VALU_PER_LEAF_STEP
+            out["wave_steps_per_launch"] = {"inner": round(inner), "leaf": round(leaf)}
+            out["valu_instr_per_launch_est"] = int(est)
+            if launches and ms > 0:
+                out["est"] = {"achieved": round(est / (ms / launches * 1e-3) / 1e9, 1), "frac": round(est / (ms / launches * 1e-3) / VALU_PEAK, 4),
+                              "what": f"wave-steps counted live x ({VALU_PER_INNER_STEP} VALU per inner visit, {VALU_PER_LEAF_STEP} per leaf visit)"}
+        if not pmc_fresh:
+            # counters of other kernel sources (or none): not mixed with this run's launch times
+            if est and launches and ms > 0:
+                out.update(achieved=out["est"]["achieved"], frac=out["est"]["frac"], frac_source="live wave-step estimate (profiles/pmc.json is stale: re-run tools/final_runs.sh)")
+            return out
         if rec and launches and ms > 0 and "SQ_INSTS_VALU" in rec:
             ach = rec["SQ_INSTS_VALU"] / (ms / launches * 1e-3)
             out.update(achieved=round(ach / 1e9, 1), frac=round(ach / VALU_PEAK, 4), valu_instr_per_launch=int(rec["SQ_INSTS_VALU"]),
@@ -154,6 +185,9 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
                 out["valu_pipe_busy"] = round(rec["SQ_ACTIVE_INST_VALU"] * 4 * 8 / (1024 * rec["GRBM_GUI_ACTIVE"]), 3)
                 out["valu_lanes_useful"] = round(rec["SQ_THREAD_CYCLES_VALU"] / (64 * rec["SQ_ACTIVE_INST_VALU"]), 3) if rec.get("SQ_THREAD_CYCLES_VALU") else None
             out["measured_issue_rates"] = VALU_MEASURED
+            out["frac_source"] = "rocprofv3 SQ_INSTS_VALU (profiles/pmc.json, same kernel sources)"
+            if est:
+                out["est_over_pmc"] = round(est / rec["SQ_INSTS_VALU"], 3)
             if alone:
                 ms_a = sum(alone[m]["ms_per_step"] for m in members if m in alone) * args.steps
                 out["alone"] = {"avg_launch_ms": round(ms_a / launches, 4), "achieved": round(rec["SQ_INSTS_VALU"] / (ms_a / launches * 1e-3) / 1e9, 1),
@@ -168,14 +202,14 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
         bytes_ = sum(alg[m] for m in members)
         ach = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         traffic = None
-        if pmc:       # HBM bytes of the kernels of the stage (memset fills + k_patch_list + k_cull_listed), per sub-batch
+        if pmc and pmc_fresh:       # HBM bytes of the kernels of the stage (memset fills + k_patch_list + k_cull_listed), per sub-batch
             names = [q for q in pmc if q.startswith(("__amd_rocclr_fill", "k_patch_list", "k_cull_listed"))]    # (k_cull<...> is the establishing step's kernel)
             if names and all("hbm_bytes_per_launch" in pmc[q] for q in names):
                 per_step = sum(pmc[q]["hbm_bytes_per_launch"] * pmc[q]["launches"] for q in names)
                 ref_launches = pmc.get("k_patch_list", {}).get("launches")
                 traffic = round(per_step / ref_launches) if ref_launches else None
         out = {"kernel": "fill + k_cull", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-               "traffic": traffic, "alg_bytes_per_launch": round(bytes_ / max(1, launches)), "avg_launch_ms": round(ms / max(1, launches), 4)}
+               "traffic": traffic, "pmc_stale": pmc_prov["stale"], "alg_bytes_per_launch": round(bytes_ / max(1, launches)), "avg_launch_ms": round(ms / max(1, launches), 4)}
         if alone and all(m in alone for m in members):
             ms_a = sum(alone[m]["ms_per_step"] for m in members) * args.steps
             out["alone"] = {"achieved": round(bytes_ / (ms_a * 1e-3) / 1e9, 1), "frac": round(bytes_ / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -430,6 +464,26 @@ def main():
     }
     prof_live = scene.optix_mesh.profile_read() if live_profile else None
     scene.optix_mesh.profile_select(None)
+    # the two modes at ONE parameter state (no optimiser step in between): same loss to rounding, or one of them is wrong
+    loss_check = None
+    if not args.graph:
+        scene.optix_mesh.profile_enable(0)
+        opt.zero_grad(set_to_none=True)
+        l_drop = float(O.local_loss_backward(scene, local_views, init_vertices, parameter, w_ray, fused=False).item())
+        g_drop = parameter.grad.clone() if parameter.grad is not None else None
+        opt.zero_grad(set_to_none=True)
+        l_fus = float(O.local_loss_backward(scene, local_views, init_vertices, parameter, w_ray, fused=True).item())
+        g_fus = parameter.grad.clone() if parameter.grad is not None else None
+        opt.zero_grad(set_to_none=True)
+        rel = abs(l_drop - l_fus) / max(abs(l_drop), 1e-300)
+        g_rel = float(((g_drop - g_fus).abs().max() / g_drop.abs().max().clamp_min(1e-300)).item()) if g_drop is not None and g_fus is not None else None
+        loss_check = {"final_loss_dropin": l_drop, "final_loss_fused": l_fus, "rel_diff": rel, "grad_max_rel_diff": g_rel}
+        assert rel <= 1e-10, f"drop-in and fused losses disagree at the same parameters: {loss_check}"
+        assert g_rel is None or g_rel <= 1e-9, f"drop-in and fused gradients disagree at the same parameters: {loss_check}"
+        out["config"]["loss_check"] = loss_check
+        if live_profile:
+            scene.optix_mesh.profile_enable(True)
+            scene.optix_mesh.profile_read()
     fused_extra = None
     if args.mode == "dropin" and not args.graph and not args.no_extras:   # (N = 1 and N > 1 alike)
         # same K steps through the one-pass API (Scene.ray_loss_fused: no dense out_ori/out_dir/mask, rays of
@@ -446,6 +500,65 @@ def main():
         tf = ddist.allreduce_max_float(time.perf_counter() - tf, dev)
         fused_extra = {"M_rays_per_s": round(total_rays / tf / 1e6, 3), "ms_per_step": round(1e3 * tf / args.steps, 3),
                        "alg_bytes_per_ray": 73, "api": "Scene.ray_loss_fused (render_transparent + ray_loss + backward in one pass)"}
+        scene.optix_mesh.profile_enable(1)
+        scene.optix_mesh.profile_read()
+    establish_extra = tight_extra = None
+    if args.mode == "dropin" and not args.graph and not args.no_extras:
+        # (a) the same steps WITHOUT the verdict cache: every call fits the image models and verifies every single ray again, as a caller
+        #     does whose capture layer hands out fresh ray tensors per call (the reference's Data.get_view, captured_data.py:44-59)
+        scene.optix_mesh.profile_enable(0)
+        Render.GRID_CACHE = False
+        try:
+            for _ in range(2):
+                step(False)
+            ddist.barrier(); torch.cuda.synchronize()
+            te = time.perf_counter()
+            ke = min(args.steps, 20)
+            for _ in range(ke):
+                step(False)
+            ddist.barrier(); torch.cuda.synchronize()
+            te = ddist.allreduce_max_float(time.perf_counter() - te, dev)
+        finally:
+            Render.GRID_CACHE = True
+        establish_extra = {"M_rays_per_s": round(args.views * P * ke / te / 1e6, 3), "ms_per_step": round(1e3 * te / ke, 3), "steps": ke,
+                           "what": "diffrender.GRID_CACHE = False: no trusted-grid shortcut -- every ray of every image is loaded and verified against the fitted pinhole model in every call"}
+        # (b) tight framing: the same mesh seen from 1.1 extents instead of 2.5 (the object fills the image: primary hit fraction 0.2-0.4 instead of 0.04)
+        cams_t = views.turntable_cameras(center, extent, args.views, res, res, distance_factor=float(os.environ.get("DRT_TIGHT_FACTOR", "1.1")))
+        gt_t = Render.Scene(gt, local_rank)
+        tv = []
+        with torch.no_grad():
+            for k in my_views:
+                o, d = views.generate_ray(res, res, cams_t[k][3], cams_t[k][2], device=dev)
+                oo, od, mk = gt_t.render_transparent(o, d)
+                sp = views.screen_targets(oo, od, mk, cams_t[k], center, extent)
+                tv.append((sp.contiguous(), (sp[:, 0] != 0).contiguous(), o, d))
+        del gt_t
+        tight_views = [tuple(torch.cat([v[j] for v in tv[i:i + bv]]).contiguous() for j in range(4)) for i in range(0, len(tv), bv)]
+        del tv
+        torch.cuda.empty_cache()
+
+        def tight_step():
+            return O.full_batch_step(scene, tight_views, init_vertices, parameter, opt, w_ray, fused=False)
+        for _ in range(3):
+            lt = tight_step()
+        scene.optix_mesh.profile_enable(1); scene.optix_mesh.profile_read()
+        tight_step()
+        pt = scene.optix_mesh.profile_read()
+        scene.optix_mesh.profile_enable(0)
+        ddist.barrier(); torch.cuda.synchronize()
+        tt = time.perf_counter()
+        kt = min(args.steps, 10)
+        for _ in range(kt):
+            lt = tight_step()
+        ddist.barrier(); torch.cuda.synchronize()
+        tt = ddist.allreduce_max_float(time.perf_counter() - tt, dev)
+        hits_t = pt["shade1"][2]
+        tight_extra = {"M_rays_per_s": round(args.views * P * kt / tt / 1e6, 3), "ms_per_step": round(1e3 * tt / kt, 3), "steps": kt,
+                       "primary_hit_fraction": round(hits_t / (len(my_views) * P), 4), "M_paths_per_s": round(hits_t * world / (tt / kt) / 1e6, 1),
+                       "exit_rays_per_step_per_gpu": int(pt["trace3"][2]),
+                       "what": f"turntable_cameras(distance_factor={os.environ.get('DRT_TIGHT_FACTOR', '1.1')}): same mesh, same step, the object fills the frame"}
+        del tight_views
+        torch.cuda.empty_cache()
         scene.optix_mesh.profile_enable(1)
         scene.optix_mesh.profile_read()
     route_b = None
@@ -517,8 +630,19 @@ def main():
         Render.PREFILL_NEXT = prefill
     scene.optix_mesh.profile_enable(0)
     if rank == 0:
-        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso, LIVE if prof_live else None)
-        for k, (ws, ls, rf, mx) in tstats.items():
+        wave_steps = {k: {"inner": ws - lf, "leaf": lf, "launches": max(1, prof2[k][1])} for k, (ws, ls, lf, mx) in tstats.items() if ws} if prof2 else None
+        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso, LIVE if prof_live else None, wave_steps)
+        # what the step actually traces: paths that start at a primary hit (every pixel counts in `value`, SURVEY section 8d, but 96 % of
+        # the benchmark's pixels see the background)
+        h0 = prof["shade1"][2] / max(1, args.steps)
+        out["paths"] = {"primary_hits_per_step_per_gpu": int(h0), "primary_hit_fraction": round(h0 / (len(my_views) * P), 4),
+                        "M_paths_per_s": round(h0 * world / (elapsed / args.steps) / 1e6, 1),
+                        "exit_rays_per_step_per_gpu": int(prof["trace3"][2] / max(1, args.steps))}
+        if establish_extra:
+            out["establish_mode"] = establish_extra
+        if tight_extra:
+            out["tight_framing"] = tight_extra
+        for k, (ws, ls, lf, mx) in tstats.items():
             if ws and k in out["roofline"]["stages"]:
                 out["roofline"]["stages"][k].update({"node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),
                                                      "lane_utilisation": round(ls / (64.0 * ws), 3), "longest_wave_visits": mx})

@@ -19,6 +19,18 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
 
 
+def source_hash():
+    """sha256 over the kernel sources and the C-ABI header (names + contents, sorted): what profiles/pmc.json is stamped with
+    (tools/make_pmc_json.py) and what bench.py recomputes before it prices live launch times against those counters."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources():
+        if f.endswith((".hip", ".h", ".cpp", ".map")):
+            h.update(os.path.basename(f).encode() + b"\0")
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def up_to_date(out=OUT):
     if not os.path.exists(out):
         return False

@@ -70,6 +70,11 @@ int drt_create(int device, drt_scene_t** out) {
         per_cu = pipeline_blocks_per_cu();        // drt_pipeline.hip: resident 256-thread blocks of k_trace
         s->grid_path = s->n_cu * per_cu;
         if (s->grid_path * 2 > kTraceGridMax) s->grid_path = kTraceGridMax / 2;
+        per_cu = mega_blocks_per_cu();            // drt_pipeline.hip: resident 256-thread blocks of k_path
+        s->grid_mega = s->n_cu * per_cu;
+        if (const char* e = getenv("DRT_MEGA_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) s->grid_mega = v * s->n_cu; }
+        if (const char* e = getenv("DRT_MEGA_MAX_LOG2")) { const int v = atoi(e); s->mega_max_rays = v <= 0 ? 0 : (v <= 31 ? (int64_t)1 << v : (int64_t)1 << 31); }
+        if (const char* e = getenv("DRT_SHADE_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->shade_min = v; }
         // tuning knobs (measurement only; defaults are the tuned values)
         if (const char* e = getenv("DRT_TRACE_BPC")) { const int v = atoi(e); if (v >= 1 && v * s->n_cu * 2 <= kTraceGridMax) s->grid_path = v * s->n_cu; }
         if (const char* e = getenv("DRT_INNER_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->inner_min = v; }

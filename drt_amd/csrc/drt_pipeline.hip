@@ -127,8 +127,9 @@ struct RasterIn {
     uint32_t* zmask;
     int32_t* gen_list;               // R0 slots that still need k_trace (count in p.count[3])
     int img_w, img_h;
-    int defer;                       // DRT_GRID_ALL_VERIFIED: the tree may still be under construction during the cull stage -- no top-box test, and a
-                                     // ray outside the grid is listed with face = kFacePending for k_gen_late (after the build has been waited for)
+    int pending;                     // a ray outside the grid is listed with face = kFacePending: its primary hit is found later (k_gen_late behind the
+                                     // asynchronous build under DRT_GRID_ALL_VERIFIED; stage T0 of k_path), not by a k_trace launch in front of k_shade1
+    int no_tree;                     // DRT_GRID_ALL_VERIFIED: the tree may still be under construction during the cull stage -- no top-box test
 };
 constexpr int32_t kFacePending = -2; // R0 entry whose primary hit is still to be found by the tree (k_shade1 leaves it alone)
 
@@ -226,7 +227,7 @@ __device__ __forceinline__ void cull_patch(unsigned patch, bool prefilled, CullS
                     cand = key != kRasterEmpty;
                     face = (int32_t)(uint32_t)key;
                 } else {
-                    cand = n_tris > 0 && (rz.defer || hits_top_boxes(nodes, o, d));
+                    cand = n_tris > 0 && (rz.no_tree || hits_top_boxes(nodes, o, d));
                     generic = cand;
                 }
             } else if (raster && rz.mode == DRT_GRID_ESTABLISH) {
@@ -266,7 +267,7 @@ __device__ __forceinline__ void cull_patch(unsigned patch, bool prefilled, CullS
         }
         if (slot >= 0) {
             p.r0.idx[slot] = (int32_t)i; store_ray32(p.r0.ray, slot, o, d);
-            if (raster) p.r0.face[slot] = generic && rz.defer ? kFacePending : face;
+            if (raster) p.r0.face[slot] = generic && rz.pending ? kFacePending : face;
         }
         if (raster && __syncthreads_or(generic ? 1 : 0)) {       // rare: rays outside the grid model
             const int g = block_push(generic, &p.count[3], s_tmp);
@@ -533,6 +534,302 @@ __global__ void __launch_bounds__(kPathBlock) k_finish(double* __restrict__ out_
         if (valid_idx) stage_push(stage, keep, (int32_t)(chunk_base + i), f3{0.f, 0.f, 0.f}, f3{0.f, 0.f, 0.f}, out, p.valid);
     }
     if (valid_idx) stage_flush(stage, out, p.valid);
+}
+
+// ---- the same path as ONE persistent kernel (small sub-batches) ----------------------------------------------------------
+//
+// Below ~2^24 camera rays a sub-batch has fewer rays in flight than the chip has lanes: every k_trace launch is then as long as
+// its slowest wavefront (one 64-ray group per wave, ~0.7 us per dependent load -> slab test -> push step, 150-230 steps), the
+// staged pipeline pays that tail twice (refracted rays, exit rays) plus five dependent launches in between, and the SIMDs sit
+// idle under both tails.  k_path runs R0 -> outputs in one launch: a LANE carries its ray through
+//     [T0: primary hit through the tree -- only for rays the projection pass did not answer]
+//     S1: float64 bounce #1 -> T1: closest hit of the refracted ray -> S2: bounces #1 + #2, provisional outputs
+//     -> T2: occlusion test of the exit ray -> finish (survivor -> list of valid rays; occluded -> dead values)
+// and takes the next R0 entry of its wave's segment when it is through, so the occlusion rays of early finishers are traced
+// under the tail of the refracted rays of the others.  The traversal phases are k_trace's ("while-while": lanes at inner nodes
+// descend together, lanes at leaves wait for a common triangle step; LDS-only stack with a redo list); the float64 stages run as
+// wave phases in between, entered when `shade_min` lanes wait for one (or nothing else can run).  T2 uses the closest-hit child
+// order (one code path for all traversing lanes) and stops at its first hit; results are those of the staged kernels bit for bit
+// (same device functions, same writes).  ~2x the registers of k_trace (4 waves per SIMD): chosen for small sub-batches only.
+enum : int { kLaneIdle = 0, kLaneS1 = 1, kLaneT0 = 2, kLaneT0D = 3, kLaneT1 = 4, kLaneT1D = 5, kLaneT2 = 6, kLaneT2D = 7 };   // odd = waits for a float64 stage
+constexpr int kVBuf = 128;            // finished rays staged per wave before one list reservation
+
+template <class STACK>
+__device__ __forceinline__ bool path_leaf(const TriRec* __restrict__ tris, TravState& s, STACK& st, bool any) {
+    if (s.cur == kEmptyChild) return trav_pop(s, st);
+    const int32_t ref = ~s.cur;
+    const int first = ref >> kLeafBits, count = (ref & (kLeafMax - 1)) + 1;
+    for (int j = 0; j < count; ++j) {
+        const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
+        const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+        float t;
+        if (tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
+            int32_t face;
+            memcpy(&face, &p0.w, 4);
+            if (any) { s.best_t = t; s.best_face = face; return true; }
+            if (t < s.best_t || (t == s.best_t && face < s.best_face)) { s.best_t = t; s.best_face = face; }
+        }
+    }
+    return trav_pop(s, st);
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                        double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int64_t chunk_base,
+                                                        int32_t* __restrict__ valid_idx, bool prefilled, bool all_pending,
+                                                        int refill_min, int inner_min, int shade_min, unsigned long long* stats, bool count_items) {
+    __shared__ int32_t lds[kStackFast + 1 + kGuardRows][kPathBlock];
+    __shared__ int32_t s_vbuf[kPathWaves][kVBuf];
+    __shared__ double s_ray2[6][kPathBlock];           // the refracted ray of bounce #1 in float64, parked per lane while T1 runs: S2 then does ONE bounce
+    FastStack st;
+    st.base = (drt::FastPtr)&lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast - 3; st.reset(); st.overflow = false;
+#if defined(DRT_CHECK)
+    for (int g = 0; g < kGuardRows; ++g) lds[kStackFast + 1 + g][threadIdx.x] = kGuardPoison;
+#endif
+    const unsigned n = p.count[0];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    // the segment of R0 this wave owns: as in k_trace (8 contiguous parts of the tile-ordered list, one per XCD; groups of 64 entries interleaved over the part's waves)
+    constexpr unsigned kXcd = 8;
+    const unsigned n_groups = (n + 63u) >> 6;
+    const bool split = gridDim.x % kXcd == 0 && n_groups >= 64u * kXcd;
+    const unsigned xcd = split ? blockIdx.x % kXcd : 0u, parts = split ? kXcd : 1u;
+    const unsigned wave = (split ? blockIdx.x / kXcd : blockIdx.x) * kPathWaves + (threadIdx.x >> 6);
+    const unsigned n_waves = (split ? gridDim.x / kXcd : gridDim.x) * kPathWaves;
+    const unsigned part_lo = (unsigned)((unsigned long long)n_groups * xcd / parts), part_hi = (unsigned)((unsigned long long)n_groups * (xcd + 1) / parts);
+    const unsigned part_groups = part_hi - part_lo;
+    const unsigned my_groups = wave < part_groups ? (part_groups - wave + n_waves - 1) / n_waves : 0u;
+    const unsigned my_rays = my_groups << 6;
+    // finished rays: the caller's list of valid rays (global index) or, fused, list R2 for k_loss_bwd_fused (index; face < 0 = "not occluded")
+    int32_t* const v_out = FUSED ? p.r2.idx : valid_idx;
+    unsigned* const v_count = FUSED ? &p.count[2] : p.valid;
+    unsigned vn = 0;                                   // entries staged in s_vbuf[wv] (wave-uniform)
+    auto v_flush = [&]() {
+        if (vn == 0) return;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(v_count, vn);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        for (unsigned k = lane; k < vn; k += 64u) {
+            v_out[base + k] = s_vbuf[wv][k];
+            if (FUSED) p.r2.face[base + k] = -1;
+        }
+        vn = 0;
+    };
+    unsigned taken = 0;
+    int stage = kLaneIdle;
+    int32_t rk = 0, ri = 0;                            // R0 slot and ray index of this lane's ray
+    TravState s;
+    s.cur = 0; s.best_face = -1; s.best_t = 0.f;
+    unsigned long long wave_steps = 0, lane_steps = 0, leaf_steps = 0;
+    unsigned n_t1 = 0, n_t2 = 0;
+    for (;;) {
+        // ---- refill: idle lanes take the next R0 entries of the segment
+        const unsigned long long idle = __ballot(stage == kLaneIdle);
+        if (idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull)) {
+            if (stage == kLaneIdle) {
+                const unsigned j = taken + (unsigned)__popcll(idle & lower);
+                const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
+                if (j < my_rays && k < n) {
+                    rk = (int32_t)k;
+                    ri = p.r0.idx[k];
+                    const int32_t f1 = all_pending ? kFacePending : p.r0.face[k];
+                    if (f1 == kFacePending) {
+                        const float* e = p.r0.ray + 6 * (int64_t)k;
+                        trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+                        st.overflow = false;
+                        stage = kLaneT0;
+                    } else {
+                        s.best_face = f1;
+                        stage = kLaneS1;
+                    }
+                }
+            }
+            taken += (unsigned)__popcll(idle);
+        }
+        if (__ballot(stage != kLaneIdle) == 0) break;
+        // ---- float64 stages, when enough lanes wait for one or nothing can be traversed meanwhile
+        {
+            const unsigned long long waiting = __ballot(stage & 1), walking = __ballot(stage != kLaneIdle && !(stage & 1));
+            if (waiting != 0 && ((int)__popcll(waiting) >= shade_min || walking == 0)) {
+                // finish: the occlusion test of the exit ray is in
+                const bool fin = stage == kLaneT2D;
+                const bool keep = fin && s.best_face < 0;
+                if (fin && !keep) { if (FUSED) face2[ri] = -1; else write_dead(ri, out_ori, out_dir, mask, face2); }
+                if (v_out) {
+                    const unsigned long long km = __ballot(keep);
+                    if (km != 0) {
+                        if (keep) s_vbuf[wv][vn + (unsigned)__popcll(km & lower)] = FUSED ? ri : (int32_t)(chunk_base + ri);
+                        vn += (unsigned)__popcll(km);
+                        __builtin_amdgcn_wave_barrier();
+                        if (vn > kVBuf - 64) v_flush();
+                    }
+                }
+                if (fin) stage = kLaneIdle;
+                // bounce #1 (k_shade1): a primary hit is known (from the projection pass, or just found in the tree)
+                if (stage == kLaneS1 || stage == kLaneT0D) {
+                    const int32_t f1 = s.best_face;
+                    if (stage == kLaneT0D) p.r0.face[rk] = f1;
+                    face1[ri] = f1;
+                    bool ok = false;
+                    if (f1 >= 0) {
+                        d3 v0, v1, v2;
+                        int32_t vid[3];
+                        Bounce b;
+                        load_tri64(c, f1, v0, v1, v2, vid);
+                        bounce_forward(load_d3(origin, ri), load_d3(dir, ri), v0, v1, v2, c.ior_ext, c.ior_int, b);
+                        ok = !b.tir;
+                        if (ok) {
+                            trav_init(s, st, to_f32(b.new_o), to_f32(b.wt));
+                            st.overflow = false;
+                            stage = kLaneT1;
+                            s_ray2[0][threadIdx.x] = b.new_o.x; s_ray2[1][threadIdx.x] = b.new_o.y; s_ray2[2][threadIdx.x] = b.new_o.z;
+                            s_ray2[3][threadIdx.x] = b.wt.x; s_ray2[4][threadIdx.x] = b.wt.y; s_ray2[5][threadIdx.x] = b.wt.z;
+                            ++n_t1;
+                        }
+                    }
+                    if (!ok) {
+                        if (!FUSED) { if (prefilled) face2[ri] = -1; else write_dead(ri, out_ori, out_dir, mask, face2); }
+                        stage = kLaneIdle;
+                    }
+                } else if (stage == kLaneT1D) {
+                    // bounce #2 (k_shade2, which recomputes bounce #1 to the same bits): the second hit is in
+                    const int32_t f2 = s.best_face;
+                    bool ok = false;
+                    if (f2 >= 0) {
+                        d3 v0, v1, v2;
+                        int32_t vid[3];
+                        Bounce b;
+                        const d3 o2{s_ray2[0][threadIdx.x], s_ray2[1][threadIdx.x], s_ray2[2][threadIdx.x]};
+                        const d3 d2{s_ray2[3][threadIdx.x], s_ray2[4][threadIdx.x], s_ray2[5][threadIdx.x]};
+                        load_tri64(c, f2, v0, v1, v2, vid);
+                        bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
+                        ok = !b.tir;
+                        if (ok) {
+                            face2[ri] = f2;
+                            if (!FUSED) {
+                                store_d3(out_ori, ri, b.new_o);
+                                store_d3(out_dir, ri, b.wt);
+                                mask[3 * (int64_t)ri] = 1; mask[3 * (int64_t)ri + 1] = 1; mask[3 * (int64_t)ri + 2] = 1;
+                            }
+                            trav_init(s, st, to_f32(b.new_o), to_f32(b.wt));
+                            st.overflow = false;
+                            stage = kLaneT2;
+                            ++n_t2;
+                        }
+                    }
+                    if (!ok) {
+                        if (FUSED) face2[ri] = -1; else write_dead(ri, out_ori, out_dir, mask, face2);
+                        stage = kLaneIdle;
+                    }
+                }
+            }
+        }
+        // ---- traversal phases (k_trace's), for the lanes in T0 / T1 / T2
+        for (;;) {
+            const bool walking = stage != kLaneIdle && !(stage & 1);
+            const bool at_inner = walking && s.cur >= 0;
+            const unsigned long long mi = __ballot(at_inner);
+            if (mi == 0) break;
+            if ((int)__popcll(mi) < inner_min && __ballot(walking && s.cur < 0) != 0) break;
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(mi);
+            if (at_inner) {
+                const bool done = trav_inner<false>(c.tc.nodes, s, st);
+                if (st.overflow) {                 // LDS stack exhausted (rare): the whole path of this ray is redone by k_path_redo
+                    p.redo[atomicAdd(&p.count[4], 1u)] = rk;
+                    stage = kLaneIdle;
+                } else if (done) {
+                    stage |= 1;
+                }
+            }
+        }
+        {
+            const bool at_leaf = stage != kLaneIdle && !(stage & 1) && s.cur < 0;
+            const unsigned long long ml = __ballot(at_leaf);
+            if (ml != 0) {
+                ++wave_steps; ++leaf_steps;
+                lane_steps += (unsigned long long)__popcll(ml);
+                if (at_leaf && path_leaf(c.tc.tris, s, st, stage == kLaneT2)) stage |= 1;
+            }
+        }
+    }
+    v_flush();
+#if defined(DRT_CHECK)
+    for (int g = 0; g < kGuardRows; ++g) DRT_DEV_ASSERT(lds[kStackFast + 1 + g][threadIdx.x] == kGuardPoison, drt::kCheckGuardRow);
+#endif
+    if (count_items) {                                  // (profiling only: list sizes of the staged pipeline's R1 / R2)
+        const unsigned t1 = (unsigned)wave_sum((double)n_t1), t2 = (unsigned)wave_sum((double)n_t2);
+        if (lane == 0 && t1) atomicAdd(&p.count[5], t1);
+        if (lane == 0 && t2) atomicAdd(&p.count[6], t2);
+    }
+    if (stats && lane == 0 && wave_steps) {
+        atomicAdd(stats + 0, wave_steps);
+        atomicAdd(stats + 1, lane_steps);
+        atomicAdd(stats + 2, leaf_steps);
+        atomicMax(stats + 3, wave_steps);
+    }
+}
+
+// The rays whose traversal overflowed the LDS-only stack inside k_path: the whole path again from the R0 entry, one thread per
+// ray, spilling stack.  Idempotent with whatever the abandoned lane had written (provisional outputs are rewritten or zeroed).
+template <bool FUSED>
+__global__ void __launch_bounds__(kTraceBlock) k_path_redo(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                           double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                           int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int64_t chunk_base,
+                                                           int32_t* __restrict__ valid_idx, bool prefilled, bool all_pending) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    const unsigned n = p.count[4];
+    if (n == 0) return;
+    Stack st = make_stack(lds, c.tc);
+    for (unsigned q = blockIdx.x * kTraceBlock + threadIdx.x; q < n; q += gridDim.x * kTraceBlock) {
+        const int32_t rk = p.redo[q];
+        const int64_t i = p.r0.idx[rk];
+        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
+        int32_t f1 = all_pending ? kFacePending : p.r0.face[rk];
+        if (f1 == kFacePending) {
+            const float* e = p.r0.ray + 6 * (int64_t)rk;
+            f1 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st).face;
+            p.r0.face[rk] = f1;
+        }
+        face1[i] = f1;
+        bool alive = false, shaded2 = false;
+        d3 v0, v1, v2;
+        int32_t vid[3];
+        Bounce b;
+        if (f1 >= 0) {
+            load_tri64(c, f1, v0, v1, v2, vid);
+            bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b);
+            if (!b.tir) {
+                const d3 o2 = b.new_o, d2 = b.wt;
+                const int32_t f2 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(o2), to_f32(d2), st).face;
+                shaded2 = true;
+                if (f2 >= 0) {
+                    load_tri64(c, f2, v0, v1, v2, vid);
+                    bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
+                    if (!b.tir && traverse<true>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(b.new_o), to_f32(b.wt), st).face < 0) {
+                        alive = true;
+                        face2[i] = f2;
+                        if (!FUSED) {
+                            store_d3(out_ori, i, b.new_o);
+                            store_d3(out_dir, i, b.wt);
+                            mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (!alive) {
+            if (FUSED) face2[i] = -1;
+            else if (shaded2 || !prefilled) write_dead(i, out_ori, out_dir, mask, face2);
+            else face2[i] = -1;
+        } else if (FUSED) {
+            const unsigned slot = atomicAdd(&p.count[2], 1u);
+            p.r2.idx[slot] = (int32_t)i; p.r2.face[slot] = -1;
+        } else if (valid_idx) {
+            valid_idx[atomicAdd(p.valid, 1u)] = (int32_t)(chunk_base + i);
+        }
+    }
 }
 
 __global__ void k_store_count(const unsigned* __restrict__ count, int64_t* __restrict__ out) {
@@ -898,12 +1195,19 @@ __global__ void __launch_bounds__(256) k_loss_bwd_listed(PathCtx c, const double
     if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
 }
 
-__global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused, int raster) {
+__global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused, int raster, bool mega) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // sub-batches on different streams may report concurrently: atomics
     atomicAdd(&tot[kStageCull], n_rays);
     if (raster) atomicAdd(&tot[kStageRaster], n_rays);
     if (raster && !fused) atomicAdd(&tot[kStageFill], n_rays);
+    if (mega) {       // one kernel did it all: its item count is the list of primary candidates; the inner list sizes it counted go to the staged stages' rows
+        atomicAdd(&tot[kStagePath], (unsigned long long)qcount[0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
+        atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[5]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[5]);
+        atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[6]);
+        atomicAdd(&tot[fused ? kStageLossBwdFused : kStageFinish], (unsigned long long)qcount[6]);
+        return;
+    }
     atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
     atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
     atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[2]);
@@ -1001,14 +1305,18 @@ extern "C++" {
 template <bool FUSED>
 static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const PathCtx& pc, const Pipe& p, const double* o, const double* d, const uint8_t* valid,
                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h,
-                        int grid_mode, ViewModel* grid_cache /* models of the images of THIS sub-batch */) {
+                        int grid_mode, ViewModel* grid_cache /* models of the images of THIS sub-batch */,
+                        hipStream_t aux /* the caller's stream: idle between the fork and the join of a call */, int64_t chunk_base, int32_t* valid_idx,
+                        bool* n_finished /* out: the sub-batch ran as ONE kernel (k_path), which also did k_finish's work */) {
+    if (n_finished) *n_finished = false;
     const bool sparse_faces = (grid_mode & DRT_GRID_SPARSE_FACES) != 0;
     const bool pre_ori = (grid_mode & kIntPreOri) != 0, pre_dir = (grid_mode & kIntPreDir) != 0, pre_mask = (grid_mode & kIntPreMask) != 0;   // zeroed ahead of time (drt_prefill_zero)
     const bool all_verified = (grid_mode & DRT_GRID_ALL_VERIFIED) != 0 && (grid_mode & 3) == DRT_GRID_TRUST && grid_cache;
     grid_mode &= 3;
     const int gs = 8 * s->n_cu;   // grid of the streaming / shading kernels
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
-    RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0};
+    RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    const bool mega = s->mega_max_rays > 0 && n <= s->mega_max_rays && n_finished != nullptr;
     bool late_fill = false;
     // the scene's build stream is idle once the tree is built (before the cull stage): it carries the late fills, so that the
     // library stays within the four hardware queues a process gets by default (more streams would share queues with these)
@@ -1041,7 +1349,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         StageTimer t(s, st, kStageRaster);
         rc = launch_raster(s, w, st, o, d, n_views, tile_w, tile_h, grid_mode == DRT_GRID_TRUST ? grid_cache : nullptr);
         if (rc) return rc;
-        rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h, all_verified ? 1 : 0};
+        rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h, (all_verified || mega) ? 1 : 0, all_verified ? 1 : 0};
     }
     // The cull stage reads the tree for rays outside the grid (top-box test, k_trace on the listed slots): wait for the build (it ran
     // beside the projection pass above).  When the caller vouches that every ray of every image is a verified grid ray, nothing before
@@ -1064,6 +1372,9 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
           k_cull<FUSED><<<n_patches, kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
       } }
     if (late_fill) {      // (StageTimer scopes must not nest: this one follows the cull stage's)
+        // (one-kernel path: the dense rows are written INSIDE k_path, so the fills cannot hide beside a later stage on the build stream -- which
+        // still carries the build at these sizes; they go to the caller's stream, idle until the join, and run beside the projection pass and the cull)
+        if (mega && fs != st && aux) fs = aux;
         if (fs != st) { HIP_TRY(hipEventRecord(w.fill_fork, st)); HIP_TRY(hipStreamWaitEvent(fs, w.fill_fork, 0)); }
         { StageTimer tf(s, fs, kStageFill);
           if (!pre_ori) (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, fs);
@@ -1073,6 +1384,18 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     }
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
+    if (mega) {
+        if (tree_late) { int rc = wait_build(s, st); if (rc) return rc; }
+        if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));
+        if (late_fill && pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
+        const bool filled = !FUSED && rz.views && grid_mode == DRT_GRID_TRUST;     // the dense outputs hold the dead values everywhere
+        StageTimer t(s, st, kStagePath);
+        k_path<FUSED><<<s->grid_mega, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, chunk_base, valid_idx, filled, rz.views == nullptr,
+                                                           s->refill_min, s->inner_min, s->shade_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr, s->prof_on);
+        k_path_redo<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, chunk_base, valid_idx, filled, rz.views == nullptr);
+        *n_finished = true;
+        return DRT_OK;
+    }
     { StageTimer t(s, st, kStageTrace1);
       if (rz.views && all_verified) {
           // every ray of every image is a verified grid ray (the caller read that off the cache): normally nothing was listed, and what
@@ -1134,6 +1457,13 @@ static PathCtx sub_ctx(const drt_scene* s, const drt_scene::Sub& w, const double
 #if defined(DRT_CHECK)
 int check_counters_pipeline(unsigned long long* out4) { return read_check_counters(out4); }
 #endif
+int mega_blocks_per_cu() {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    int f = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, k_path<true>, kPathBlock, 0) == hipSuccess && f >= 1 && f < per_cu) per_cu = f;
+    return per_cu;
+}
 int pipeline_blocks_per_cu() {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, 0>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
@@ -1159,7 +1489,11 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, false); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
     grid_mode &= ~kIntMask;
-    if (s->n_prefill) {       // buffers zeroed ahead of time (drt_prefill_zero): which of this call's outputs are they?
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    // (while a graph is being captured the buffers zeroed ahead of time stay registered: the capturing call brings its own outputs, and
+    // nothing outside the capture may be waited for inside it)
+    if (s->n_prefill && cap == hipStreamCaptureStatusNone) {       // buffers zeroed ahead of time (drt_prefill_zero): which of this call's outputs are they?
         int matched = 0;
         for (int k = 0; k < s->n_prefill; ++k) {
             const drt_scene::Prefill& f = s->prefill[k];
@@ -1183,12 +1517,16 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
         HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
+        bool finished = false;
         rc = launch_chunk<false>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
-                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h));
+                                 d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h),
+                                 st, b, d_valid_idx, &finished);
         if (rc) return rc;
-        { StageTimer t(s, w.stream, kStageFinish);
-          k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx); }
-        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 0, raster_on(s, n, tile_w, tile_h));
+        if (!finished) {
+            StageTimer t(s, w.stream, kStageFinish);
+            k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx);
+        }
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 0, raster_on(s, n, tile_w, tile_h), finished);
     }
     rc = join_streams(s, st, pl.streams);
     if (rc) return rc;
@@ -1337,7 +1675,9 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     hipStream_t st = (hipStream_t)stream;
     const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true); if (rc) return rc; }
-    if (s->n_prefill) {            // buffers zeroed ahead of time for a drt_render_forward that did not come: forgotten, their zeroing ordered in front of this stream's future
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (s->n_prefill && cap == hipStreamCaptureStatusNone) {   // buffers zeroed ahead of time for a drt_render_forward that did not come: forgotten, their zeroing ordered in front of this stream's future
         HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
         s->n_prefill = 0;
     }
@@ -1351,12 +1691,14 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
         HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
-        rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h));
+        bool finished = false;
+        rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h),
+                                st, b, nullptr, &finished);
         if (rc) return rc;
         { StageTimer t(s, w.stream, kStageLossBwdFused);
           k_loss_bwd_fused<<<DRT_BWD_BPC * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
                                                                d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
-        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1, raster_on(s, n, tile_w, tile_h));
+        if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1, raster_on(s, n, tile_w, tile_h), finished);
     }
     rc = join_streams(s, st, pl.streams);
     if (rc) return rc;

@@ -60,7 +60,8 @@ constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds th
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kRadix = 256;
 
 // stage ids of drt_profile_read
-enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kStageRaster, kStageFill, kProfStages };
+enum { kStageBuild = 0, kStageCull, kStageTrace1, kStageShade1, kStageTrace2, kStageShade2, kStageTrace3, kStageFinish, kStageCollect, kStageBackward, kStageLossBwdFused, kStageRaster, kStageFill, kStagePath, kProfStages };
+static_assert(kProfStages == DRT_PROFILE_STAGES, "include/drt_hip.h");
 
 struct BuildParams {   // written by k_bounds, read by the later build kernels
     float lox, loy, loz;
@@ -154,6 +155,9 @@ struct drt_scene {
     int grid_trace = 2048;         // resident blocks of the pure-traversal kernels
     int grid_path = 2048;          // resident 256-thread blocks of k_trace
     int64_t trace_stats[12] = {0};  // per k_trace stage: wave-steps, lane-steps, refills, max wave-steps (last profile read)
+    int grid_mega = 1024;          // resident 256-thread blocks of k_path
+    int64_t mega_max_rays = 1 << 24;  // sub-batches of at most this many camera rays run as ONE kernel (k_path); 0: never (DRT_MEGA_MAX_LOG2)
+    int shade_min = 8;             // k_path enters a float64 stage once this many lanes wait for one
     int refill_min = 32;           // k_trace refills a wave once this many lanes are idle
     int inner_min = 24;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
     int64_t chunk_rays = kChunkRays;
@@ -167,6 +171,7 @@ struct drt_scene {
 // occupancy of the persistent kernels (defined next to them: drt_trace.hip, drt_pipeline.hip)
 int query_blocks_per_cu();
 int pipeline_blocks_per_cu();
+int mega_blocks_per_cu();
 
 // defined in drt_raster.hip
 int ensure_raster(drt_scene* s, drt_scene::Sub& w, int64_t n_rays, int n_views, hipStream_t st);

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
     unsigned taken = 0;
     int32_t slot = -1;
     TravState s;
-    unsigned long long wave_steps = 0, lane_steps = 0, refills = 0;   // wave-uniform diagnostics (scalar registers)
+    unsigned long long wave_steps = 0, lane_steps = 0, leaf_steps = 0;   // wave-uniform diagnostics (scalar registers)
     for (;;) {
         const unsigned long long idle = __ballot(slot < 0);
         if (idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull)) {
@@ -94,7 +94,6 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                 }
             }
             taken += (unsigned)__popcll(idle);
-            ++refills;
         }
         const unsigned long long busy = __ballot(slot >= 0);
         if (busy == 0) break;
@@ -122,7 +121,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         const bool at_leaf = slot >= 0 && s.cur < 0;
         const unsigned long long ml = __ballot(at_leaf);
         if (ml != 0) {
-            ++wave_steps;
+            ++wave_steps; ++leaf_steps;
             lane_steps += (unsigned long long)__popcll(ml);
             if (at_leaf && trav_leaf<ANY>(c.tris, s, st)) {
                 trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
@@ -136,7 +135,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
     if (stats && lane == 0 && wave_steps) {
         atomicAdd(stats + 0, wave_steps);
         atomicAdd(stats + 1, lane_steps);
-        atomicAdd(stats + 2, refills);
+        atomicAdd(stats + 2, leaf_steps);
         atomicMax(stats + 3, wave_steps);
     }
 }

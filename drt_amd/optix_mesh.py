@@ -155,7 +155,7 @@ class optix_mesh:
             _lib.check(_lib.lib().drt_bvh_sorted_faces(self._h, out.data_ptr(), _stream()))
         return out
 
-    STAGES = ("build", "cull", "trace1", "shade1", "trace2", "shade2", "trace3", "finish", "collect", "backward", "loss_bwd_fused", "raster", "fill")
+    STAGES = ("build", "cull", "trace1", "shade1", "trace2", "shade2", "trace3", "finish", "collect", "backward", "loss_bwd_fused", "raster", "fill", "path")
 
     def profile_enable(self, on=1):
         """1: bracket every pipeline kernel with hipEvents on its launch stream (bench.py's live timing);

@@ -300,10 +300,11 @@ int drt_subdivide_midpoint(const int64_t* d_faces, int64_t n_faces, const double
  * items (rays in the stage's input queue) since the previous read.  Arrays have DRT_PROFILE_STAGES
  * entries: 0 build, 1 cull, 2 trace1, 3 shade1, 4 trace2, 5 shade2, 6 trace3 (occlusion),
  * 7 finish, 8 collect (backward compaction when no list was saved), 9 backward,
- * 10 fused loss+backward, 11 projected primary visibility (fit + raster kernels), 12 pre-fill of the dense outputs (memsets, DRT_GRID_TRUST).  The event pool grows with the number of launches between two reads; if it could not
+ * 10 fused loss+backward, 11 projected primary visibility (fit + raster kernels), 12 pre-fill of the dense outputs (memsets, DRT_GRID_TRUST),
+ * 13 the one-kernel path of small sub-batches (k_path: stages 3-7 in one launch; their rows then only carry item counts).  The event pool grows with the number of launches between two reads; if it could not
  * (allocation failure), drt_profile_read FAILS (DRT_E_INVALID, message with the number of lost timings) instead
  * of returning under-reported stage times. */
-#define DRT_PROFILE_STAGES 13
+#define DRT_PROFILE_STAGES 14
 int drt_profile_enable(drt_scene_t* s, int on);
 /* Which stages are timed while the profile is on: bit k = stage k of the list above (default: all).  Every timed launch costs
  * two event records on its stream (~1.5 us each inside a step of ~100 launches): a measurement that only needs the traversal
@@ -312,7 +313,8 @@ int drt_profile_select(drt_scene_t* s, uint32_t stage_mask);
 int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int64_t* items_out);
 /* Traversal diagnostics of the last drt_profile_read interval, 4 values for each of the three
  * k_trace stages: node visits summed over wavefronts ("wave-steps"), over lanes ("lane-steps";
- * lane-steps / (64 * wave-steps) = SIMD lane utilisation), lane refills, longest wavefront. */
+ * lane-steps / (64 * wave-steps) = SIMD lane utilisation), the wave-steps that were leaf (triangle) visits
+ * (the others are inner-node visits), longest wavefront. */
 int drt_profile_trace_stats(drt_scene_t* s, int64_t* out12);
 
 /* Debug builds (hipcc -DDRT_CHECK=1): the persistent traversal kernels assert the invariants of their bound-check-free LDS stack

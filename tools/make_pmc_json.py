@@ -36,6 +36,14 @@ try:
 except Exception:
     res = {}
 res[mode] = out
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from drt_amd import build as _build  # noqa: E402
+import subprocess  # noqa: E402
+res["source_sha256"] = _build.source_hash()          # bench.py refuses to price live launch times against counters of other kernels
+try:
+    res["git_head"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+except Exception:
+    res["git_head"] = None
 res["workload"] = os.environ.get("PMC_WORKLOAD", "horse res 1024 views 72 streams default")
 res["note"] = ("per-launch means from separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-extras --random-targets` "
                "(tools/profile.sh); SQ_* cycle counters are quad-cycles; FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte requests as 64, "
