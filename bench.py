@@ -642,9 +642,11 @@ def main():
             out["establish_mode"] = establish_extra
         if tight_extra:
             out["tight_framing"] = tight_extra
+        if tstats.get("trace2", (0,))[0] and "path" in out["roofline"]["stages"] and "trace2" not in out["roofline"]["stages"]:
+            tstats["path"] = tstats.pop("trace2")         # (k_path reports in trace2's slot)
         for k, (ws, ls, lf, mx) in tstats.items():
             if ws and k in out["roofline"]["stages"]:
-                out["roofline"]["stages"][k].update({"node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),
+                out["roofline"]["stages"][k].update({"wave_steps": ws, "node_visits_per_ray": round(ls / max(1, prof2[k][2]), 2),
                                                      "lane_utilisation": round(ls / (64.0 * ws), 3), "longest_wave_visits": mx})
         if fused_extra:
             out["fused_mode"] = fused_extra

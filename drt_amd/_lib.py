@@ -45,7 +45,7 @@ SIGNATURES = {
     "drt_dihedral_backward": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
     "drt_sm_loss_fused": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
     "drt_silhouette_flags": (_c.c_int, [_P, _P, _I64, _P, _P, _P]),
-    "drt_edge_sample_forward": (_c.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P]),
+    "drt_edge_sample_forward": (_c.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _P]),
     "drt_edge_sample_backward": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _c.c_int, _P, _P]),
     "drt_edge_tables_workspace": (_I64, [_I64]),
     "drt_edge_tables": (_c.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),

@@ -38,6 +38,12 @@ int drt_create(int device, drt_scene_t** out) {
     s->device = device;
     hipError_t e = hipMalloc(&s->params, sizeof(BuildParams));
     if (e == hipSuccess) e = hipMalloc(&s->scratch, sizeof(unsigned long long) * 8);
+    if (e == hipSuccess) e = hipMalloc(&s->bounds_acc, sizeof(uint32_t) * 12);
+    if (e == hipSuccess) {
+        const uint32_t init[12] = {0xFF800000u, 0xFF800000u, 0xFF800000u, 0x007FFFFFu, 0x007FFFFFu, 0x007FFFFFu,
+                                   0xFF800000u, 0xFF800000u, 0xFF800000u, 0x007FFFFFu, 0x007FFFFFu, 0x007FFFFFu};     // +inf / -inf in k_cast_verts' ordered encoding
+        e = hipMemcpy(s->bounds_acc, init, sizeof(init), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->build_stream, hipStreamNonBlocking);
@@ -57,7 +63,7 @@ int drt_create(int device, drt_scene_t** out) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w.fill_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&w.fill_join, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * 8);
+        if (e == hipSuccess) e = hipMalloc(&w.qcount, sizeof(unsigned) * kQCount);
         if (e == hipSuccess) e = hipMalloc(&w.slow_stack, sizeof(int32_t) * (size_t)kRedoGrid * kTraceBlock * kStackSlowDev);
     }
     if (e == hipSuccess) {
@@ -75,6 +81,7 @@ int drt_create(int device, drt_scene_t** out) {
         if (const char* e = getenv("DRT_MEGA_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) s->grid_mega = v * s->n_cu; }
         if (const char* e = getenv("DRT_MEGA_MAX_LOG2")) { const int v = atoi(e); s->mega_max_rays = v <= 0 ? 0 : (v <= 31 ? (int64_t)1 << v : (int64_t)1 << 31); }
         if (const char* e = getenv("DRT_SHADE_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->shade_min = v; }
+        if (const char* e = getenv("DRT_MEGA_REFILL_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->mega_refill_min = v; }
         // tuning knobs (measurement only; defaults are the tuned values)
         if (const char* e = getenv("DRT_TRACE_BPC")) { const int v = atoi(e); if (v >= 1 && v * s->n_cu * 2 <= kTraceGridMax) s->grid_path = v * s->n_cu; }
         if (const char* e = getenv("DRT_INNER_MIN")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->inner_min = v; }
@@ -99,13 +106,13 @@ void drt_destroy(drt_scene_t* s) {
     if (s->build_stream) (void)hipStreamDestroy(s->build_stream);
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
-    (void)hipFree(s->scratch);
+    (void)hipFree(s->scratch); (void)hipFree(s->bounds_acc);
     (void)hipFree(s->b1_list); (void)hipFree(s->b1_redo); (void)hipFree(s->b1_count);
     for (int j = 0; j < drt_scene::kMaxSub; ++j) {
         drt_scene::Sub& w = s->sub[j];
         for (int k = 0; k < 3; ++k) { (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]); }
         (void)hipFree(w.tmp_face1); (void)hipFree(w.tmp_face2); (void)hipFree(w.qcount); (void)hipFree(w.slow_stack); (void)hipFree(w.redo);
-        (void)hipFree(w.zbuf); (void)hipFree(w.zmask); (void)hipFree(w.vmodel); (void)hipFree(w.big); (void)hipFree(w.big_count); (void)hipFree(w.gen_list);
+        (void)hipFree(w.zbuf); (void)hipFree(w.zmask); (void)hipFree(w.vmodel); (void)hipFree(w.big); (void)hipFree(w.big_count); (void)hipFree(w.gen_list); (void)hipFree(w.ray64);
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.fill_fork) (void)hipEventDestroy(w.fill_fork);
         if (w.fill_join) (void)hipEventDestroy(w.fill_join);

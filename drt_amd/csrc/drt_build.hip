@@ -17,9 +17,56 @@ void scene_free_mesh(drt_scene* s) {
 // ------------------------------------------------------------------------------------------
 // build kernels
 // ------------------------------------------------------------------------------------------
-__global__ void k_cast_verts(const double* __restrict__ v64, float* __restrict__ v32, int64_t n3) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x)
-        v32[i] = (float)v64[i];
+// float <-> unsigned with the same order (atomicMin / atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t f32_ordered(float f) { const uint32_t b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ float f32_unordered(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+constexpr uint32_t kOrdPosInf = 0xFF800000u, kOrdNegInf = 0x007FFFFFu;      // f32_ordered(+inf), f32_ordered(-inf)
+
+// float64 -> float32 vertices (Scene.update_verticex, reference DiffRender.py:379) AND, in the same pass, the scene box the Morton keys are
+// normalised with: every block reduces its elements and folds them into six accumulators, so that the build needs no single-block
+// pass over the vertices (k_bounds: 16 us of latency in front of a ~0.15 ms build).  `acc`: this build's accumulators, `acc_next`: the
+// other half, reset here for the NEXT build (the previous build, which read it, has been waited for); `hist_zero`: the digit
+// histograms of the fused sort.
+__global__ void __launch_bounds__(256) k_cast_verts(const double* __restrict__ v64, float* __restrict__ v32, int64_t n3, uint32_t* acc, uint32_t* acc_next,
+                                                    uint32_t* __restrict__ hist_zero, int hist_entries) {
+    __shared__ float red[6][4];
+    if (blockIdx.x == 0 && threadIdx.x < 6 && acc_next) acc_next[threadIdx.x] = threadIdx.x < 3 ? kOrdPosInf : kOrdNegInf;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hist_entries; i += (int64_t)gridDim.x * blockDim.x) hist_zero[i] = 0u;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    // a thread takes whole vertices (three consecutive values), so that its three running bounds are per axis
+    const int64_t n = n3 / 3;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+        for (int a = 0; a < 3; ++a) {
+            const float f = (float)v64[3 * v + a];
+            v32[3 * v + a] = f;
+            lo[a] = fminf(lo[a], f); hi[a] = fmaxf(hi[a], f);
+        }
+    }
+    if (!acc) return;
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off >= 1; off >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float v = red[a][0];
+        for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[a][w]) : fmaxf(v, red[a][w]);
+        if (a < 3) { if (v < INFINITY) atomicMin(&acc[a], f32_ordered(v)); }
+        else if (v > -INFINITY) atomicMax(&acc[a], f32_ordered(v));
+    }
+}
+
+// BuildParams from the scene box (what k_bounds' last thread does)
+__device__ __forceinline__ void params_from_box(const float* lo, const float* hi, BuildParams* out) {
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    out->lox = lo[0]; out->loy = lo[1]; out->loz = lo[2];
+    out->ix = ex > 0.f ? 1.0f / ex : 0.f;
+    out->iy = ey > 0.f ? 1.0f / ey : 0.f;
+    out->iz = ez > 0.f ? 1.0f / ez : 0.f;
+    out->pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
+    out->reserved = 0;
+    out->plan = morton_plan(ex, ey, ez);
 }
 
 // One block: scene box over all vertices -> Morton normalisation + leaf padding.
@@ -64,14 +111,8 @@ __global__ void __launch_bounds__(1024) k_bounds(const float* __restrict__ verts
                 red[a][0] = fminf(red[a][0], red[a][w]);
                 red[3 + a][0] = fmaxf(red[3 + a][0], red[3 + a][w]);
             }
-        const float ex = red[3][0] - red[0][0], ey = red[4][0] - red[1][0], ez = red[5][0] - red[2][0];
-        out->lox = red[0][0]; out->loy = red[1][0]; out->loz = red[2][0];
-        out->ix = ex > 0.f ? 1.0f / ex : 0.f;
-        out->iy = ey > 0.f ? 1.0f / ey : 0.f;
-        out->iz = ez > 0.f ? 1.0f / ez : 0.f;
-        out->pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
-        out->reserved = 0;
-        out->plan = morton_plan(ex, ey, ez);
+        const float lo3[3] = {red[0][0], red[1][0], red[2][0]}, hi3[3] = {red[3][0], red[4][0], red[5][0]};
+        params_from_box(lo3, hi3, out);
     }
 }
 
@@ -79,16 +120,31 @@ __device__ __forceinline__ f3 ld_vert(const float* __restrict__ verts, int32_t i
     return f3{verts[3 * (int64_t)i], verts[3 * (int64_t)i + 1], verts[3 * (int64_t)i + 2]};
 }
 
-__global__ void k_morton(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n,
-                         const BuildParams* __restrict__ bp, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
-                         uint32_t* hist0, int tiles) {
+// `acc` non-null: the scene box comes from k_cast_verts' accumulators -- every block derives the BuildParams from them (one thread,
+// ~1 us) and block 0 also stores them for the later build kernels; otherwise `bp` was written by k_bounds.
+// `drop`: low key bits cleared.  Meshes small enough for the fused sort keep 24 of the 30 key bits (256^3 cells for <= 262 144 triangles
+// on a surface: still almost one triangle per occupied cell; equal keys are ordered by face id either way) -- one radix pass less.
+__global__ void __launch_bounds__(256) k_morton(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n,
+                         BuildParams* bp, const uint32_t* __restrict__ acc, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                         uint32_t* hist0, int tiles, int drop) {
+    __shared__ BuildParams s_bp;
+    if (acc) {
+        if (threadIdx.x == 0) {
+            float lo3[3], hi3[3];
+            for (int a = 0; a < 3; ++a) { lo3[a] = f32_unordered(acc[a]); hi3[a] = f32_unordered(acc[3 + a]); }
+            params_from_box(lo3, hi3, &s_bp);
+            if (blockIdx.x == 0) *bp = s_bp;
+        }
+        __syncthreads();
+    }
+    const BuildParams* q = acc ? &s_bp : bp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const f3 a = ld_vert(verts, faces[3 * i]), b = ld_vert(verts, faces[3 * i + 1]), c = ld_vert(verts, faces[3 * i + 2]);
-    const uint32_t key = morton_key(a, b, c, f3{bp->lox, bp->loy, bp->loz}, f3{bp->ix, bp->iy, bp->iz}, bp->plan);
+    const uint32_t key = morton_key(a, b, c, f3{q->lox, q->loy, q->loz}, f3{q->ix, q->iy, q->iz}, q->plan) & ~((1u << drop) - 1u);
     keys[i] = key;
     idx[i] = (uint32_t)i;
-    if (hist0) atomicAdd(&hist0[(key & (kRadix - 1)) * tiles + i / kSortTile], 1u);   // first pass of the fused sort
+    if (hist0) atomicAdd(&hist0[((key >> drop) & (kRadix - 1)) * tiles + i / kSortTile], 1u);   // first pass of the fused sort
 }
 
 // Fused pass for small meshes (tiles <= kSortFusedTiles): the per-tile digit offsets are derived inside the scatter
@@ -347,7 +403,8 @@ int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
     return DRT_OK;
 }
 
-static int rebuild_impl(drt_scene* s, hipStream_t st) {
+// `acc`: scene-box accumulators filled by k_cast_verts on the way in (which also zeroed the sort histograms); null: k_bounds does both.
+static int rebuild_impl(drt_scene* s, hipStream_t st, const uint32_t* acc) {
     const int n = (int)s->n_faces;
     s->built = true;
     s->order_valid = false;
@@ -355,13 +412,15 @@ static int rebuild_impl(drt_scene* s, hipStream_t st) {
     const int tiles = (n + kSortTile - 1) / kSortTile;
     const bool fused_sort = tiles <= kSortFusedTiles;
     const int table = kRadix * tiles;
-    k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params, s->hist, fused_sort ? 4 * table : 0);
-    k_morton<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->params, s->keys[0], s->idx[0], fused_sort ? s->hist : nullptr, tiles);
+    const int drop = fused_sort ? 6 : 0;               // 24-bit keys, three radix passes (see k_morton)
+    const int last_pass = fused_sort ? 2 : 3;
+    if (!acc) k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params, s->hist, fused_sort ? 4 * table : 0);
+    k_morton<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->params, acc, s->keys[0], s->idx[0], fused_sort ? s->hist : nullptr, tiles, drop);
     int cur = 0;
-    for (int shift = 0, pass = 0; shift < 30; shift += 8, ++pass) {
+    for (int shift = drop, pass = 0; shift < 30; shift += 8, ++pass) {
         if (fused_sort) {
             k_sort_pass_fused<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], s->idx[cur], s->keys[cur ^ 1], s->idx[cur ^ 1], n, shift,
-                                                            s->hist + pass * table, pass < 3 ? s->hist + (pass + 1) * table : nullptr, tiles);
+                                                            s->hist + pass * table, pass < last_pass ? s->hist + (pass + 1) * table : nullptr, tiles);
         } else {
             k_sort_hist<<<tiles, kSortBlock, 0, st>>>(s->keys[cur], n, shift, s->hist, tiles);
             k_sort_scan<<<1, 1024, 0, st>>>(s->hist, kRadix * tiles);
@@ -369,14 +428,15 @@ static int rebuild_impl(drt_scene* s, hipStream_t st) {
         }
         cur ^= 1;
     }
-    // four passes -> result is back in buffer 0
+    // (four passes end in buffer 0, three in buffer 1)
     const int inner = n > 1 ? n - 1 : 1;
     k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags, s->range_lo, s->range_hi);
     k_refit<<<(n + 255) / 256, 256, 0, st>>>(s->idx[cur], s->faces, s->verts, n, s->params, s->tris, s->nodes,
                                              s->parent_inner, s->parent_leaf, s->flags);
     k_collapse4<<<(inner + 255) / 256, 256, 0, st>>>(s->nodes, s->parent_inner, s->range_lo, s->range_hi, n, s->wide);
     HIP_TRY(hipGetLastError());
-    s->order_valid = cur == 0;       // idx[0] = the face ids in Morton order, kept until the next build starts
+    s->order_valid = true;           // idx[cur] = the face ids in Morton order, kept until the next build starts
+    s->sorted_buf = cur;
     return DRT_OK;
 }
 
@@ -398,11 +458,11 @@ __global__ void k_tri_flat(const int32_t* __restrict__ faces, const float* __res
 // scene's own stream, after the vertices are in place on the caller's stream, and every consumer of the tree waits for
 // `build_done` (wait_build): the next render call's output fills and projection pass, which only need the flat triangle
 // records written here, overlap it.
-int rebuild(drt_scene* s, hipStream_t st) {
+int rebuild(drt_scene* s, hipStream_t st, const uint32_t* acc) {
     const int n = (int)s->n_faces;
-    // (the previous build's sorted ids are still in idx[0]: this launch precedes the fork of the build stream, whose k_morton
-    // overwrites them)
-    if (n > 0) k_tri_flat<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->tris_flat, s->order_valid ? s->idx[0] : nullptr);
+    // (the previous build's sorted ids are still in idx[sorted_buf]: this launch precedes the fork of the build stream, whose k_morton /
+    // sort passes overwrite them)
+    if (n > 0) k_tri_flat<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->tris_flat, s->order_valid ? s->idx[s->sorted_buf] : nullptr);
     hipStream_t bs = s->async_build ? s->build_stream : st;
     if (bs != st) {
         HIP_TRY(hipEventRecord(s->build_fork, st));
@@ -410,7 +470,7 @@ int rebuild(drt_scene* s, hipStream_t st) {
     }
     int rc;
     { StageTimer t(s, bs, kStageBuild);
-      rc = rebuild_impl(s, bs); }
+      rc = rebuild_impl(s, bs, acc); }
     if (bs != st) HIP_TRY(hipEventRecord(s->build_done, bs));
     s->build_pending = bs != st;
     return rc;
@@ -445,7 +505,7 @@ int drt_update_mesh(drt_scene_t* s, const int32_t* d_faces, int64_t n_faces, con
     s->order_valid = false;          // new topology: the previous build's order is not a permutation of these faces
     if (n_faces) HIP_TRY(hipMemcpyAsync(s->faces, d_faces, sizeof(int32_t) * 3 * n_faces, hipMemcpyDeviceToDevice, st));
     if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
-    return rebuild(s, st);
+    return rebuild(s, st, nullptr);
 }
 
 int drt_update_vert(drt_scene_t* s, const float* d_verts, int64_t n_verts, void* stream) {
@@ -455,7 +515,7 @@ int drt_update_vert(drt_scene_t* s, const float* d_verts, int64_t n_verts, void*
     int rc = begin_update(s, st);
     if (rc) return rc;
     if (n_verts) HIP_TRY(hipMemcpyAsync(s->verts, d_verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, st));
-    return rebuild(s, st);
+    return rebuild(s, st, nullptr);
 }
 
 int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, void* stream) {
@@ -464,8 +524,18 @@ int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, 
     hipStream_t st = (hipStream_t)stream;
     int rc = begin_update(s, st);
     if (rc) return rc;
-    if (n_verts) k_cast_verts<<<grid_for(3 * n_verts, 256, 1024), 256, 0, st>>>(d_verts, s->verts, 3 * n_verts);
-    return rebuild(s, st);
+    const uint32_t* acc = nullptr;
+    if (n_verts) {
+        // the cast also gathers the scene box and zeroes the fused sort's histograms (both otherwise k_bounds' job, a single-block kernel)
+        const int tiles = (int)((s->n_faces + kSortTile - 1) / kSortTile);
+        const bool fused_sort = s->n_faces > 0 && tiles <= kSortFusedTiles;
+        uint32_t* mine = s->bounds_acc + 6 * s->bounds_par;
+        k_cast_verts<<<grid_for(n_verts, 256, 256), 256, 0, st>>>(d_verts, s->verts, 3 * n_verts, mine, s->bounds_acc + 6 * (s->bounds_par ^ 1),
+                                                                 s->hist, fused_sort ? 4 * kRadix * tiles : 0);
+        s->bounds_par ^= 1;
+        acc = mine;
+    }
+    return rebuild(s, st, acc);
 }
 
 int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height, int32_t* wide_depth) {
@@ -494,7 +564,7 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream) {
     CHECK_BUILT(s);
     if (s->n_faces && !d_order) return fail(DRT_E_INVALID, "d_order is null");
     { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
-    if (s->n_faces) HIP_TRY(hipMemcpyAsync(d_order, s->idx[0], sizeof(int32_t) * s->n_faces, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (s->n_faces) HIP_TRY(hipMemcpyAsync(d_order, s->idx[s->sorted_buf], sizeof(int32_t) * s->n_faces, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DRT_OK;
 }
 

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_silhouette_flags(const double* __restri
 __global__ void __launch_bounds__(kTraceBlock) k_edge_sample_fwd(TraceCtx c, const double* __restrict__ verts, const int64_t* __restrict__ edges,
                                                                   int64_t n, const Camera* __restrict__ cam, const double* __restrict__ origin3,
                                                                   int64_t* __restrict__ index, float* __restrict__ f_out,
-                                                                  uint8_t* __restrict__ keep, int resx, int resy) {
+                                                                  uint8_t* __restrict__ keep, int resx, int resy, const uint8_t* __restrict__ flags) {
     __shared__ int32_t lds[kStackFast][kTraceBlock];
     Stack st = make_stack(lds, c);
     const Camera cm = *cam;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_edge_sample_fwd(TraceCtx c, con
     const int side = threadIdx.x & 1;
     for (int64_t base = blockIdx.x * kPairs; base < n; base += (int64_t)gridDim.x * kPairs) {     // block-uniform trip count (shuffle below)
         const int64_t e = base + (threadIdx.x >> 1);
-        const bool live = e < n;
+        const bool live = e < n && (!flags || flags[e]);       // (`flags`: the edge list is ALL edges and only the flagged ones are silhouette edges)
         const int64_t el = live ? e : 0;
         Projected pa, pb;
         project_endpoint(cm, load_d3(verts, edges[2 * el]), pa);
@@ -266,7 +266,7 @@ int drt_silhouette_flags(const double* d_verts, const int64_t* d_e2f, int64_t n_
 }
 
 int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera,
-                            const double* d_origin3, int64_t* d_index, float* d_f, uint8_t* d_keep, int resx, int resy, void* stream) {
+                            const double* d_origin3, int64_t* d_index, float* d_f, uint8_t* d_keep, int resx, int resy, const uint8_t* d_flags, void* stream) {
     CHECK_BUILT(s);
     if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
     if (n_edges == 0) return DRT_OK;
@@ -274,7 +274,7 @@ int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t
     { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
     { int rc = ensure_slow_stack(s); if (rc) return rc; }
     k_edge_sample_fwd<<<grid_for(2 * n_edges, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(
-        trace_ctx(s), d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_origin3, d_index, d_f, d_keep, resx, resy);
+        trace_ctx(s), d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_origin3, d_index, d_f, d_keep, resx, resy, d_flags);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -27,6 +27,12 @@ struct RayList {
     float* ray;       // [cap,6] float32 origin, direction -- exactly what the tracer sees
     int32_t* face;    // [cap] traversal result
 };
+// where the float64 refracted ray of ray i is parked between bounce #1 (k_shade1 / k_gen_late) and bounce #2 inside k_path: rows of the
+// dense outputs themselves (overwritten by the exit ray or by zeros later), or a side buffer in the fused form; null for the staged kernels
+struct Ray64 {
+    double* o;      // [N,3]
+    double* d;      // [N,3]
+};
 struct Pipe {
     RayList r0, r1, r2;
     unsigned* count;   // [0..2] list sizes of the sub-batch in flight, [4..6] rays handed to k_trace_redo per stage
@@ -395,7 +401,7 @@ template <bool FUSED>
 __global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
                                                         int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p,
-                                                        bool prefilled /* the dense outputs hold (or are being filled with) the dead values */) {
+                                                        bool prefilled /* the dense outputs hold (or are being filled with) the dead values */, Ray64 r64) {
     __shared__ StageMem stage;
     stage_init(stage);
     const unsigned n0 = p.count[0];
@@ -419,6 +425,7 @@ __global__ void __launch_bounds__(kPathBlock) k_shade1(PathCtx c, const double* 
                 bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
                 ok = !b.tir;
                 o2 = to_f32(b.new_o); d2 = to_f32(b.wt);
+                if (ok && r64.o) { store_d3(r64.o, i, b.new_o); store_d3(r64.d, i, b.wt); }
             }
             if (!ok && !FUSED && f1 != kFacePending) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
         }
@@ -437,7 +444,7 @@ template <bool FUSED>
 __global__ void __launch_bounds__(kTraceBlock) k_gen_late(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                           double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
                                                           int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p,
-                                                          const int32_t* __restrict__ gen_list, bool prefilled) {
+                                                          const int32_t* __restrict__ gen_list, bool prefilled, Ray64 r64) {
     __shared__ int32_t lds[kStackFast][kTraceBlock];
     const unsigned n = p.count[3];
     if (n == 0) return;
@@ -462,6 +469,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_gen_late(PathCtx c, const doubl
                 const unsigned s1 = atomicAdd(&p.count[1], 1u);
                 p.r1.idx[s1] = (int32_t)i;
                 store_ray32(p.r1.ray, (int)s1, to_f32(b.new_o), to_f32(b.wt));
+                if (r64.o) { store_d3(r64.o, i, b.new_o); store_d3(r64.d, i, b.wt); }
             }
         }
         if (!ok && !FUSED) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
@@ -536,22 +544,25 @@ __global__ void __launch_bounds__(kPathBlock) k_finish(double* __restrict__ out_
     if (valid_idx) stage_flush(stage, out, p.valid);
 }
 
-// ---- the same path as ONE persistent kernel (small sub-batches) ----------------------------------------------------------
+// ---- the back half of the path as ONE persistent kernel (small sub-batches) ----------------------------------------------
 //
 // Below ~2^24 camera rays a sub-batch has fewer rays in flight than the chip has lanes: every k_trace launch is then as long as
 // its slowest wavefront (one 64-ray group per wave, ~0.7 us per dependent load -> slab test -> push step, 150-230 steps), the
-// staged pipeline pays that tail twice (refracted rays, exit rays) plus five dependent launches in between, and the SIMDs sit
-// idle under both tails.  k_path runs R0 -> outputs in one launch: a LANE carries its ray through
-//     [T0: primary hit through the tree -- only for rays the projection pass did not answer]
-//     S1: float64 bounce #1 -> T1: closest hit of the refracted ray -> S2: bounces #1 + #2, provisional outputs
+// staged pipeline pays that tail twice (refracted rays, exit rays) plus four dependent launches in between, and the SIMDs sit
+// idle under both tails.  k_path runs R1 -> outputs in one launch: a LANE carries its ray through
+//     T1: closest hit of the refracted ray -> S2: float64 bounce #2, provisional outputs
 //     -> T2: occlusion test of the exit ray -> finish (survivor -> list of valid rays; occluded -> dead values)
-// and takes the next R0 entry of its wave's segment when it is through, so the occlusion rays of early finishers are traced
-// under the tail of the refracted rays of the others.  The traversal phases are k_trace's ("while-while": lanes at inner nodes
-// descend together, lanes at leaves wait for a common triangle step; LDS-only stack with a redo list); the float64 stages run as
-// wave phases in between, entered when `shade_min` lanes wait for one (or nothing else can run).  T2 uses the closest-hit child
-// order (one code path for all traversing lanes) and stops at its first hit; results are those of the staged kernels bit for bit
-// (same device functions, same writes).  ~2x the registers of k_trace (4 waves per SIMD): chosen for small sub-batches only.
-enum : int { kLaneIdle = 0, kLaneS1 = 1, kLaneT0 = 2, kLaneT0D = 3, kLaneT1 = 4, kLaneT1D = 5, kLaneT2 = 6, kLaneT2D = 7 };   // odd = waits for a float64 stage
+// and takes another R1 entry when it is through, so the occlusion rays of early finishers are traced under the tail of the
+// refracted rays of the others.  Rays are handed out DYNAMICALLY (a cursor per XCD part of the list, bumped by as many entries as a
+// wave has idle lanes), so that no wave is left with a second whole group when the others are done.  The traversal phases are
+// k_trace's ("while-while": lanes at inner nodes descend together, lanes at leaves wait for a common triangle step; LDS-only stack
+// with a redo list); the float64 stages run as wave phases in between, entered when `shade_min` lanes wait for one (or nothing
+// else can run).  T2 uses the closest-hit child order (one code path for all traversing lanes) and stops at its first hit.
+// Bounce #1 stays a kernel of its own (k_shade1): it needs no tree, so it runs while the asynchronous build finishes, and it parks
+// the float64 refracted ray of every R1 entry in `ray64` (rows of the dense outputs themselves, or a side buffer in the fused form)
+// so that S2 is ONE bounce.  Results are those of the staged kernels bit for bit (same device functions, same final writes).
+// ~2x the registers of k_trace (4 waves per SIMD): chosen for small sub-batches only.
+enum : int { kLaneIdle = 0, kLaneT1 = 2, kLaneT1D = 3, kLaneT2 = 4, kLaneT2D = 5 };   // odd = waits for a float64 stage
 constexpr int kVBuf = 128;            // finished rays staged per wave before one list reservation
 
 template <class STACK>
@@ -574,33 +585,38 @@ __device__ __forceinline__ bool path_leaf(const TriRec* __restrict__ tris, TravS
 }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
-                                                        double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                        int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int64_t chunk_base,
-                                                        int32_t* __restrict__ valid_idx, bool prefilled, bool all_pending,
-                                                        int refill_min, int inner_min, int shade_min, unsigned long long* stats, bool count_items) {
+__global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, Ray64 r64, double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                        int32_t* __restrict__ face2, Pipe p, unsigned* cursor /* [8], zero */, int64_t chunk_base,
+                                                        int32_t* __restrict__ valid_idx, int refill_min, int inner_min, int shade_min,
+                                                        unsigned long long* stats, bool count_items) {
     __shared__ int32_t lds[kStackFast + 1 + kGuardRows][kPathBlock];
     __shared__ int32_t s_vbuf[kPathWaves][kVBuf];
-    __shared__ double s_ray2[6][kPathBlock];           // the refracted ray of bounce #1 in float64, parked per lane while T1 runs: S2 then does ONE bounce
     FastStack st;
     st.base = (drt::FastPtr)&lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast - 3; st.reset(); st.overflow = false;
 #if defined(DRT_CHECK)
     for (int g = 0; g < kGuardRows; ++g) lds[kStackFast + 1 + g][threadIdx.x] = kGuardPoison;
 #endif
-    const unsigned n = p.count[0];
+    const unsigned n = p.count[1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lower = (1ull << lane) - 1ull;
-    // the segment of R0 this wave owns: as in k_trace (8 contiguous parts of the tile-ordered list, one per XCD; groups of 64 entries interleaved over the part's waves)
+    // R1 (tile order) in 8 contiguous parts, one per XCD (block b runs on XCD b % 8; each XCD has its own L2).  Within a part every wave
+    // starts with the 64 entries at 64 x its number; what is left is handed out through the part's cursor.
     constexpr unsigned kXcd = 8;
-    const unsigned n_groups = (n + 63u) >> 6;
-    const bool split = gridDim.x % kXcd == 0 && n_groups >= 64u * kXcd;
+    const bool split = gridDim.x % kXcd == 0 && n >= 4096u * kXcd;
     const unsigned xcd = split ? blockIdx.x % kXcd : 0u, parts = split ? kXcd : 1u;
     const unsigned wave = (split ? blockIdx.x / kXcd : blockIdx.x) * kPathWaves + (threadIdx.x >> 6);
     const unsigned n_waves = (split ? gridDim.x / kXcd : gridDim.x) * kPathWaves;
-    const unsigned part_lo = (unsigned)((unsigned long long)n_groups * xcd / parts), part_hi = (unsigned)((unsigned long long)n_groups * (xcd + 1) / parts);
-    const unsigned part_groups = part_hi - part_lo;
-    const unsigned my_groups = wave < part_groups ? (part_groups - wave + n_waves - 1) / n_waves : 0u;
-    const unsigned my_rays = my_groups << 6;
+    const unsigned part_lo = (unsigned)((unsigned long long)n * xcd / parts), part_hi = (unsigned)((unsigned long long)n * (xcd + 1) / parts);
+    // the first share of a wave is static; it shrinks below 64 when the list is short, so that every wave of the grid gets some
+    const unsigned part_n = part_hi - part_lo;
+    unsigned first = (part_n + n_waves - 1) / n_waves;
+    first = first > 64u ? 64u : (first < 8u ? 8u : first);
+    unsigned my_next = part_lo + wave * first;         // next entry of the static share
+    unsigned my_end = my_next + first;
+    if (my_end > part_hi) my_end = part_hi;
+    if (my_next > part_hi) my_next = part_hi;
+    const unsigned dyn_lo = part_lo + n_waves * first; // entries beyond the static shares
+    bool dry = dyn_lo >= part_hi;                      // nothing (left) to hand out dynamically
     // finished rays: the caller's list of valid rays (global index) or, fused, list R2 for k_loss_bwd_fused (index; face < 0 = "not occluded")
     int32_t* const v_out = FUSED ? p.r2.idx : valid_idx;
     unsigned* const v_count = FUSED ? &p.count[2] : p.valid;
@@ -616,38 +632,45 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double*
         }
         vn = 0;
     };
-    unsigned taken = 0;
     int stage = kLaneIdle;
-    int32_t rk = 0, ri = 0;                            // R0 slot and ray index of this lane's ray
+    int32_t rk = 0, ri = 0;                            // R1 slot and ray index of this lane's ray
     TravState s;
     s.cur = 0; s.best_face = -1; s.best_t = 0.f;
     unsigned long long wave_steps = 0, lane_steps = 0, leaf_steps = 0;
-    unsigned n_t1 = 0, n_t2 = 0;
+    unsigned n_t2 = 0;
     for (;;) {
-        // ---- refill: idle lanes take the next R0 entries of the segment
+        // ---- refill: idle lanes take R1 entries -- the rest of the static share first, then from the part's cursor
         const unsigned long long idle = __ballot(stage == kLaneIdle);
-        if (idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull)) {
-            if (stage == kLaneIdle) {
-                const unsigned j = taken + (unsigned)__popcll(idle & lower);
-                const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
-                if (j < my_rays && k < n) {
-                    rk = (int32_t)k;
-                    ri = p.r0.idx[k];
-                    const int32_t f1 = all_pending ? kFacePending : p.r0.face[k];
-                    if (f1 == kFacePending) {
-                        const float* e = p.r0.ray + 6 * (int64_t)k;
-                        trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
-                        st.overflow = false;
-                        stage = kLaneT0;
-                    } else {
-                        s.best_face = f1;
-                        stage = kLaneS1;
-                    }
-                }
+        if (idle != 0 && (my_next < my_end || !dry) && ((int)__popcll(idle) >= refill_min || idle == ~0ull)) {
+            const unsigned want = (unsigned)__popcll(idle);
+            unsigned base, got;
+            if (my_next < my_end) {
+                base = my_next;
+                got = my_end - my_next < want ? my_end - my_next : want;
+                my_next += got;
+            } else {
+                unsigned b0 = 0;
+                if (lane == 0) b0 = atomicAdd(&cursor[xcd], want);
+                b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b0);
+                base = dyn_lo + b0;
+                got = base >= part_hi ? 0u : (part_hi - base < want ? part_hi - base : want);
+                if (got < want) dry = true;
             }
-            taken += (unsigned)__popcll(idle);
+            const unsigned r = (unsigned)__popcll(idle & lower);
+            if (stage == kLaneIdle && r < got) {
+                const unsigned k = base + r;
+                rk = (int32_t)k;
+                ri = p.r1.idx[k];
+                const float* e = p.r1.ray + 6 * (int64_t)k;
+                trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+                st.overflow = false;
+                stage = kLaneT1;
+            }
         }
-        if (__ballot(stage != kLaneIdle) == 0) break;
+        if (__ballot(stage != kLaneIdle) == 0) {
+            if (my_next < my_end || !dry) continue;    // (all lanes idle: the refill above runs whatever refill_min says)
+            break;
+        }
         // ---- float64 stages, when enough lanes wait for one or nothing can be traversed meanwhile
         {
             const unsigned long long waiting = __ballot(stage & 1), walking = __ballot(stage != kLaneIdle && !(stage & 1));
@@ -666,33 +689,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double*
                     }
                 }
                 if (fin) stage = kLaneIdle;
-                // bounce #1 (k_shade1): a primary hit is known (from the projection pass, or just found in the tree)
-                if (stage == kLaneS1 || stage == kLaneT0D) {
-                    const int32_t f1 = s.best_face;
-                    if (stage == kLaneT0D) p.r0.face[rk] = f1;
-                    face1[ri] = f1;
-                    bool ok = false;
-                    if (f1 >= 0) {
-                        d3 v0, v1, v2;
-                        int32_t vid[3];
-                        Bounce b;
-                        load_tri64(c, f1, v0, v1, v2, vid);
-                        bounce_forward(load_d3(origin, ri), load_d3(dir, ri), v0, v1, v2, c.ior_ext, c.ior_int, b);
-                        ok = !b.tir;
-                        if (ok) {
-                            trav_init(s, st, to_f32(b.new_o), to_f32(b.wt));
-                            st.overflow = false;
-                            stage = kLaneT1;
-                            s_ray2[0][threadIdx.x] = b.new_o.x; s_ray2[1][threadIdx.x] = b.new_o.y; s_ray2[2][threadIdx.x] = b.new_o.z;
-                            s_ray2[3][threadIdx.x] = b.wt.x; s_ray2[4][threadIdx.x] = b.wt.y; s_ray2[5][threadIdx.x] = b.wt.z;
-                            ++n_t1;
-                        }
-                    }
-                    if (!ok) {
-                        if (!FUSED) { if (prefilled) face2[ri] = -1; else write_dead(ri, out_ori, out_dir, mask, face2); }
-                        stage = kLaneIdle;
-                    }
-                } else if (stage == kLaneT1D) {
+                if (stage == kLaneT1D) {
                     // bounce #2 (k_shade2, which recomputes bounce #1 to the same bits): the second hit is in
                     const int32_t f2 = s.best_face;
                     bool ok = false;
@@ -700,8 +697,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double*
                         d3 v0, v1, v2;
                         int32_t vid[3];
                         Bounce b;
-                        const d3 o2{s_ray2[0][threadIdx.x], s_ray2[1][threadIdx.x], s_ray2[2][threadIdx.x]};
-                        const d3 d2{s_ray2[3][threadIdx.x], s_ray2[4][threadIdx.x], s_ray2[5][threadIdx.x]};
+                        const d3 o2 = load_d3(r64.o, ri), d2 = load_d3(r64.d, ri);
                         load_tri64(c, f2, v0, v1, v2, vid);
                         bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
                         ok = !b.tir;
@@ -725,7 +721,7 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double*
                 }
             }
         }
-        // ---- traversal phases (k_trace's), for the lanes in T0 / T1 / T2
+        // ---- traversal phases (k_trace's), for the lanes in T1 / T2
         for (;;) {
             const bool walking = stage != kLaneIdle && !(stage & 1);
             const bool at_inner = walking && s.cur >= 0;
@@ -736,8 +732,8 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double*
             lane_steps += (unsigned long long)__popcll(mi);
             if (at_inner) {
                 const bool done = trav_inner<false>(c.tc.nodes, s, st);
-                if (st.overflow) {                 // LDS stack exhausted (rare): the whole path of this ray is redone by k_path_redo
-                    p.redo[atomicAdd(&p.count[4], 1u)] = rk;
+                if (st.overflow) {                 // LDS stack exhausted (rare): the rest of this ray's path is redone by k_path_redo
+                    p.redo[atomicAdd(&p.count[5], 1u)] = rk;       // (count[5]: the second traversal's redo counter -- count[4] may hold the first one's)
                     stage = kLaneIdle;
                 } else if (done) {
                     stage |= 1;
@@ -758,9 +754,8 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double*
 #if defined(DRT_CHECK)
     for (int g = 0; g < kGuardRows; ++g) DRT_DEV_ASSERT(lds[kStackFast + 1 + g][threadIdx.x] == kGuardPoison, drt::kCheckGuardRow);
 #endif
-    if (count_items) {                                  // (profiling only: list sizes of the staged pipeline's R1 / R2)
-        const unsigned t1 = (unsigned)wave_sum((double)n_t1), t2 = (unsigned)wave_sum((double)n_t2);
-        if (lane == 0 && t1) atomicAdd(&p.count[5], t1);
+    if (count_items) {                                  // (profiling only: the size the staged pipeline's list R2 would have)
+        const unsigned t2 = (unsigned)wave_sum((double)n_t2);
         if (lane == 0 && t2) atomicAdd(&p.count[6], t2);
     }
     if (stats && lane == 0 && wave_steps) {
@@ -771,58 +766,45 @@ __global__ void __launch_bounds__(kPathBlock, 4) k_path(PathCtx c, const double*
     }
 }
 
-// The rays whose traversal overflowed the LDS-only stack inside k_path: the whole path again from the R0 entry, one thread per
-// ray, spilling stack.  Idempotent with whatever the abandoned lane had written (provisional outputs are rewritten or zeroed).
+// The rays whose traversal overflowed the LDS-only stack inside k_path: the rest of the path again from the R1 entry, one thread per
+// ray, spilling stack.  Idempotent with whatever the abandoned lane had written (provisional outputs are rewritten or zeroed).  The
+// float64 refracted ray is recomputed from the camera ray and the first face (like k_shade2 does): where it was parked -- rows of the
+// dense outputs in the drop-in form -- may already hold the provisional EXIT ray of a lane that gave up during the occlusion test.
 template <bool FUSED>
-__global__ void __launch_bounds__(kTraceBlock) k_path_redo(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
+__global__ void __launch_bounds__(kTraceBlock) k_path_redo(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir, const int32_t* __restrict__ face1,
                                                            double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                           int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int64_t chunk_base,
-                                                           int32_t* __restrict__ valid_idx, bool prefilled, bool all_pending) {
+                                                           int32_t* __restrict__ face2, Pipe p, int64_t chunk_base, int32_t* __restrict__ valid_idx) {
     __shared__ int32_t lds[kStackFast][kTraceBlock];
-    const unsigned n = p.count[4];
+    const unsigned n = p.count[5];
     if (n == 0) return;
     Stack st = make_stack(lds, c.tc);
     for (unsigned q = blockIdx.x * kTraceBlock + threadIdx.x; q < n; q += gridDim.x * kTraceBlock) {
         const int32_t rk = p.redo[q];
-        const int64_t i = p.r0.idx[rk];
-        const d3 o = load_d3(origin, i), d = load_d3(dir, i);
-        int32_t f1 = all_pending ? kFacePending : p.r0.face[rk];
-        if (f1 == kFacePending) {
-            const float* e = p.r0.ray + 6 * (int64_t)rk;
-            f1 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st).face;
-            p.r0.face[rk] = f1;
-        }
-        face1[i] = f1;
-        bool alive = false, shaded2 = false;
-        d3 v0, v1, v2;
-        int32_t vid[3];
-        Bounce b;
-        if (f1 >= 0) {
-            load_tri64(c, f1, v0, v1, v2, vid);
-            bounce_forward(o, d, v0, v1, v2, c.ior_ext, c.ior_int, b);
-            if (!b.tir) {
-                const d3 o2 = b.new_o, d2 = b.wt;
-                const int32_t f2 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(o2), to_f32(d2), st).face;
-                shaded2 = true;
-                if (f2 >= 0) {
-                    load_tri64(c, f2, v0, v1, v2, vid);
-                    bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
-                    if (!b.tir && traverse<true>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(b.new_o), to_f32(b.wt), st).face < 0) {
-                        alive = true;
-                        face2[i] = f2;
-                        if (!FUSED) {
-                            store_d3(out_ori, i, b.new_o);
-                            store_d3(out_dir, i, b.wt);
-                            mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
-                        }
-                    }
+        const int64_t i = p.r1.idx[rk];
+        const float* e = p.r1.ray + 6 * (int64_t)rk;
+        const int32_t f2 = traverse<false>(c.tc.nodes, c.tc.tris, c.tc.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st).face;
+        bool alive = false;
+        if (f2 >= 0) {
+            d3 v0, v1, v2;
+            int32_t vid[3];
+            Bounce b;
+            load_tri64(c, face1[i], v0, v1, v2, vid);
+            bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+            const d3 o2 = b.new_o, d2 = b.wt;
+            load_tri64(c, f2, v0, v1, v2, vid);
+            bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
+            if (!b.tir && traverse<true>(c.tc.nodes, c.tc.tris, c.tc.n_tris, to_f32(b.new_o), to_f32(b.wt), st).face < 0) {
+                alive = true;
+                face2[i] = f2;
+                if (!FUSED) {
+                    store_d3(out_ori, i, b.new_o);
+                    store_d3(out_dir, i, b.wt);
+                    mask[3 * i] = 1; mask[3 * i + 1] = 1; mask[3 * i + 2] = 1;
                 }
             }
         }
         if (!alive) {
-            if (FUSED) face2[i] = -1;
-            else if (shaded2 || !prefilled) write_dead(i, out_ori, out_dir, mask, face2);
-            else face2[i] = -1;
+            if (FUSED) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2);
         } else if (FUSED) {
             const unsigned slot = atomicAdd(&p.count[2], 1u);
             p.r2.idx[slot] = (int32_t)i; p.r2.face[slot] = -1;
@@ -1201,9 +1183,10 @@ __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long
     atomicAdd(&tot[kStageCull], n_rays);
     if (raster) atomicAdd(&tot[kStageRaster], n_rays);
     if (raster && !fused) atomicAdd(&tot[kStageFill], n_rays);
-    if (mega) {       // one kernel did it all: its item count is the list of primary candidates; the inner list sizes it counted go to the staged stages' rows
-        atomicAdd(&tot[kStagePath], (unsigned long long)qcount[0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
-        atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[5]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[5]);
+    if (mega) {       // one kernel did the back half: its item count is list R1; the size list R2 would have had was counted inside it
+        atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
+        atomicAdd(&tot[kStagePath], (unsigned long long)qcount[1]);
+        atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
         atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[6]);
         atomicAdd(&tot[fused ? kStageLossBwdFused : kStageFinish], (unsigned long long)qcount[6]);
         return;
@@ -1221,7 +1204,12 @@ __global__ void k_prof_counts_bwd(const unsigned* __restrict__ vcount, unsigned 
 
 // Queue workspace for one chunk of `n` rays (grown, never shrunk).  Growing frees the old buffers,
 // which synchronises the device once; steady-state calls allocate nothing.
-static int ensure_queues(drt_scene::Sub& w, int64_t n, bool fused) {
+static int ensure_queues(drt_scene::Sub& w, int64_t n, bool fused, bool mega = false) {
+    if (fused && mega && n > w.ray64_cap) {         // fused one-kernel path: float64 refracted rays parked between bounce #1 and #2 (the drop-in form uses rows of its outputs)
+        (void)hipFree(w.ray64); w.ray64 = nullptr; w.ray64_cap = 0;
+        HIP_TRY(hipMalloc(&w.ray64, sizeof(double) * 6 * n));
+        w.ray64_cap = n;
+    }
     if (n > w.q_cap) {
         for (int k = 0; k < 3; ++k) {
             (void)hipFree(w.q_idx[k]); (void)hipFree(w.q_ray[k]); (void)hipFree(w.q_face[k]);
@@ -1317,6 +1305,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     if (tile_w < 64 || tile_w % 64 != 0 || n % (4 * (int64_t)tile_w) != 0) tile_w = 0;   // not whole 64x4 patches: linear order
     RasterIn rz{nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     const bool mega = s->mega_max_rays > 0 && n <= s->mega_max_rays && n_finished != nullptr;
+    const Ray64 r64 = !mega ? Ray64{nullptr, nullptr} : (FUSED ? Ray64{w.ray64, w.ray64 + 3 * n} : Ray64{out_ori, out_dir});
     bool late_fill = false;
     // the scene's build stream is idle once the tree is built (before the cull stage): it carries the late fills, so that the
     // library stays within the four hardware queues a process gets by default (more streams would share queues with these)
@@ -1346,10 +1335,22 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
             }
             if (!sparse_faces) { (void)hipMemsetAsync(face1, 0xFF, sizeof(int32_t) * n, st); (void)hipMemsetAsync(face2, 0xFF, sizeof(int32_t) * n, st); }
         }
+        if (late_fill && mega) {
+            // (one-kernel path: the dense rows are written by k_shade1 already -- the float64 refracted rays are parked in them -- so the fills
+            // cannot hide beside a later stage on the build stream, which still carries the build at these sizes; they go to the caller's
+            // stream, idle until the join, and run beside the projection pass and the cull)
+            if (fs != st && aux) fs = aux;
+            if (fs != st) { HIP_TRY(hipEventRecord(w.fill_fork, st)); HIP_TRY(hipStreamWaitEvent(fs, w.fill_fork, 0)); }
+            { StageTimer tf(s, fs, kStageFill);
+              if (!pre_ori) (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, fs);
+              if (!pre_dir) (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, fs);
+              if (!pre_mask) (void)hipMemsetAsync(mask, 0, 3 * n, fs); }
+            if (fs != st) HIP_TRY(hipEventRecord(w.fill_join, fs));
+        }
         StageTimer t(s, st, kStageRaster);
         rc = launch_raster(s, w, st, o, d, n_views, tile_w, tile_h, grid_mode == DRT_GRID_TRUST ? grid_cache : nullptr);
         if (rc) return rc;
-        rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h, (all_verified || mega) ? 1 : 0, all_verified ? 1 : 0};
+        rz = RasterIn{w.vmodel, grid_mode, w.zbuf, w.zmask, w.gen_list, tile_w, tile_h, all_verified ? 1 : 0, all_verified ? 1 : 0};
     }
     // The cull stage reads the tree for rays outside the grid (top-box test, k_trace on the listed slots): wait for the build (it ran
     // beside the projection pass above).  When the caller vouches that every ray of every image is a verified grid ray, nothing before
@@ -1371,10 +1372,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
       } else {
           k_cull<FUSED><<<n_patches, kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
       } }
-    if (late_fill) {      // (StageTimer scopes must not nest: this one follows the cull stage's)
-        // (one-kernel path: the dense rows are written INSIDE k_path, so the fills cannot hide beside a later stage on the build stream -- which
-        // still carries the build at these sizes; they go to the caller's stream, idle until the join, and run beside the projection pass and the cull)
-        if (mega && fs != st && aux) fs = aux;
+    if (late_fill && !mega) {      // (StageTimer scopes must not nest: this one follows the cull stage's)
         if (fs != st) { HIP_TRY(hipEventRecord(w.fill_fork, st)); HIP_TRY(hipStreamWaitEvent(fs, w.fill_fork, 0)); }
         { StageTimer tf(s, fs, kStageFill);
           if (!pre_ori) (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, fs);
@@ -1384,18 +1382,6 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     }
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
-    if (mega) {
-        if (tree_late) { int rc = wait_build(s, st); if (rc) return rc; }
-        if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));
-        if (late_fill && pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
-        const bool filled = !FUSED && rz.views && grid_mode == DRT_GRID_TRUST;     // the dense outputs hold the dead values everywhere
-        StageTimer t(s, st, kStagePath);
-        k_path<FUSED><<<s->grid_mega, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, chunk_base, valid_idx, filled, rz.views == nullptr,
-                                                           s->refill_min, s->inner_min, s->shade_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr, s->prof_on);
-        k_path_redo<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, chunk_base, valid_idx, filled, rz.views == nullptr);
-        *n_finished = true;
-        return DRT_OK;
-    }
     { StageTimer t(s, st, kStageTrace1);
       if (rz.views && all_verified) {
           // every ray of every image is a verified grid ray (the caller read that off the cache): normally nothing was listed, and what
@@ -1408,12 +1394,24 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
           k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
           k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, TraceOut{p.r0.face, nullptr, nullptr, nullptr});
       } }
+    if (mega) {     // k_shade1 parks float64 rays in rows of the dense outputs: their zeroing must be through
+        if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));
+        if (pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
+    }
     { StageTimer t(s, st, kStageShade1);
-      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill); }
+      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill, r64); }
     if (tree_late) {
         int rc = wait_build(s, st); if (rc) return rc;
         StageTimer t(s, st, kStageTrace1);
-        k_gen_late<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, w.gen_list, late_fill);
+        k_gen_late<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, w.gen_list, late_fill, r64);
+    }
+    if (mega) {
+        StageTimer t(s, st, kStagePath);
+        k_path<FUSED><<<s->grid_mega, kPathBlock, 0, st>>>(pc, r64, out_ori, out_dir, mask, face2, p, p.count + 8, chunk_base, valid_idx,
+                                                           s->mega_refill_min, s->inner_min, s->shade_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr, s->prof_on);
+        k_path_redo<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, face1, out_ori, out_dir, mask, face2, p, chunk_base, valid_idx);
+        *n_finished = true;
+        return DRT_OK;
     }
     { StageTimer t(s, st, kStageTrace2);
       k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
@@ -1516,7 +1514,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
-        HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, kQCount * sizeof(unsigned), w.stream));
         bool finished = false;
         rc = launch_chunk<false>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
                                  d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h),
@@ -1674,7 +1672,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
     const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
-    for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true); if (rc) return rc; }
+    for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true, s->mega_max_rays > 0 && pl.size <= s->mega_max_rays); if (rc) return rc; }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     if (s->n_prefill && cap == hipStreamCaptureStatusNone) {   // buffers zeroed ahead of time for a drt_render_forward that did not come: forgotten, their zeroing ordered in front of this stream's future
@@ -1690,7 +1688,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
         const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
         const Pipe p = pipe_of(s, w);
-        HIP_TRY(hipMemsetAsync(w.qcount, 0, 8 * sizeof(unsigned), w.stream));
+        HIP_TRY(hipMemsetAsync(w.qcount, 0, kQCount * sizeof(unsigned), w.stream));
         bool finished = false;
         rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h),
                                 st, b, nullptr, &finished);

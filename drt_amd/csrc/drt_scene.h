@@ -53,6 +53,7 @@ constexpr int kStackFast = DRT_STACK_FAST;         // LDS stack entries per lane
 static_assert(kStackFast >= 3, "FastStack keeps four spare entries (kStackFast + 1 rows) above its usable depth");
 constexpr int kStackTotal = 192;
 constexpr int kStackSlowDev = kStackTotal - kStackFast;   // global overflow entries per thread
+constexpr int kQCount = 16;            // words of a pipeline's counter block
 constexpr int kRedoGrid = 64;          // blocks of k_trace_redo (rays that overflowed the LDS-only stack of k_trace)
 constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
 constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds the list workspace (96 B per ray of the largest pass)
@@ -85,7 +86,10 @@ struct drt_scene {
     hipStream_t build_stream = nullptr;   // the LBVH build runs here, beside the caller's next fills / projection pass
     hipEvent_t build_fork = nullptr, build_done = nullptr;
     bool build_pending = false;    // a build was enqueued on build_stream: consumers of the tree wait for build_done
-    bool order_valid = false;      // idx[0] holds the Morton order of the last build over the CURRENT faces (k_tri_flat's order)
+    bool order_valid = false;      // idx[sorted_buf] holds the Morton order of the last build over the CURRENT faces (k_tri_flat's order)
+    int sorted_buf = 0;            // which of keys[] / idx[] the last sort ended in (three radix passes end in 1, four in 0)
+    uint32_t* bounds_acc = nullptr;  // [2][6] scene-box accumulators of drt_update_vert_f64's cast kernel (order-preserving uint encodings; double-buffered)
+    int bounds_par = 0;            // which half the NEXT cast accumulates into (the other one is reset by it)
     bool async_build = true;       // DRT_ASYNC_BUILD=0: build on the caller's stream
     uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
     uint32_t* hist = nullptr;      // [kRadix * tiles]
@@ -109,7 +113,9 @@ struct drt_scene {
         float* q_ray[3] = {nullptr, nullptr, nullptr};       //   float32 ray [cap,6],
         int32_t* q_face[3] = {nullptr, nullptr, nullptr};    //   traversal result
         int32_t *tmp_face1 = nullptr, *tmp_face2 = nullptr;  // fused path keeps face ids here; backward fallback list
-        unsigned* qcount = nullptr;                          // [8] list sizes + redo counts of the sub-batch in flight
+        unsigned* qcount = nullptr;                          // [kQCount] list sizes + redo counts of the sub-batch in flight, [8..15]: k_path's cursors
+        double* ray64 = nullptr;                             // fused one-kernel path: [2][cap,3] float64 refracted rays between bounce #1 and #2
+        int64_t ray64_cap = 0;
         int32_t* redo = nullptr;                             // [cap] rays for k_trace_redo
         int32_t* slow_stack = nullptr;                       // [kRedoGrid * kTraceBlock * kStackSlowDev] overflow area of this stream's k_trace_redo
         int64_t q_cap = 0, fused_cap = 0;
@@ -156,8 +162,9 @@ struct drt_scene {
     int grid_path = 2048;          // resident 256-thread blocks of k_trace
     int64_t trace_stats[12] = {0};  // per k_trace stage: wave-steps, lane-steps, refills, max wave-steps (last profile read)
     int grid_mega = 1024;          // resident 256-thread blocks of k_path
-    int64_t mega_max_rays = 1 << 24;  // sub-batches of at most this many camera rays run as ONE kernel (k_path); 0: never (DRT_MEGA_MAX_LOG2)
+    int64_t mega_max_rays = 0;     // sub-batches of at most this many camera rays run their back half as ONE kernel (k_path); 0: never (DRT_MEGA_MAX_LOG2; measured: no gain)
     int shade_min = 8;             // k_path enters a float64 stage once this many lanes wait for one
+    int mega_refill_min = 16;      // k_path hands new rays to a wave once this many lanes are idle
     int refill_min = 32;           // k_trace refills a wave once this many lanes are idle
     int inner_min = 24;            // k_trace leaves the inner phase once fewer lanes than this are at inner nodes
     int64_t chunk_rays = kChunkRays;
@@ -187,7 +194,7 @@ int check_counters_trace(unsigned long long* out4);
 // defined in drt_build.hip
 void scene_free_mesh(drt_scene* s);
 int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts);
-int rebuild(drt_scene* s, hipStream_t st);
+int rebuild(drt_scene* s, hipStream_t st, const uint32_t* acc);
 int wait_build(drt_scene* s, hipStream_t st);
 
 inline int grid_for(int64_t n, int block, int cap) {

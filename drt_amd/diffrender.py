@@ -512,10 +512,14 @@ class Scene(StepwiseMixin):
         flags = torch.empty(n, dtype=torch.uint8, device=v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().drt_silhouette_flags(v.data_ptr(), self.E2F.data_ptr(), n, o.data_ptr(), flags.data_ptr(), _stream()))
+        if LAZY_SILHOUETTE:
+            return SilhouetteEdges(self.Edges, flags)
         return self.Edges[flags.view(torch.bool)]
 
     def primary_visibility(self, silhouette_edge, camera_M, origin, detach_depth=False):
         """(index int64 [M,2] (x, y), output float32 [M]) of the in-view silhouette samples (DiffRender.py:459-479)."""
+        if isinstance(silhouette_edge, SilhouetteEdges):      # (unwrapped here: autograd.Function.apply should see plain tensors / tuples)
+            silhouette_edge = (silhouette_edge._edges, silhouette_edge._flags) if silhouette_edge._t is None else silhouette_edge.tensor()
         return _EdgeSample.apply(self.vertices, silhouette_edge, camera_M, origin, self, bool(detach_depth), int(resx), int(resy))
 
     def vh_loss_fused(self, camera_M, origin, soft_mask):
@@ -550,6 +554,46 @@ def pack_camera(camera_M):
         _camera_cache.clear()
     _camera_cache[key] = (tuple(weakref.ref(t) for t in camera_M), tuple(t._version for t in camera_M), packed)
     return packed
+
+
+LAZY_SILHOUETTE = True
+
+
+class SilhouetteEdges:
+    """What ``Scene.silhouette_edge`` returns: the int64 [Es,2] tensor ``Edges[flags]`` of the reference (DiffRender.py:445-457), materialised
+    only when somebody looks at it.  The reference's loop hands it straight to ``primary_visibility`` (optim.py:76-77), which here reads
+    the per-edge flags on the device instead -- so that the boolean-mask indexing, a device->host synchronisation per silhouette view, never
+    happens.  Anything else (indexing, ``len``, ``.shape``, torch functions, attribute access) sees the materialised tensor."""
+
+    def __init__(self, edges, flags):
+        self._edges, self._flags, self._t = edges, flags, None
+
+    def tensor(self):
+        if self._t is None:
+            self._t = self._edges[self._flags.view(torch.bool)]
+        return self._t
+
+    def __getattr__(self, name):                     # (only reached for names this object does not define itself)
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, k):
+        return self.tensor()[k]
+
+    def __len__(self):
+        return len(self.tensor())
+
+    def __iter__(self):
+        return iter(self.tensor())
+
+    def __repr__(self):
+        return f"SilhouetteEdges({self.tensor()!r})"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        un = lambda a: a.tensor() if isinstance(a, SilhouetteEdges) else a
+        args = tuple(un(a) if not isinstance(a, (list, tuple)) else type(a)(un(b) for b in a) for a in args)
+        kwargs = {k: un(v) for k, v in (kwargs or {}).items()}
+        return func(*args, **kwargs)
 
 
 class _Dihedral(torch.autograd.Function):
@@ -600,17 +644,24 @@ class _EdgeSample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vertices, sil_edges, camera_M, origin, scene, detach_depth, res_x, res_y):
         v = _f64c(vertices.detach(), "vertices")
-        edges = sil_edges.contiguous()
+        flags = None
+        if isinstance(sil_edges, tuple):
+            # straight from silhouette_edge: every unique edge with its flag, no compaction (and no host round trip) in between
+            edges, flags = sil_edges[0].contiguous(), sil_edges[1]
+        else:
+            edges = sil_edges.contiguous()
         assert edges.dtype == torch.long and edges.dim() == 2 and edges.shape[1] == 2
         cam = pack_camera(camera_M)
         o = _f64c(origin.detach(), "origin")
         n = edges.shape[0]
+        alloc = torch.zeros if flags is not None else torch.empty          # (rows of unflagged edges are not written)
         index = torch.empty((n, 2), dtype=torch.long, device=v.device)
-        f = torch.empty(n, dtype=torch.float32, device=v.device)
-        keep = torch.empty(n, dtype=torch.uint8, device=v.device)
+        f = alloc(n, dtype=torch.float32, device=v.device)
+        keep = alloc(n, dtype=torch.uint8, device=v.device)
         with torch.cuda.device(v.device):
             _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), n, cam.data_ptr(),
-                                                          o.data_ptr(), index.data_ptr(), f.data_ptr(), keep.data_ptr(), int(res_x), int(res_y), _stream()))
+                                                          o.data_ptr(), index.data_ptr(), f.data_ptr(), keep.data_ptr(), int(res_x), int(res_y),
+                                                          _lib.ptr(flags), _stream()))
         # |f| > 1e-5 (DiffRender.py:244) and inside the view (DiffRender.py:478), decided by the kernel: ONE boolean index, one host sync
         sel = torch.nonzero(keep).squeeze(1)             # (the host sync; the row numbers also serve the backward, which then needs none)
         index = index.index_select(0, sel)

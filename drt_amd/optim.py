@@ -84,14 +84,43 @@ class Loss_calculator:
         exit_o, exit_d, exit_mask = self.scene.render_transparent(origin, ray_dir)
         return Render.ray_loss(exit_o, exit_d, exit_mask, target, valid)
 
+    # The three terms of an iteration are independent given the mesh.  With the one-pass kernels (fused=True: no host synchronisation inside a
+    # term) the silhouette and smoothness terms are enqueued on a SIDE stream and run beside the refraction term -- at the reference's
+    # iteration size (one 960x1280 view, ~50 k primary hits) each term is a chain of small launches that leaves most of the chip idle, so
+    # the iteration costs the longest chain instead of their sum.  Values are unchanged (same kernels, same inputs).
+    CONCURRENT_TERMS = True
+
     def all_loss(self):
         hp = self.HyperParams
         none = torch.zeros((), dtype=Float, device=self.scene.vertices.device)
-        parts = (self.ray_loss() if hp["ray_w"] != 0 else none,
-                 self.vh_loss() if hp["vh_w"] != 0 else none,
-                 self.sm_loss() if hp["sm_w"] != 0 else none)
+        if self.fused and self.CONCURRENT_TERMS and self.scene.vertices.is_cuda and not torch.cuda.is_current_stream_capturing():
+            main = torch.cuda.current_stream()
+            side = getattr(self, "_side_stream", None)
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(device=self.scene.vertices.device)
+            side.wait_stream(main)                      # the rebuild (update_verticex) and the vertices are enqueued on `main`
+            # (the refraction term first: it is the longest chain, and at this size the HOST's enqueue order is the GPU's start order)
+            ray = self.ray_loss() if hp["ray_w"] != 0 else none
+            with torch.cuda.stream(side):
+                vh = self.vh_loss() if hp["vh_w"] != 0 else none
+                sm = self.sm_loss() if hp["sm_w"] != 0 else none
+            main.wait_stream(side)
+            for t in (vh, sm):
+                t.record_stream(main)                   # allocated on the side stream, consumed on `main` from here on
+            parts = (ray, vh, sm)
+        else:
+            parts = (self.ray_loss() if hp["ray_w"] != 0 else none,
+                     self.vh_loss() if hp["vh_w"] != 0 else none,
+                     self.sm_loss() if hp["sm_w"] != 0 else none)
         w = loss_weights(hp, self.data.resy, self.scene.mean_len)
-        total = w[0] * parts[0] + w[1] * parts[1] + w[2] * parts[2]
+        if self.fused:
+            # one stack + one dot instead of five scalar kernels (and five more in the backward pass): the iteration is a chain of small launches
+            key = (w, parts[0].device)
+            if getattr(self, "_w_key", None) != key:
+                self._w_key, self._w_vec = key, torch.tensor(w, dtype=Float, device=parts[0].device)
+            total = torch.dot(torch.stack(parts), self._w_vec)
+        else:
+            total = w[0] * parts[0] + w[1] * parts[1] + w[2] * parts[2]
         return total, parts
 
 
@@ -186,7 +215,7 @@ def optimize(scene, data, HyperParams, remesh="isotropic", output=True, fused=Fa
             print(f"remesh_len {remesh_len:g} lr {lr:g}")
         if remesh is not None:
             remesh(scene, remesh_len)
-        init_vertices, parameter, opt = setup_opt(scene, lr, HyperParams)
+        init_vertices, parameter, opt = setup_opt(scene, lr, HyperParams, hook=not fused, fused=fused)    # fused: limit_hook + SGD in one kernel
         for it in range(HyperParams["Iters"]):
             opt.zero_grad()
             vertices = init_vertices + parameter

@@ -209,6 +209,9 @@ int drt_sm_loss_fused(const double* d_verts, const int64_t* d_e2f, int64_t n_edg
  * trunc(midpoint x, y) and f float32 [Es] = hit(+) - hit(-) in {-1, 0, 1}.  The caller keeps edges with
  * |f| > 1e-5 (DiffRender.py:244) and in-view indices (:478): d_keep (uint8 [Es], may be NULL) = exactly that test for a
  * resx x resy image, so that the caller needs one boolean index instead of ten elementwise launches.
+ * d_flags (uint8 [Es], may be NULL): d_edges is then the list of ALL unique edges and only the flagged ones (drt_silhouette_flags)
+ * are silhouette edges -- the others are skipped (their rows of index / f / keep are left untouched: zero them first) -- which
+ * spares the caller the device->host round trip of compacting Edges[flags] between the two calls.
  * drt_edge_sample_backward <- primary_edge_sample.backward (DiffRender.py:263-267) chained through the
  * projection (depth row detached when detach_depth != 0, DiffRender.py:470-471):
  * grad_verts [V,3] += sum_e coef[e] * f[e] * d(-N_e . E_pos)/dV, coef float64 [Es] = incoming
@@ -217,7 +220,7 @@ int drt_silhouette_flags(const double* d_verts, const int64_t* d_e2f, int64_t n_
                          const double* d_origin3, uint8_t* d_flags, void* stream);
 int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, int64_t n_edges,
                             const double* d_camera, const double* d_origin3, int64_t* d_index,
-                            float* d_f, uint8_t* d_keep, int resx, int resy, void* stream);
+                            float* d_f, uint8_t* d_keep, int resx, int resy, const uint8_t* d_flags, void* stream);
 int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int64_t n_edges,
                              const double* d_camera, const float* d_f, const double* d_coef,
                              int detach_depth, double* d_grad_verts, void* stream);

@@ -1,0 +1,87 @@
+"""The call bench.py TIMES, checked: 72 views x 1024 x 1024 rays of the 50 248-triangle horse in ONE render_transparent, in the mode the timed
+steps run in -- trusted grid verdict with every image verified (DRT_GRID_TRUST | DRT_GRID_ALL_VERIFIED), sparse face ids, out_ori / mask
+zeroed ahead of time by the previous call (PREFILL_NEXT), two sub-batches of 36 images on the two internal streams -- against the plainest
+path the library has: 72 separate one-view calls on a scene created with DRT_RASTER=0 (every primary ray through the tree, no projection
+pass, no verdict cache, no ahead-of-time fills).  Loss and d loss / d vertices to 1e-12; outputs, mask and face ids of three views exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import IOR, data_path
+from drt_amd import mesh_io, views
+
+pytestmark = pytest.mark.gpu
+
+N_VIEWS, RES = 72, 1024
+
+
+def test_the_timed_call_equals_72_plain_tree_calls():
+    from drt_amd import diffrender as Render
+    Render.intIOR = IOR
+    Render.resx = Render.resy = RES
+    P = RES * RES
+    mesh = mesh_io.subdivide_midpoint(mesh_io.read_ply(data_path("horse_vh.ply")))
+    assert len(mesh.faces) == 50248
+    center, extent = views.mesh_frame(mesh.vertices)
+    cams = views.turntable_cameras(center, extent, N_VIEWS, RES, RES)
+    rays = [views.generate_ray(RES, RES, cams[k][3], cams[k][2], device="cuda") for k in range(N_VIEWS)]
+    o_all = torch.cat([r[0] for r in rays]).contiguous()
+    d_all = torch.cat([r[1] for r in rays]).contiguous()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    sp_all = torch.randn(o_all.shape, dtype=torch.float64, device="cuda", generator=gen) * 40.0 + torch.tensor(center, device="cuda") + torch.tensor([0.0, 0.0, 150.0], device="cuda", dtype=torch.float64)
+    valid_all = torch.rand(len(o_all), device="cuda", generator=gen) < 0.6
+    rng = np.random.default_rng(5)
+    V0 = torch.tensor(mesh.vertices + 0.05 * rng.standard_normal(mesh.vertices.shape), dtype=torch.float64, device="cuda")
+
+    dense = Render.DENSE_FACE_IDS
+    Render.DENSE_FACE_IDS = False                      # what bench.py runs with (the autouse fixture of this suite asks for dense ids)
+    try:
+        scene = Render.Scene(mesh, 0)
+        assert scene.optix_mesh is not None
+        for it in range(3):                            # establish the verdict, read it back, then the trusted + prefilled call that is timed
+            V = V0.clone().requires_grad_(True)
+            scene.update_verticex(V)
+            oo, od, mk = scene.render_transparent(o_all, d_all)
+            loss = Render.ray_loss(oo, od, mk, sp_all, valid_all)
+            if it == 1:
+                assert d_all._drt_grid[3][0] is True                       # every image verified in every ray -> DRT_GRID_ALL_VERIFIED from now on
+                if Render.PREFILL_NEXT and len(o_all) >= Render.PREFILL_MIN_RAYS:
+                    assert scene.optix_mesh._prefilled is not None         # the next call's out_ori / mask are being zeroed right now
+        assert (Render._grid_cache(o_all, d_all, len(o_all), RES, RES)[0] & (3 | 32)) == (2 | 32)
+        grad, = torch.autograd.grad(loss, V)
+        f1_all, f2_all = scene.last_face1, scene.last_face2
+        m_all = mk[:, 0]
+        assert 0.005 < m_all.float().mean().item() < 0.2 and float(oo[~m_all].abs().sum()) == 0.0 and float(od[~m_all].abs().sum()) == 0.0
+
+        # ---- the reference: one view per call, tree for every ray
+        os.environ["DRT_RASTER"] = "0"
+        try:
+            plain = Render.Scene(mesh, 0)
+        finally:
+            del os.environ["DRT_RASTER"]
+        Render.GRID_CACHE = False
+        Vp = V0.clone().requires_grad_(True)
+        plain.update_verticex(Vp)
+        total = torch.zeros((), dtype=torch.float64, device="cuda")
+        tr = plain.optix_mesh
+        tr.profile_enable(1); tr.profile_read()
+        for k in range(N_VIEWS):
+            sl = slice(k * P, (k + 1) * P)
+            o_k, d_k = rays[k]
+            oo_k, od_k, mk_k = plain.render_transparent(o_k, d_k)
+            total = total + Render.ray_loss(oo_k, od_k, mk_k, sp_all[sl], valid_all[sl])
+            if k in (0, 29, 71):
+                assert torch.equal(mk_k, mk[sl]) and torch.equal(oo_k.detach(), oo.detach()[sl]) and torch.equal(od_k.detach(), od.detach()[sl])
+                mm = mk_k[:, 0]
+                assert torch.equal(plain.last_face1[mm], f1_all[sl][mm]) and torch.equal(plain.last_face2[mm], f2_all[sl][mm])
+        prof = tr.profile_read(); tr.profile_enable(0)
+        assert prof["raster"][1] == 0 and prof["trace1"][2] > 0            # no projection pass: the primary rays really went through the tree
+        gref, = torch.autograd.grad(total, Vp)
+        assert abs(loss.item() - total.item()) <= 1e-12 * abs(total.item()), (loss.item(), total.item())
+        scale = gref.abs().max().item()
+        assert scale > 0 and (grad - gref).abs().max().item() <= 1e-12 * scale, (grad - gref).abs().max().item() / scale
+    finally:
+        Render.DENSE_FACE_IDS = dense
+        Render.GRID_CACHE = True

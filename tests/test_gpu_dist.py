@@ -124,3 +124,78 @@ def test_a_whole_step_captured_as_a_hip_graph_equals_eager_steps(fused):
     scale = np.abs(eager).max()
     assert scale > 1e-3 and np.isfinite(replayed).all()
     assert np.abs(eager - replayed).max() <= 1e-11 * scale, np.abs(eager - replayed).max() / scale
+
+
+def _nccl_worker(rank, world, port, out_dir, fused, graph):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      DRT_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 1:
+        os.environ["DRT_DIST_FORCE"] = "1"          # create the process group and issue the collectives with ONE rank
+    import importlib
+    from drt_amd import dist as ddist
+    importlib.reload(ddist)                         # (DRT_DIST_FORCE is read at import)
+    import drt_amd.optim as O
+    O.ddist = ddist
+    torch.cuda.set_device(rank)
+    r, _, w = ddist.init(backend="nccl")
+    assert (r, w) == (rank, world)
+    # SURVEY section 8e rests on the all-reduce delivering the SAME bits to every rank: checked on a vector whose partial sums round
+    probe = torch.tensor(np.random.default_rng(7 + rank).standard_normal(75378) * 10.0 ** np.random.default_rng(3).integers(-8, 8, 75378), device="cuda")
+    ddist.allreduce_sum_(probe)
+    from drt_amd import diffrender as Render, mesh_io, views
+    Render.intIOR = IOR
+    Render.resx = Render.resy = RES
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    center, extent = views.mesh_frame(mesh.vertices)
+    scene = Render.Scene(mesh, rank)
+    cams = views.turntable_cameras(center, extent, N_VIEWS, RES, RES)
+    parts = []
+    for k in (range(3) if world == 1 else ddist.shard_views(N_VIEWS, rank, world)):       # (one rank: the three views of _graph_run)
+        o, d = views.generate_ray(RES, RES, cams[k][3], cams[k][2], device="cuda")
+        rng = np.random.default_rng(100 + k)
+        sp = torch.tensor(rng.standard_normal((RES * RES, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0]), device="cuda")
+        parts.append((sp, torch.tensor(rng.random(RES * RES) > 0.1, device="cuda"), o, d))
+    local = [tuple(torch.cat([p[j] for p in parts]).contiguous() for j in range(4))]
+    init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False, fused=True)
+    ray_w = 40 * 217.5 / RES / RES
+    step = lambda: O.full_batch_step(scene, local, init_vertices, parameter, opt, ray_w, fused=fused)
+    if graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for _ in range(STEPS):
+            g.replay()
+    else:
+        for _ in range(3 + STEPS):
+            step()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"nccl{rank}.npz"), param=parameter.detach().cpu().numpy(), probe=probe.cpu().numpy())
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "whole-step-graph"])
+def test_rccl_step_with_one_rank_per_gpu(tmp_path, graph):
+    """The step over RCCL (backend "nccl"), eagerly and as a captured hipGraph with the all-reduce INSIDE the graph -- what bench.py runs
+    for N > 1.  With two or more GPUs: two ranks, one per GPU, bit-identical parameters and all-reduce results on both (the
+    replicas-stay-identical-without-a-broadcast assumption of SURVEY section 8e), equal to the one-rank run up to summation order.  On a
+    one-GPU box: ONE rank with the process group forced on (DRT_DIST_FORCE), so that communicator creation, the collective's launch
+    and its capture have run at least once before the first multi-GPU driver run."""
+    world = 2 if torch.cuda.device_count() >= 2 else 1
+    mp.spawn(_nccl_worker, args=(world, _free_port(), str(tmp_path), False, graph), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"nccl{k}.npz") for k in range(world)]
+    assert np.isfinite(r[0]["param"]).all() and np.abs(r[0]["param"]).max() > 1e-3
+    for other in r[1:]:
+        assert np.array_equal(r[0]["param"], other["param"]) and np.array_equal(r[0]["probe"], other["probe"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DRT_DIST_FORCE", "DRT_DIST_BACKEND"):
+        os.environ.pop(k, None)
+    ref = _graph_run(False, False, steps=STEPS) if world == 1 else None
+    if ref is not None:      # one rank: the same three views in one call as _graph_run -> same numbers up to the order of the atomics
+        scale = np.abs(ref).max()
+        assert np.abs(r[0]["param"] - ref).max() <= 1e-11 * scale

@@ -441,16 +441,18 @@ def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
     from drt_amd import build
     so = str(tmp_path / "libdrt_hip_stack3.so")
     build.build(force=True, out=so, extra_flags=("-DDRT_STACK_FAST=3",))
-    env = dict(os.environ, DRT_HIP_LIB=so)
     sel = "test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or test_silhouette_branch_vs_golden"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    for extra in ({}, {"DRT_MEGA_MAX_LOG2": "24"}):          # (the staged kernels' redo passes; k_path's redo pass)
+        env = dict(os.environ, DRT_HIP_LIB=so, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel if not extra else "test_render_transparent_vs_golden or test_two_optimisation_steps"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("flags", [("-DDRT_CHECK=1",), ("-DDRT_CHECK=1", "-DDRT_STACK_FAST=5")], ids=["default-stack", "five-entry-stack"])
-def test_lds_stack_invariants_hold_in_a_checked_build(tmp_path, flags):
+@pytest.mark.parametrize("flags,extra", [(("-DDRT_CHECK=1",), {}), (("-DDRT_CHECK=1", "-DDRT_STACK_FAST=5"), {}), (("-DDRT_CHECK=1", "-DDRT_STACK_FAST=5"), {"DRT_MEGA_MAX_LOG2": "24"})],
+                         ids=["default-stack", "five-entry-stack", "five-entry-stack-one-kernel-path"])
+def test_lds_stack_invariants_hold_in_a_checked_build(tmp_path, flags, extra):
     """k_trace's LDS stack has no bound check per push: "a visit that starts with a legal stack stores at most three rows above it"
     (drt_traverse.h FastStack).  A -DDRT_CHECK=1 build ASSERTS that at every store, checks pops against underflow and validates
     poisoned guard rows around each block's stack; the golden, full-size brute-force and monkey (184 k triangles, deepest tree)
@@ -462,7 +464,7 @@ def test_lds_stack_invariants_hold_in_a_checked_build(tmp_path, flags):
     from drt_amd import build
     so = str(tmp_path / "libdrt_hip_check.so")
     build.build(force=True, out=so, extra_flags=flags)
-    env = dict(os.environ, DRT_HIP_LIB=so, DRT_EXPECT_CHECKED="1")
+    env = dict(os.environ, DRT_HIP_LIB=so, DRT_EXPECT_CHECKED="1", **extra)
     here = os.path.dirname(os.path.abspath(__file__))
     sel = ("test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or "
            "test_silhouette_branch_vs_golden or test_two_optimisation_steps or test_zz_check_counters")

@@ -241,18 +241,19 @@ def test_grid_verdict_is_cached_per_ray_tensors_and_invalidated_by_inplace_write
     assert prof3["trace1"][2] >= prof["trace1"][2]
 
 
-def test_small_calls_through_the_staged_kernels_too():
-    """Calls of at most 2^24 rays -- every test of this suite but the full-size ones -- run the path as ONE persistent kernel (k_path);
-    the staged kernels (k_shade1 / k_trace / k_shade2 / k_trace / k_finish, k_gen_late) serve the larger ones.  Both must give the
-    reference's results on the golden, oracle, raster-fallback and optimisation-step tests: this re-runs those files with the one-kernel
-    path switched off (DRT_MEGA_MAX_LOG2=0), so that the staged path is held to them as well."""
+def test_small_calls_through_the_one_kernel_path_too():
+    """DRT_MEGA_MAX_LOG2=n sends sub-batches of at most 2^n camera rays through k_path -- bounce #1, then ONE persistent kernel for the second
+    traversal, bounce #2, the occlusion test and the valid-ray list (an option: measured no faster than the staged kernels, DESIGN.md
+    section 6).  It must give the reference's results on the golden, oracle, raster-fallback and optimisation-step tests: this re-runs
+    those files with every call of the suite taking that path."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, DRT_MEGA_MAX_LOG2="0")
+    env = dict(os.environ, DRT_MEGA_MAX_LOG2="24")
     sel = ("not test_many_sub_batches and not test_small_calls_through and not test_stack_overflow_paths and not test_lds_stack_invariants "
-           "and not test_full_loop_with_remesh and not test_optimize_loop and not test_closest_point and not test_large_mesh and not test_b1_")
+           "and not test_full_loop_with_remesh and not test_optimize_loop and not test_closest_point and not test_large_mesh and not test_b1_ "
+           "and not test_profile_select")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_raster.py"), os.path.join(here, "test_gpu_parity.py"),
                         "-m", "gpu", "-x", "-q", "-k", sel], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -365,15 +366,15 @@ def test_sparse_face_ids_leave_results_unchanged(Render):
         assert torch.equal(a[5][m], b[5][m]) and torch.equal(a[6][m], b[6][m])
 
 
-@pytest.mark.parametrize("extra", [{}, {"DRT_FILL_OVERLAP": "0"}, {"DRT_MEGA_MAX_LOG2": "0"}, {"DRT_MEGA_MAX_LOG2": "0", "DRT_FILL_OVERLAP": "0"}],
-                         ids=["one-kernel-path-late-fills", "one-kernel-path-front-fills", "staged-late-fills", "staged-front-fills"])
+@pytest.mark.parametrize("extra", [{}, {"DRT_FILL_OVERLAP": "0"}, {"DRT_MEGA_MAX_LOG2": "24"}, {"DRT_MEGA_MAX_LOG2": "24", "DRT_FILL_OVERLAP": "0"}],
+                         ids=["late-fills", "front-fills", "one-kernel-path-late-fills", "one-kernel-path-front-fills"])
 def test_many_sub_batches_on_two_streams(extra):
     """Force every call to be cut into sub-batches of one or two images dealt to the two internal streams (the benchmark's 72 x 1024^2
     calls are cut like that; the tests' calls are normally one sub-batch): the projection pass, the verdict cache (indexed by global
     image), the key buffers and the lists of each stream must give the same results.  Re-runs this file and the multi-image tests
     of the other files in a subprocess with the sub-batch knobs set -- with the output fills issued beside the traversal (default: every
-    sub-batch's memsets go through the build stream, one after the other) and in front of the projection pass; through the one-kernel
-    path (k_path: what sub-batches of this size take by default) and through the staged kernels the benchmark-sized calls take."""
+    sub-batch's memsets go through the build stream, one after the other) and in front of the projection pass; through the staged kernels
+    (the default) and through the one-kernel path (k_path, DRT_MEGA_MAX_LOG2)."""
     import os
     import subprocess
     import sys

@@ -16,7 +16,7 @@ data = O.SyntheticData(gt, center, extent, resx, resy, num_view=16, n_total=16)
 scene = Render.Scene(mesh, 0)
 hp = dict(O.HyperParams, Pass=1, Iters=1)
 lc = O.Loss_calculator(scene, data, hp, fused=True)
-init_vertices, parameter, opt = O.setup_opt(scene, 0.05, hp)
+init_vertices, parameter, opt = O.setup_opt(scene, 0.05, hp, hook=False, fused=True)
 def iteration():
     opt.zero_grad(); scene.update_verticex(init_vertices + parameter)
     loss, parts = lc.all_loss(); loss.backward(); opt.step()

@@ -30,7 +30,7 @@ scene = Render.Scene(mesh, 0)
 for fused in (False, True):
     hp = dict(O.HyperParams, Pass=1, Iters=1)
     lc = O.Loss_calculator(scene, data, hp, fused=fused)
-    init_vertices, parameter, opt = O.setup_opt(scene, 0.05, hp)
+    init_vertices, parameter, opt = O.setup_opt(scene, 0.05, hp, hook=not fused, fused=fused)     # (fused terms come with the one-kernel limit_hook + SGD)
 
     def iteration():
         opt.zero_grad()
