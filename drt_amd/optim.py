@@ -177,6 +177,95 @@ class FusedLimitSGD:
                                                       int(self.nesterov), int(first), self.max_abs, _stream()))
 
 
+class FusedIteration:
+    """One iteration of the reference's loop (optim.py:198-215: vertices = init + parameter, update_verticex, all_loss, backward,
+    limit_hook, SGD) on the one-pass kernels WITHOUT the autograd graph around them.
+
+    With ``Loss_calculator(fused=True)`` every term already returns its loss together with d term / d vertices; autograd only
+    multiplies those by the weights and adds them up -- ~15 tiny torch ops, three Function nodes and a backward pass whose HOST cost
+    (0.7 ms) exceeds the GPU time of the whole iteration at the reference's size (one 960x1280 refraction view, 8 silhouette views).
+    Here the three entry points write into one [3, V, 3] buffer, the weighted sum is one matrix product and the update is the
+    one-kernel limit_hook + SGD(nesterov): the same kernels, inputs and arithmetic, ~10 host calls.  The silhouette and smoothness
+    terms run on a side stream beside the refraction term.  Same view schedule generators as Loss_calculator."""
+
+    N_SILHOUETTE_VIEWS = 8
+
+    def __init__(self, scene, data, HyperParams, lr, concurrent=True):
+        from . import _lib
+        self._lib = _lib
+        self.scene, self.data, self.hp = scene, data, HyperParams
+        self.ray_view = data.ray_view_generator()
+        self.silh_view = data.silh_view_generator()
+        dev = scene.vertices.device
+        self.init_vertices = scene.vertices.detach().clone()
+        self.parameter = torch.zeros_like(self.init_vertices)
+        self.grads = torch.zeros((3,) + tuple(self.init_vertices.shape), dtype=Float, device=dev)
+        self.losses = torch.zeros(3, dtype=Float, device=dev)
+        self.total_grad = torch.empty_like(self.init_vertices)
+        self.buf = torch.empty_like(self.init_vertices) if HyperParams["momentum"] != 0 else None
+        self.first = True
+        self.lr, self.momentum = float(lr), float(HyperParams["momentum"])
+        self.side = torch.cuda.Stream(device=dev) if concurrent else None
+        self._w = None
+
+    def step(self):
+        """Runs the iteration; returns (weighted total, parts [ray, vh, sm]) as device tensors of THIS iteration (views of
+        buffers that the next call overwrites: read them, or clone them, before stepping again)."""
+        from . import diffrender as R
+        from .optix_mesh import _stream
+        lib, check, ptr = self._lib.lib(), self._lib.check, self._lib.ptr
+        scene, hp, data = self.scene, self.hp, self.data
+        dev = self.init_vertices.device
+        with torch.no_grad(), torch.cuda.device(dev):
+            vertices = self.init_vertices + self.parameter
+            scene.update_verticex(vertices)
+            self.grads.zero_()
+            self.losses.zero_()
+            h = scene.optix_mesh._h
+            main = torch.cuda.current_stream()
+            if self.side is not None:
+                self.side.wait_stream(main)
+            if hp["ray_w"] != 0:
+                target, valid, _, origin, ray_dir, _ = data.get_view(next(self.ray_view))
+                n = origin.shape[0]
+                o, d, sp = R._f64c(origin, "origin"), R._f64c(ray_dir, "ray_dir"), R._f64c(target, "screen_pixel")
+                va = R._flag_bytes(valid, "valid", n)
+                grid = R._grid_cache(origin, ray_dir, n, *R._tile_hint(n)) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
+                check(lib.drt_render_ray_loss_fused(h, vertices.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
+                                                    float(R.intIOR), float(R.extIOR), self.losses[0:].data_ptr(), self.grads[0].data_ptr(), None,
+                                                    *R._tile_hint(n), grid[0], ptr(grid[1]), _stream()))
+            ctx = torch.cuda.stream(self.side) if self.side is not None else torch.no_grad()
+            with ctx:
+                if hp["vh_w"] != 0:
+                    import ctypes
+                    k = self.N_SILHOUETTE_VIEWS
+                    cams, orgs, softs = (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)()
+                    keep = []
+                    for j in range(k):
+                        _, _, soft_mask, origin, _, camera_M = data.get_view(next(self.silh_view))
+                        cam, o3, sm_ = R.pack_camera(camera_M), R._f64c(origin[0], "origin"), R._f64c(soft_mask, "soft_mask")
+                        keep += [cam, o3, sm_]
+                        cams[j], orgs[j], softs[j] = cam.data_ptr(), o3.data_ptr(), sm_.data_ptr()
+                    check(lib.drt_vh_loss_fused(h, vertices.data_ptr(), scene.Edges.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], k,
+                                                cams, orgs, softs, int(data.resx), int(data.resy), 1, self.losses[1:].data_ptr(), self.grads[1].data_ptr(), _stream()))
+                if hp["sm_w"] != 0:
+                    check(lib.drt_sm_loss_fused(vertices.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], self.losses[2:].data_ptr(),
+                                                self.grads[2].data_ptr(), _stream()))
+            if self.side is not None:
+                main.wait_stream(self.side)
+            w = loss_weights(hp, data.resy, scene.mean_len)
+            if self._w is None or self._w[0] != w:
+                self._w = (w, torch.tensor(w, dtype=Float, device=dev))
+            wv = self._w[1]
+            torch.matmul(wv.view(1, 3), self.grads.view(3, -1), out=self.total_grad.view(1, -1))        # d total / d vertices = d total / d parameter
+            total = torch.dot(wv, self.losses)
+            check(lib.drt_limit_sgd_step(self.parameter.data_ptr(), self.total_grad.data_ptr(), ptr(self.buf), self.parameter.numel(), self.lr,
+                                         self.momentum, 1, int(self.first), 1.0, _stream()))
+            self.first = False
+            self._vertices = vertices          # (alive until the next step: kernels enqueued above read it)
+        return total, self.losses
+
+
 def setup_opt(scene, lr, HyperParams, hook=True, fused=False):
     """``fused=True`` (needs ``hook=False``): a FusedLimitSGD, which applies limit_hook itself inside its one-kernel step."""
     init_vertices = scene.vertices.detach().clone()
@@ -215,7 +304,17 @@ def optimize(scene, data, HyperParams, remesh="isotropic", output=True, fused=Fa
             print(f"remesh_len {remesh_len:g} lr {lr:g}")
         if remesh is not None:
             remesh(scene, remesh_len)
-        init_vertices, parameter, opt = setup_opt(scene, lr, HyperParams, hook=not fused, fused=fused)    # fused: limit_hook + SGD in one kernel
+        if fused:      # the one-pass terms without the autograd graph around them (same arithmetic, a third of the host work)
+            stepper = FusedIteration(scene, data, HyperParams, lr)
+            stepper.ray_view, stepper.silh_view = loss_calculator.ray_view, loss_calculator.silh_view      # one view schedule across passes
+            for it in range(HyperParams["Iters"]):
+                total, parts = stepper.step()
+                if it % 100 == 0:
+                    if output:
+                        print(f"Iteration {it}: {loss_string(tuple(parts))} maxgrad={stepper.total_grad.abs().max():g}")
+                    history.append(float(total))
+            continue
+        init_vertices, parameter, opt = setup_opt(scene, lr, HyperParams)
         for it in range(HyperParams["Iters"]):
             opt.zero_grad()
             vertices = init_vertices + parameter

@@ -450,6 +450,60 @@ def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
         assert " passed" in r.stdout
 
 
+def test_fused_iteration_without_autograd_equals_the_autograd_loop(Render, hand):
+    """optim.FusedIteration (the three one-pass terms written into one buffer, weighted sum, one-kernel limit_hook + SGD; no autograd graph,
+    terms on two streams) must walk the SAME trajectory as Loss_calculator(fused=True) + backward() + FusedLimitSGD, and that one the same
+    as the drop-in terms with the reference's hook + torch.optim.SGD: same view schedule (seeded generator), first-iteration losses equal to 1e-12,
+    parameters and loss histories to 1e-7 after five iterations."""
+    from drt_amd import optim as O
+    g = golden("hand_smooth_sm")
+    Vs = g["vertices"].astype(np.float64)
+    mesh = mesh_io.TriMesh(Vs, hand.faces)
+    res = 128
+    Render.intIOR = IOR
+    Render.resx = Render.resy = res
+    center, extent = views.mesh_frame(Vs)
+    scene_gt = Render.Scene(views.displaced_ground_truth(mesh, sigma=0.15, seed=3), 0)
+    hp = dict(O.HyperParams, Pass=1, Iters=5, start_lr=0.05, vh_w=2e-3, sm_w=0.08, ray_w=40, num_view=12)
+
+    def data_for(seed):
+        return O.SyntheticData(scene_gt, center, extent, res, res, num_view=12, n_total=12, seed=seed)      # (seeded view schedule)
+
+    def autograd_loop(fused):
+        scene = Render.Scene(mesh, 0)
+        lc = O.Loss_calculator(scene, data_for(7), hp, fused=fused)
+        init_vertices, parameter, opt = O.setup_opt(scene, 0.05, hp, hook=not fused, fused=fused)
+        parts_hist = []
+        for _ in range(hp["Iters"]):
+            opt.zero_grad()
+            scene.update_verticex(init_vertices + parameter)
+            loss, parts = lc.all_loss()
+            loss.backward()
+            opt.step()
+            parts_hist.append([float(p.detach()) for p in parts] + [float(loss.detach())])
+        return parameter.detach().clone(), np.array(parts_hist)
+
+    p_drop, h_drop = autograd_loop(False)
+    p_fused, h_fused = autograd_loop(True)
+    scene = Render.Scene(mesh, 0)
+    it = O.FusedIteration(scene, data_for(7), hp, 0.05)
+    h_direct = []
+    for _ in range(hp["Iters"]):
+        total, parts = it.step()
+        h_direct.append(parts.tolist() + [float(total)])
+    h_direct = np.array(h_direct)
+    scale = p_drop.abs().max().item()
+    assert scale > 1e-3
+    # (summation orders differ -- float64 atomics, the weighted sum as a matrix product -- and five SGD steps amplify the last bits: the
+    # first iteration agrees to 1e-12, the parameters after the fifth to 1e-7)
+    np.testing.assert_allclose(h_fused[0], h_drop[0], rtol=1e-12)
+    np.testing.assert_allclose(h_direct[0], h_drop[0], rtol=1e-12)
+    assert (p_fused - p_drop).abs().max().item() <= 1e-7 * scale, (p_fused - p_drop).abs().max().item() / scale
+    assert (it.parameter - p_drop).abs().max().item() <= 1e-7 * scale, (it.parameter - p_drop).abs().max().item() / scale
+    np.testing.assert_allclose(h_fused, h_drop, rtol=1e-7)
+    np.testing.assert_allclose(h_direct, h_drop, rtol=1e-7)
+
+
 @pytest.mark.parametrize("flags,extra", [(("-DDRT_CHECK=1",), {}), (("-DDRT_CHECK=1", "-DDRT_STACK_FAST=5"), {}), (("-DDRT_CHECK=1", "-DDRT_STACK_FAST=5"), {"DRT_MEGA_MAX_LOG2": "24"})],
                          ids=["default-stack", "five-entry-stack", "five-entry-stack-one-kernel-path"])
 def test_lds_stack_invariants_hold_in_a_checked_build(tmp_path, flags, extra):

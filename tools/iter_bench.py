@@ -65,3 +65,34 @@ for fused in (False, True):
             iteration()
         torch.cuda.synchronize(); pr.disable()
         pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+
+# the same iteration without the autograd graph around the one-pass terms (optim.FusedIteration)
+hp = dict(O.HyperParams, Pass=1, Iters=1)
+it = O.FusedIteration(scene, data, hp, 0.05)
+for _ in range(5):
+    it.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 100
+for _ in range(n):
+    total, parts = it.step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+p = parts.tolist()
+print(f"fused, no autograd (FusedIteration): {1e3 * dt:.3f} ms/iteration  ({resx * resy / dt / 1e6:.1f} M refraction rays/s)  ray={p[0]:g} vh={p[1]:g} sm={p[2]:g}")
+t0 = time.perf_counter()
+for _ in range(n):
+    it.step()
+host = (time.perf_counter() - t0) / n
+torch.cuda.synchronize()
+print(f"    host enqueue alone: {1e3 * host:.3f} ms/iteration")
+it2 = O.FusedIteration(scene, data, hp, 0.05, concurrent=False)
+for _ in range(5):
+    it2.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    it2.step()
+torch.cuda.synchronize()
+print(f"    terms one after the other on one stream: {1e3 * (time.perf_counter() - t0) / n:.3f} ms/iteration")
+
