@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # gfx950 kernels + the C ABI, one translation unit per concern; drt_remesh.cpp is the host-only part (remeshing)
-UNITS = ["drt_api.hip", "drt_build.hip", "drt_trace.hip", "drt_pipeline.hip", "drt_raster.hip", "drt_edges.hip", "drt_topology.hip", "drt_remesh.cpp"]
+UNITS = ["drt_api.hip", "drt_build.hip", "drt_trace.hip", "drt_pipeline.hip", "drt_raster.hip", "drt_edges.hip", "drt_topology.hip", "drt_remesh_gpu.hip", "drt_remesh.cpp"]
 OUT = os.path.join(HERE, "libdrt_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 

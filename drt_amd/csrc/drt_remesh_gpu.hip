@@ -1,0 +1,440 @@
+// drt_remesh_gpu.hip -- the geometric kernels of the isotropic remesher on the device (drt_amd/remesh_gpu.py drives them).
+//
+// The reference re-tessellates the mesh between passes with MeshLab's "Isotropic Explicit Remeshing" (reference optim.py:12-52);
+// csrc/drt_remesh.cpp is the host restatement of that algorithm (Botsch & Kobbelt 2004: split > 4/3 L, collapse < 4/5 L, flip
+// towards valence 6, tangential relaxation, projection onto the input surface) with sequential edge operations.  This file is its
+// data-parallel form: every edge operation is EVALUATED for all candidates at once against the mesh as it stands; the candidates
+// that pass claim the vertices they would write with an atomicMin of their priority (collapses: shorter length class first, a hash
+// inside a class; flips: edge index), and those that no higher priority contests anywhere in what they read or write are APPLIED --
+// they share no face and do not change each other's premises, so they commute; the driver repeats evaluate / claim / apply on the
+// updated mesh until a round applies nothing.  Same acceptance rules as the host version (link condition, valence limits, consensus-normal fold
+// test, maximum edge length, MaxSurfDist through closest-point queries on the scene's tree), same split patterns, same
+// relaxation and roll-back; a different, but equally legitimate, visiting order -- so the two are compared statistically
+// (tests/test_gpu_remesh.py), the host version being the checker.
+//
+// Layout: faces int64 [F,3] (what drt_edge_tables takes), vertices float64 [V,3]; vertex -> incident faces as a CSR pair
+// (vf_start int64 [V+1], vf_face int64 [3F]: face ids grouped by vertex, ascending -- built by the driver with a stable sort).
+#include "drt_scene.h"
+
+namespace {
+
+constexpr int kMaxRing = 32;          // neighbours of one vertex an edge operation looks at (a vertex with more is left alone)
+
+__device__ __forceinline__ double len3(d3 a) { return sqrt(dot(a, a)); }
+__device__ __forceinline__ d3 ldv(const double* __restrict__ V, int64_t i) { return load_d3(V, i); }
+__device__ __forceinline__ d3 tri_normal(d3 a, d3 b, d3 c) { return cross(b - a, c - a); }
+
+// cosine between a face normal n and the consensus (sum of the area-weighted vertex normals) of its corners; 1 without a consensus
+__device__ __forceinline__ double agreement(d3 n, const double* __restrict__ vn, int64_t a, int64_t b, int64_t c) {
+    const d3 r = (ldv(vn, a) + ldv(vn, b)) + ldv(vn, c);
+    const double ln = len3(n), lr = len3(r);
+    return ln > 0 && lr > 0 ? dot(n, r) / (ln * lr) : (ln > 0 ? 1.0 : -1.0);
+}
+__device__ __forceinline__ bool acceptable(double before, double after) { return after >= 0.3 || after >= before; }
+
+struct Ring {
+    int n;
+    bool overflow;
+    int64_t v[kMaxRing];
+    __device__ void add(int64_t u) {
+        for (int k = 0; k < n; ++k) if (v[k] == u) return;
+        if (n < kMaxRing) v[n++] = u; else overflow = true;
+    }
+    __device__ bool has(int64_t u) const { for (int k = 0; k < n; ++k) if (v[k] == u) return true; return false; }
+};
+__device__ __forceinline__ void collect_ring(int64_t v, const int64_t* __restrict__ F, const int64_t* __restrict__ vf_start,
+                                             const int64_t* __restrict__ vf_face, Ring& r) {
+    r.n = 0; r.overflow = false;
+    for (int64_t q = vf_start[v]; q < vf_start[v + 1]; ++q) {
+        const int64_t f = vf_face[q];
+        for (int k = 0; k < 3; ++k) { const int64_t u = F[3 * f + k]; if (u != v) r.add(u); }
+    }
+}
+
+// ---- split -------------------------------------------------------------------------------------------------------------------
+// per face: the midpoint vertex of each of its edges (-1: not split) -> number of faces it becomes
+__global__ void k_rm_split_count(const int32_t* __restrict__ row2edge, const int64_t* __restrict__ mid_of_edge, int64_t n_faces,
+                                 int64_t* __restrict__ count) {
+    const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (f >= n_faces) return;
+    int n = 0;
+    for (int k = 0; k < 3; ++k) n += mid_of_edge[row2edge[3 * f + k]] >= 0;
+    count[f] = n + 1;
+}
+// the patterns of drt_remesh.cpp::split_long_edges: 1 -> 2 faces, 2 -> 3 with the shorter diagonal, 3 -> 4
+__global__ void k_rm_split_faces(const int64_t* __restrict__ F, const int32_t* __restrict__ row2edge, const int64_t* __restrict__ mid_of_edge,
+                                 const double* __restrict__ V /* midpoints already appended */, int64_t n_faces,
+                                 const int64_t* __restrict__ offset /* exclusive prefix sum of the counts */, int64_t* __restrict__ out) {
+    const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (f >= n_faces) return;
+    const int64_t v[3] = {F[3 * f], F[3 * f + 1], F[3 * f + 2]};
+    const int64_t m[3] = {mid_of_edge[row2edge[3 * f]], mid_of_edge[row2edge[3 * f + 1]], mid_of_edge[row2edge[3 * f + 2]]};
+    const int n = (m[0] >= 0) + (m[1] >= 0) + (m[2] >= 0);
+    int64_t* o = out + 3 * offset[f];
+    auto put = [&](int t, int64_t a, int64_t b, int64_t c) { o[3 * t] = a; o[3 * t + 1] = b; o[3 * t + 2] = c; };
+    if (n == 0) { put(0, v[0], v[1], v[2]); return; }
+    if (n == 3) { put(0, v[0], m[0], m[2]); put(1, m[0], v[1], m[1]); put(2, m[2], m[1], v[2]); put(3, m[0], m[1], m[2]); return; }
+    if (n == 1) {
+        const int r = m[0] >= 0 ? 0 : (m[1] >= 0 ? 1 : 2);                      // split edge (a, b)
+        const int64_t a = v[r], b = v[(r + 1) % 3], c = v[(r + 2) % 3], mab = m[r];
+        put(0, a, mab, c); put(1, mab, b, c);
+        return;
+    }
+    const int r = m[0] < 0 ? 1 : (m[1] < 0 ? 2 : 0);                            // the unsplit edge is (c, a); split (a, b) and (b, c)
+    const int64_t a = v[r], b = v[(r + 1) % 3], c = v[(r + 2) % 3], mab = m[r], mbc = m[(r + 1) % 3];
+    put(0, mab, b, mbc);
+    if (len3(ldv(V, a) - ldv(V, mbc)) <= len3(ldv(V, mab) - ldv(V, c))) { put(1, a, mab, mbc); put(2, a, mbc, c); }
+    else { put(1, a, mab, c); put(2, mab, mbc, c); }
+}
+
+// ---- vertex normals (area-weighted, summed in CSR order: deterministic) ------------------------------------------------------------
+__global__ void k_rm_vertex_normals(const int64_t* __restrict__ F, const double* __restrict__ V, const int64_t* __restrict__ vf_start,
+                                    const int64_t* __restrict__ vf_face, int64_t n_verts, double* __restrict__ vn) {
+    const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (v >= n_verts) return;
+    d3 s{0, 0, 0};
+    for (int64_t q = vf_start[v]; q < vf_start[v + 1]; ++q) {
+        const int64_t f = vf_face[q];
+        s += tri_normal(ldv(V, F[3 * f]), ldv(V, F[3 * f + 1]), ldv(V, F[3 * f + 2]));
+    }
+    store_d3(vn, v, s);
+}
+
+// ---- collapse -----------------------------------------------------------------------------------------------------------------
+// faces around `v` (other than the two that die with edge (a, b)) must stay valid when v moves to pnew; their centroids after the move
+// go to the query list (drt_remesh.cpp::faces_stay_valid)
+__device__ bool faces_stay_valid(int64_t v, d3 pnew, int64_t ea, int64_t eb, const int64_t* __restrict__ F, const double* __restrict__ V,
+                                 const double* __restrict__ vn, const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face,
+                                 double max_len, double* __restrict__ q, int& nq, int max_q) {
+    for (int64_t s = vf_start[v]; s < vf_start[v + 1]; ++s) {
+        const int64_t f = vf_face[s];
+        const int64_t t[3] = {F[3 * f], F[3 * f + 1], F[3 * f + 2]};
+        if ((t[0] == ea || t[1] == ea || t[2] == ea) && (t[0] == eb || t[1] == eb || t[2] == eb)) continue;     // dies
+        d3 p[3] = {ldv(V, t[0]), ldv(V, t[1]), ldv(V, t[2])};
+        const d3 n0 = tri_normal(p[0], p[1], p[2]);
+        for (int k = 0; k < 3; ++k) if (t[k] == v) p[k] = pnew;
+        const d3 n1 = tri_normal(p[0], p[1], p[2]);
+        const double l0 = len3(n0), l1 = len3(n1);
+        if (!(l1 > 1e-12 * (1.0 + l0))) return false;                                                            // degenerate
+        if (!acceptable(agreement(n0, vn, t[0], t[1], t[2]), agreement(n1, vn, t[0], t[1], t[2]))) return false;   // would fold
+        for (int k = 0; k < 3; ++k) if (t[k] != v && len3(p[k] - pnew) > max_len) return false;                  // would need a split again
+        if (nq >= max_q) return false;
+        const d3 c = ((p[0] + p[1]) + p[2]) * (1.0 / 3.0);
+        q[3 * nq] = c.x; q[3 * nq + 1] = c.y; q[3 * nq + 2] = c.z; ++nq;
+    }
+    return true;
+}
+
+// one thread per candidate edge (length < min_len, listed by the driver): every check of drt_remesh.cpp::collapse_short_edges but the
+// surface distance, whose query points (the midpoint, then the centroids of the surviving faces) it writes to q[c][max_q][3]
+__global__ void k_rm_collapse_eval(const int64_t* __restrict__ cand, int64_t n_cand, const int64_t* __restrict__ E, const int64_t* __restrict__ F,
+                                   const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start,
+                                   const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
+                                   uint8_t* __restrict__ ok, int32_t* __restrict__ n_query, double* __restrict__ q) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    ok[c] = 0; n_query[c] = 0;
+    const int64_t e = cand[c], a = E[2 * e], b = E[2 * e + 1];
+    const d3 pa = ldv(V, a), pb = ldv(V, b);
+    if (!(len3(pa - pb) < min_len)) return;
+    Ring ra, rb;
+    collect_ring(a, F, vf_start, vf_face, ra);
+    collect_ring(b, F, vf_start, vf_face, rb);
+    if (ra.overflow || rb.overflow) return;
+    int common = 0;
+    int64_t opp[2] = {-1, -1};
+    for (int k = 0; k < ra.n; ++k) if (rb.has(ra.v[k])) { if (common < 2) opp[common] = ra.v[k]; ++common; }
+    if (common != 2) return;                                                                        // link condition
+    const int64_t va = vf_start[a + 1] - vf_start[a], vb = vf_start[b + 1] - vf_start[b];
+    if (vf_start[opp[0] + 1] - vf_start[opp[0]] < 4 || vf_start[opp[1] + 1] - vf_start[opp[1]] < 4) return;   // no valence-3 vertices
+    if (va + vb - 4 < 3) return;
+    const d3 m = (pa + pb) * 0.5;
+    double* qc = q + 3 * (int64_t)max_q * c;
+    int nq = 0;
+    qc[0] = m.x; qc[1] = m.y; qc[2] = m.z; nq = 1;
+    if (!faces_stay_valid(a, m, a, b, F, V, vn, vf_start, vf_face, max_len, qc, nq, max_q)) return;
+    if (!faces_stay_valid(b, m, a, b, F, V, vn, vf_start, vf_face, max_len, qc, nq, max_q)) return;
+    n_query[c] = nq;
+    ok[c] = 1;
+}
+
+// Priority of a collapse: the shorter edges first (eight length classes below min_len, as the host version's sweep goes by length), a
+// hash inside a class -- a strict (length, index) order leaves only the local minima of a smooth field to win a round, one candidate
+// in a hundred -- and the edge index for uniqueness.
+__device__ __forceinline__ unsigned long long collapse_key(double l, double min_len, int64_t e, unsigned seed) {
+    int cls = (int)(8.0 * l / min_len);
+    cls = cls < 0 ? 0 : (cls > 15 ? 15 : cls);
+    unsigned h = (unsigned)e * 2654435761u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    return ((unsigned long long)cls << 44) | ((unsigned long long)(h & 0xFFFu) << 32) | (unsigned long long)(uint32_t)e;
+}
+// A collapse WRITES a, b (position, faces) and the two vertices opposite the edge (their valence drops) and READS both rings.  It claims
+// what it writes (64-bit atomicMin of its priority) and goes ahead when nobody with a higher priority has claimed anything it reads or
+// writes: two collapses that go ahead in one round then share no face, and neither changes a valence or a position the other's checks
+// relied on.
+template <bool APPLY>
+__global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_cand, const uint8_t* __restrict__ ok, const int64_t* __restrict__ E,
+                                    int64_t* F, double* V, const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double min_len,
+                                    unsigned seed, const double* __restrict__ length, unsigned long long* lock, uint8_t* __restrict__ f_alive,
+                                    uint8_t* __restrict__ v_alive, int32_t* n_done) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n_cand || !ok[c]) return;
+    const int64_t e = cand[c], a = E[2 * e], b = E[2 * e + 1];
+    const unsigned long long key = collapse_key(length[e], min_len, e, seed);      // (from the lengths of the round's start: V changes under APPLY)
+    Ring ra, rb;
+    collect_ring(a, F, vf_start, vf_face, ra);
+    collect_ring(b, F, vf_start, vf_face, rb);
+    if (!APPLY) {
+        atomicMin(&lock[a], key); atomicMin(&lock[b], key);
+        for (int k = 0; k < ra.n; ++k) if (rb.has(ra.v[k])) atomicMin(&lock[ra.v[k]], key);       // the two opposite vertices
+        return;
+    }
+    bool mine = lock[a] == key && lock[b] == key;
+    for (int k = 0; k < ra.n && mine; ++k) mine = lock[ra.v[k]] >= key;
+    for (int k = 0; k < rb.n && mine; ++k) mine = lock[rb.v[k]] >= key;
+    if (!mine) return;
+    // commit: b -> a, a moves to the midpoint, the two shared faces die (every face touched has all its vertices under this claim)
+    const d3 m = (ldv(V, a) + ldv(V, b)) * 0.5;
+    for (int64_t s = vf_start[b]; s < vf_start[b + 1]; ++s) {
+        const int64_t f = vf_face[s];
+        const bool shared = F[3 * f] == a || F[3 * f + 1] == a || F[3 * f + 2] == a;
+        if (shared) { f_alive[f] = 0; continue; }
+        for (int k = 0; k < 3; ++k) if (F[3 * f + k] == b) F[3 * f + k] = a;
+    }
+    v_alive[b] = 0;
+    store_d3(V, a, m);
+    atomicAdd(n_done, 1);
+}
+
+// ---- flip ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool edge_exists(const int64_t* __restrict__ E, int64_t n_edges, int64_t x, int64_t y) {
+    const int64_t lo = x < y ? x : y, hi = x < y ? y : x;
+    int64_t l = 0, r = n_edges;                                  // E ascends by (lo, hi)
+    while (l < r) {
+        const int64_t mid = (l + r) >> 1;
+        const int64_t a = E[2 * mid], b = E[2 * mid + 1];
+        if (a < lo || (a == lo && b < hi)) l = mid + 1; else r = mid;
+    }
+    return l < n_edges && E[2 * l] == lo && E[2 * l + 1] == hi;
+}
+// one thread per edge: the rules of drt_remesh.cpp::flip_edges (valence improvement across nearly flat pairs, or the repair of a folded
+// pair); edge_rows [E,2] = the two directed-edge rows (3 f + k) of every unique edge.  Writes the four vertices and two faces of a flip
+// that passes, and the midpoint of the new edge as its surface-distance query.
+__global__ void k_rm_flip_eval(const int64_t* __restrict__ E, int64_t n_edges, const int64_t* __restrict__ edge_rows, const int64_t* __restrict__ F,
+                               const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start, double max_len,
+                               uint8_t* __restrict__ ok, int64_t* __restrict__ quad /* [E,6]: a b c d f1 f2 */, double* __restrict__ q) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    ok[e] = 0;
+    const int64_t a = E[2 * e], b = E[2 * e + 1];
+    int64_t f1 = edge_rows[2 * e] / 3, f2 = edge_rows[2 * e + 1] / 3;
+    auto has_dir = [&](int64_t f, int64_t x, int64_t y) { for (int k = 0; k < 3; ++k) if (F[3 * f + k] == x && F[3 * f + (k + 1) % 3] == y) return true; return false; };
+    if (!has_dir(f1, a, b)) { const int64_t t = f1; f1 = f2; f2 = t; }
+    if (!has_dir(f1, a, b) || !has_dir(f2, b, a)) return;
+    auto third = [&](int64_t f) { for (int k = 0; k < 3; ++k) if (F[3 * f + k] != a && F[3 * f + k] != b) return F[3 * f + k]; return (int64_t)-1; };
+    const int64_t c = third(f1), d = third(f2);
+    if (c < 0 || d < 0 || c == d) return;
+    auto val = [&](int64_t v) { return (int)(vf_start[v + 1] - vf_start[v]); };
+    const int va = val(a), vb = val(b), vc = val(c), vd = val(d);
+    if (va < 4 || vb < 4) return;
+    const d3 pa = ldv(V, a), pb = ldv(V, b), pc = ldv(V, c), pd = ldv(V, d);
+    const d3 n1 = tri_normal(ldv(V, F[3 * f1]), ldv(V, F[3 * f1 + 1]), ldv(V, F[3 * f1 + 2]));
+    const d3 n2 = tri_normal(ldv(V, F[3 * f2]), ldv(V, F[3 * f2 + 1]), ldv(V, F[3 * f2 + 2]));
+    const d3 m1 = tri_normal(pc, pa, pd), m2 = tri_normal(pd, pb, pc);
+    const double l1 = len3(n1), l2 = len3(n2), k1 = len3(m1), k2 = len3(m2);
+    if (!(k1 > 1e-12 * (1.0 + l1)) || !(k2 > 1e-12 * (1.0 + l2))) return;
+    const bool folded = dot(n1, n2) < -0.5 * l1 * l2;                      // the pair overlaps itself: repair, whatever the valences
+    if (folded) {
+        if (dot(m1, m2) < 0.5 * k1 * k2) return;
+        if (agreement(m1, vn, c, a, d) < 0.3 || agreement(m2, vn, d, b, c) < 0.3) return;
+    } else {
+        const int before = abs(va - 6) + abs(vb - 6) + abs(vc - 6) + abs(vd - 6);
+        const int after = abs(va - 7) + abs(vb - 7) + abs(vc - 5) + abs(vd - 5);
+        if (after >= before) return;
+        if (dot(n1, n2) < 0.94 * l1 * l2) return;                          // only across nearly flat pairs (< 20 degrees)
+        if (dot(m1, n1) < 0.5 * k1 * l1 || dot(m1, n2) < 0.5 * k1 * l2 || dot(m2, n1) < 0.5 * k2 * l1 || dot(m2, n2) < 0.5 * k2 * l2) return;
+    }
+    if (edge_exists(E, n_edges, c, d)) return;
+    if (len3(pc - pd) > max_len) return;
+    const d3 mid = (pc + pd) * 0.5;
+    q[3 * e] = mid.x; q[3 * e + 1] = mid.y; q[3 * e + 2] = mid.z;
+    int64_t* o = quad + 6 * e;
+    o[0] = a; o[1] = b; o[2] = c; o[3] = d; o[4] = f1; o[5] = f2;
+    ok[e] = 1;
+}
+template <bool APPLY>
+__global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok, const int64_t* __restrict__ quad, int64_t* F, unsigned* lock, int32_t* n_done) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= n_edges || !ok[e]) return;
+    const int64_t* o = quad + 6 * e;
+    const unsigned key = (unsigned)e;
+    if (!APPLY) { for (int k = 0; k < 4; ++k) atomicMin(&lock[o[k]], key); return; }
+    for (int k = 0; k < 4; ++k) if (lock[o[k]] != key) return;
+    const int64_t a = o[0], b = o[1], c = o[2], d = o[3], f1 = o[4], f2 = o[5];
+    F[3 * f1] = c; F[3 * f1 + 1] = a; F[3 * f1 + 2] = d;
+    F[3 * f2] = d; F[3 * f2 + 1] = b; F[3 * f2 + 2] = c;
+    atomicAdd(n_done, 1);
+}
+
+// ---- relaxation / projection with roll-back ---------------------------------------------------------------------------------------
+// tangential relaxation target: the ring centroid moved back along the vertex normal (drt_remesh.cpp::smooth_tangential)
+__global__ void k_rm_smooth_target(const int64_t* __restrict__ F, const double* __restrict__ V, const int64_t* __restrict__ vf_start,
+                                   const int64_t* __restrict__ vf_face, int64_t n_verts, double* __restrict__ target) {
+    const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (v >= n_verts) return;
+    const d3 pv = ldv(V, v);
+    store_d3(target, v, pv);
+    if (vf_start[v + 1] == vf_start[v]) return;
+    d3 n{0, 0, 0};
+    for (int64_t s = vf_start[v]; s < vf_start[v + 1]; ++s) {
+        const int64_t f = vf_face[s];
+        n += tri_normal(ldv(V, F[3 * f]), ldv(V, F[3 * f + 1]), ldv(V, F[3 * f + 2]));
+    }
+    const double ln = len3(n);
+    if (!(ln > 0)) return;
+    n = n * (1.0 / ln);
+    Ring r;
+    collect_ring(v, F, vf_start, vf_face, r);
+    if (r.overflow || r.n == 0) return;
+    for (int i = 1; i < r.n; ++i) {                                   // ascending ids: a summation order that does not depend on the adjacency order
+        const int64_t x = r.v[i];
+        int j = i - 1;
+        while (j >= 0 && r.v[j] > x) { r.v[j + 1] = r.v[j]; --j; }
+        r.v[j + 1] = x;
+    }
+    d3 g{0, 0, 0};
+    for (int i = 0; i < r.n; ++i) g += ldv(V, r.v[i]);
+    g = g * (1.0 / (double)r.n);
+    store_d3(target, v, g + n * dot(n, pv - g));
+}
+// agreement of every face with the consensus before the move
+__global__ void k_rm_face_agreement(const int64_t* __restrict__ F, const double* __restrict__ V, const double* __restrict__ vn, int64_t n_faces,
+                                    double* __restrict__ a0) {
+    const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (f >= n_faces) return;
+    const int64_t a = F[3 * f], b = F[3 * f + 1], c = F[3 * f + 2];
+    a0[f] = agreement(tri_normal(ldv(V, a), ldv(V, b), ldv(V, c)), vn, a, b, c);
+}
+// a face the move degenerated or folded takes its three vertices back (flags; the driver applies them and calls again, four rounds at most)
+__global__ void k_rm_move_check(const int64_t* __restrict__ F, const double* __restrict__ V, const double* __restrict__ vn, const double* __restrict__ a0,
+                                int64_t n_faces, uint8_t* __restrict__ revert, int32_t* n_bad) {
+    const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (f >= n_faces) return;
+    const int64_t a = F[3 * f], b = F[3 * f + 1], c = F[3 * f + 2];
+    const d3 n1 = tri_normal(ldv(V, a), ldv(V, b), ldv(V, c));
+    if (!(len3(n1) > 0) || !acceptable(a0[f], agreement(n1, vn, a, b, c))) {
+        revert[a] = 1; revert[b] = 1; revert[c] = 1;
+        atomicAdd(n_bad, 1);
+    }
+}
+__global__ void k_rm_revert(double* __restrict__ V, const double* __restrict__ old, const uint8_t* __restrict__ revert, int64_t n_verts) {
+    const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (v < n_verts && revert[v]) store_d3(V, v, ldv(old, v));
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
+
+}  // namespace
+
+extern "C" {
+
+int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int32_t* d_row2edge, const int64_t* d_mid_of_edge, const double* d_verts,
+                       int64_t* d_count, const int64_t* d_offset, int64_t* d_faces_out, void* stream) {
+    if (n_faces < 0) return fail(DRT_E_INVALID, "negative face count");
+    if (n_faces == 0) return DRT_OK;
+    if (!d_faces || !d_row2edge || !d_mid_of_edge) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (d_count) k_rm_split_count<<<blocks_for(n_faces), 256, 0, st>>>(d_row2edge, d_mid_of_edge, n_faces, d_count);
+    if (d_faces_out) {
+        if (!d_offset || !d_verts) return fail(DRT_E_INVALID, "null pointer argument");
+        k_rm_split_faces<<<blocks_for(n_faces), 256, 0, st>>>(d_faces, d_row2edge, d_mid_of_edge, d_verts, n_faces, d_offset, d_faces_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
+                          double* d_vn, void* stream) {
+    if (n_verts <= 0) return DRT_OK;
+    if (!d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_vn) return fail(DRT_E_INVALID, "null pointer argument");
+    k_rm_vertex_normals<<<blocks_for(n_verts), 256, 0, (hipStream_t)stream>>>(d_faces, d_verts, d_vf_start, d_vf_face, n_verts, d_vn);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d_edges, const int64_t* d_faces, const double* d_verts,
+                         const double* d_vn, const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, double max_len, int max_q,
+                         uint8_t* d_ok, int32_t* d_n_query, double* d_query, void* stream) {
+    if (n_cand <= 0) return DRT_OK;
+    if (!d_cand || !d_edges || !d_faces || !d_verts || !d_vn || !d_vf_start || !d_vf_face || !d_ok || !d_n_query || !d_query || max_q < 1)
+        return fail(DRT_E_INVALID, "bad argument");
+    k_rm_collapse_eval<<<blocks_for(n_cand), 256, 0, (hipStream_t)stream>>>(d_cand, n_cand, d_edges, d_faces, d_verts, d_vn, d_vf_start, d_vf_face,
+                                                                           min_len, max_len, max_q, d_ok, d_n_query, d_query);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
+                          const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, uint32_t seed, const double* d_length,
+                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, int32_t* d_n_done, void* stream) {
+    if (n_cand <= 0) return DRT_OK;
+    if (!d_cand || !d_ok || !d_edges || !d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_length || !d_lock || !d_f_alive || !d_v_alive || !d_n_done)
+        return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* lock = reinterpret_cast<unsigned long long*>(d_lock);
+    k_rm_collapse_claim<false><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, seed, d_length, lock, d_f_alive, d_v_alive, d_n_done);
+    k_rm_collapse_claim<true><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, seed, d_length, lock, d_f_alive, d_v_alive, d_n_done);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_flip_eval(const int64_t* d_edges, int64_t n_edges, const int64_t* d_edge_rows, const int64_t* d_faces, const double* d_verts, const double* d_vn,
+                     const int64_t* d_vf_start, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream) {
+    if (n_edges <= 0) return DRT_OK;
+    if (!d_edges || !d_edge_rows || !d_faces || !d_verts || !d_vn || !d_vf_start || !d_ok || !d_quad || !d_query) return fail(DRT_E_INVALID, "null pointer argument");
+    k_rm_flip_eval<<<blocks_for(n_edges), 256, 0, (hipStream_t)stream>>>(d_edges, n_edges, d_edge_rows, d_faces, d_verts, d_vn, d_vf_start, max_len, d_ok, d_quad, d_query);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, uint32_t* d_lock, int32_t* d_n_done, void* stream) {
+    if (n_edges <= 0) return DRT_OK;
+    if (!d_ok || !d_quad || !d_faces || !d_lock || !d_n_done) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    k_rm_flip_claim<false><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_n_done);
+    k_rm_flip_claim<true><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_n_done);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_smooth_target(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
+                         double* d_target, void* stream) {
+    if (n_verts <= 0) return DRT_OK;
+    if (!d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_target) return fail(DRT_E_INVALID, "null pointer argument");
+    k_rm_smooth_target<<<blocks_for(n_verts), 256, 0, (hipStream_t)stream>>>(d_faces, d_verts, d_vf_start, d_vf_face, n_verts, d_target);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_face_agreement(const int64_t* d_faces, const double* d_verts, const double* d_vn, int64_t n_faces, double* d_a0, void* stream) {
+    if (n_faces <= 0) return DRT_OK;
+    if (!d_faces || !d_verts || !d_vn || !d_a0) return fail(DRT_E_INVALID, "null pointer argument");
+    k_rm_face_agreement<<<blocks_for(n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, d_verts, d_vn, n_faces, d_a0);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_move_check(const int64_t* d_faces, double* d_verts, const double* d_old, const double* d_vn, const double* d_a0, int64_t n_faces,
+                      int64_t n_verts, uint8_t* d_revert, int32_t* d_n_bad, void* stream) {
+    if (n_faces <= 0) return DRT_OK;
+    if (!d_faces || !d_verts || !d_old || !d_vn || !d_a0 || !d_revert || !d_n_bad) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d_revert, 0, (size_t)n_verts, st));
+    HIP_TRY(hipMemsetAsync(d_n_bad, 0, sizeof(int32_t), st));
+    k_rm_move_check<<<blocks_for(n_faces), 256, 0, st>>>(d_faces, d_verts, d_vn, d_a0, n_faces, d_revert, d_n_bad);
+    k_rm_revert<<<blocks_for(n_verts), 256, 0, st>>>(d_verts, d_old, d_revert, n_verts);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+}  // extern "C"

@@ -284,9 +284,12 @@ def setup_opt(scene, lr, HyperParams, hook=True, fused=False):
 def optimize(scene, data, HyperParams, remesh="isotropic", output=True, fused=False):
     """The reference's pass / iteration loop (optim.py:190-215) for an existing scene and data object.
     ``remesh``: "isotropic" (default) re-tessellates to ``remesh_len`` before every pass like the reference's
-    ``meshlabserver.remesh`` (optim.py:195), with the in-process remesher of drt_amd.remesh; ``None`` keeps the
-    topology; or any callable ``remesh(scene, remesh_len)``."""
-    if remesh == "isotropic":
+    ``meshlabserver.remesh`` (optim.py:195), with the device remesher of drt_amd.remesh_gpu ("isotropic-host": the sequential
+    host version of drt_amd.remesh); ``None`` keeps the topology; or any callable ``remesh(scene, remesh_len)``."""
+    if remesh == "isotropic":               # on the device (drt_amd.remesh_gpu); "isotropic-host": the sequential host version, its checker
+        from .remesh_gpu import GpuMeshlabserver
+        remesh = GpuMeshlabserver().remesh
+    elif remesh == "isotropic-host":
         from .remesh import Meshlabserver
         remesh = Meshlabserver().remesh
     Render.intIOR = HyperParams["IOR"]

@@ -1,0 +1,262 @@
+"""Isotropic remeshing between optimisation passes ON THE DEVICE -- the data-parallel form of drt_amd/csrc/drt_remesh.cpp.
+
+    GpuMeshlabserver().remesh(scene, remesh_len)          reference optim.py:12-52 (Meshlabserver.remesh)
+
+The reference shells out to MeshLab's "Remeshing: Isotropic Explicit Remeshing" (3 iterations, TargetLen = remesh_len,
+MaxSurfDist 1, refine / collapse / swap / smooth / reproject).  ``drt_amd.remesh`` runs that algorithm (Botsch & Kobbelt 2004)
+sequentially on the host; here every step runs on the GPU without the mesh leaving it:
+
+    split     edge lengths, midpoints and the 1 -> 2 / 3 / 4 face patterns for all faces at once (drt_rm_split_faces)
+    collapse  all short edges evaluated at once (link condition, valences, fold test against the consensus normals, maximum
+              length, surface distance of the midpoint and of every surviving face's centroid through the scene's closest-point
+              kernel); the survivors claim their two rings by priority (length, index) and the ones that hold every claim are
+              applied -- disjoint neighbourhoods commute -- then the rest is evaluated again on the new mesh, until a round
+              applies nothing
+    flip      the same evaluate / claim / apply rounds on the four vertices of every edge
+    smooth    tangential relaxation of every vertex, faces that would fold take their vertices back (four rounds)
+    project   closest point on the INPUT surface (the tree of the scene the mesh came from), same roll-back
+    topology  edge tables by the radix sort of drt_edge_tables; vertex -> face lists by a stable sort
+
+The geometric decisions and the conflict-free application are hand-written kernels (csrc/drt_remesh_gpu.hip); torch provides the
+prefix sums, stable sorts and stream compactions in between (plumbing).  The result is a closed oriented manifold of the same
+genus with edge lengths concentrated around the target, on the input surface, deterministic -- and statistically the mesh the
+host version produces (tests/test_gpu_remesh.py holds the two against each other); vertex order and the exact set of operations
+differ, as they do between the host version and MeshLab.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, diffrender, mesh_io
+from .optix_mesh import _stream
+from .remesh import SPLIT, COLLAPSE, FLIP, SMOOTH, REPROJECT, CHECK_DIST, ALL  # noqa: F401
+
+MAX_Q = 24                 # surface-distance queries per collapse candidate (midpoint + surviving faces); more -> the edge is left alone
+MAX_ROUNDS = 96            # evaluate / claim / apply rounds per step (a round applies an independent set of the candidates: a few per cent)
+DEBUG = False
+
+
+def _check(rc):
+    _lib.check(rc)
+
+
+class _Work:
+    """The mesh being edited: float64 vertices [V,3], int64 faces [F,3] on the device, and the derived tables."""
+
+    def __init__(self, V, F, surface, max_dist):
+        self.V, self.F = V.contiguous(), F.contiguous()
+        self.surface, self.max_dist = surface, max_dist
+        self.dev = V.device
+
+    # ---- derived tables
+    def edges(self):
+        """Edges [E,2] ascending by (lo, hi), row2edge int32 [3F], edge_rows int64 [E,2] (the two directed-edge rows of every edge)."""
+        E, _, _, rows = diffrender.edge_tables(self.F, self.V, want_rows=True)
+        order = torch.argsort(rows, stable=True)                # rows grouped by edge id: two per edge (watertight: asserted above)
+        return E, rows, order.view(-1, 2)
+
+    def csr(self):
+        """vertex -> incident faces: vf_start int64 [V+1], vf_face int64 [3F] (ascending face order inside a vertex)."""
+        flat = self.F.reshape(-1)
+        order = torch.argsort(flat, stable=True)
+        vf_face = (order // 3).contiguous()
+        counts = torch.bincount(flat, minlength=self.V.shape[0])
+        vf_start = torch.zeros(self.V.shape[0] + 1, dtype=torch.long, device=self.dev)
+        torch.cumsum(counts, 0, out=vf_start[1:])
+        return vf_start, vf_face
+
+    def vertex_normals(self, vf_start, vf_face):
+        vn = torch.empty_like(self.V)
+        _check(_lib.lib().drt_rm_vertex_normals(self.F.data_ptr(), self.V.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(), self.V.shape[0],
+                                                vn.data_ptr(), _stream()))
+        return vn
+
+    def near_surface(self, points):
+        """bool [n]: within max_dist of the input surface (CheckSurfDist)."""
+        if self.surface is None or not np.isfinite(self.max_dist) or len(points) == 0:
+            return torch.ones(len(points), dtype=torch.bool, device=self.dev)
+        return self.surface.closest_point(points.contiguous(), want_face=False)[0] <= self.max_dist
+
+    # ---- 1. refine
+    def split_long_edges(self, max_len):
+        E, rows, _ = self.edges()
+        lo, hi = self.V[E[:, 0]], self.V[E[:, 1]]
+        long_ = (lo - hi).norm(dim=1) > max_len
+        n_split = int(long_.sum())
+        if n_split == 0:
+            return 0
+        nv = self.V.shape[0]
+        mid_of_edge = torch.full((E.shape[0],), -1, dtype=torch.long, device=self.dev)
+        mid_of_edge[long_] = nv + torch.arange(n_split, device=self.dev)
+        self.V = torch.cat([self.V, (lo[long_] + hi[long_]) * 0.5]).contiguous()          # (V[lo] + V[hi]) * 0.5: the host version's bits
+        nf = self.F.shape[0]
+        count = torch.empty(nf, dtype=torch.long, device=self.dev)
+        lib = _lib.lib()
+        _check(lib.drt_rm_split_faces(self.F.data_ptr(), nf, rows.data_ptr(), mid_of_edge.data_ptr(), None, count.data_ptr(), None, None, _stream()))
+        offset = torch.cumsum(count, 0) - count
+        out = torch.empty((int(count.sum()), 3), dtype=torch.long, device=self.dev)
+        _check(lib.drt_rm_split_faces(self.F.data_ptr(), nf, rows.data_ptr(), mid_of_edge.data_ptr(), self.V.data_ptr(), None, offset.data_ptr(),
+                                      out.data_ptr(), _stream()))
+        self.F = out
+        return n_split
+
+    # ---- 2. collapse
+    def collapse_short_edges(self, min_len, max_len):
+        lib = _lib.lib()
+        done = 0
+        v_alive = torch.ones(self.V.shape[0], dtype=torch.uint8, device=self.dev)
+        for rnd in range(MAX_ROUNDS):
+            E, _, _ = self.edges()
+            length = (self.V[E[:, 0]] - self.V[E[:, 1]]).norm(dim=1).contiguous()
+            cand = torch.nonzero(length < min_len).squeeze(1).contiguous()
+            if len(cand) == 0:
+                break
+            vf_start, vf_face = self.csr()
+            vn = self.vertex_normals(vf_start, vf_face)
+            ok = torch.zeros(len(cand), dtype=torch.uint8, device=self.dev)
+            nq = torch.zeros(len(cand), dtype=torch.int32, device=self.dev)
+            q = torch.empty((len(cand), MAX_Q, 3), dtype=torch.float64, device=self.dev)
+            _check(lib.drt_rm_collapse_eval(cand.data_ptr(), len(cand), E.data_ptr(), self.F.data_ptr(), self.V.data_ptr(), vn.data_ptr(),
+                                            vf_start.data_ptr(), vf_face.data_ptr(), float(min_len), float(max_len), MAX_Q,
+                                            ok.data_ptr(), nq.data_ptr(), q.data_ptr(), _stream()))
+            # CheckSurfDist: the midpoint and the centroid of every face that survives must stay near the input surface
+            used = torch.arange(MAX_Q, device=self.dev).unsqueeze(0) < nq.unsqueeze(1)
+            used &= ok.bool().unsqueeze(1)
+            pts = q[used]
+            near = self.near_surface(pts)
+            far_rows = torch.nonzero(used)[:, 0][~near]
+            ok[far_rows] = 0
+            if int(ok.sum()) == 0:
+                break
+            lock = torch.full((self.V.shape[0],), -1, dtype=torch.int64, device=self.dev)        # all ones = no claim (compared as unsigned)
+            f_alive = torch.ones(self.F.shape[0], dtype=torch.uint8, device=self.dev)
+            n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            _check(lib.drt_rm_collapse_apply(cand.data_ptr(), len(cand), ok.data_ptr(), E.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
+                                             vf_start.data_ptr(), vf_face.data_ptr(), float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, length.data_ptr(),
+                                             lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), n_done.data_ptr(), _stream()))
+            n = int(n_done.item())
+            if DEBUG:
+                print(f"  collapse round: {len(cand)} short edges, {int(ok.sum())} pass, {n} applied")
+            if n == 0:
+                break
+            done += n
+            self.F = self.F[f_alive.bool()].contiguous()
+        return done
+
+    # ---- 3. flip
+    def flip_edges(self, max_len):
+        lib = _lib.lib()
+        done = 0
+        for _ in range(MAX_ROUNDS):
+            E, _, edge_rows = self.edges()
+            vf_start, vf_face = self.csr()
+            vn = self.vertex_normals(vf_start, vf_face)
+            n_e = E.shape[0]
+            ok = torch.zeros(n_e, dtype=torch.uint8, device=self.dev)
+            quad = torch.empty((n_e, 6), dtype=torch.long, device=self.dev)
+            q = torch.zeros((n_e, 3), dtype=torch.float64, device=self.dev)
+            _check(lib.drt_rm_flip_eval(E.data_ptr(), n_e, edge_rows.contiguous().data_ptr(), self.F.data_ptr(), self.V.data_ptr(), vn.data_ptr(),
+                                        vf_start.data_ptr(), float(max_len), ok.data_ptr(), quad.data_ptr(), q.data_ptr(), _stream()))
+            idx = torch.nonzero(ok).squeeze(1)
+            if len(idx) == 0:
+                break
+            near = self.near_surface(q[idx])
+            ok[idx[~near]] = 0
+            if int(ok.sum()) == 0:
+                break
+            lock = torch.full((self.V.shape[0],), -1, dtype=torch.int32, device=self.dev)
+            n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), lock.data_ptr(), n_done.data_ptr(), _stream()))
+            n = int(n_done.item())
+            if DEBUG:
+                print(f"  flip round: {int(ok.sum())} pass, {n} applied")
+            if n == 0:
+                break
+            done += n
+        return done
+
+    # ---- 4./5. relaxation and projection, with roll-back
+    def move_vertices(self, target, vf_start, vf_face):
+        lib = _lib.lib()
+        old = self.V.clone()
+        vn = self.vertex_normals(vf_start, vf_face)
+        nf, nv = self.F.shape[0], self.V.shape[0]
+        a0 = torch.empty(nf, dtype=torch.float64, device=self.dev)
+        _check(lib.drt_rm_face_agreement(self.F.data_ptr(), self.V.data_ptr(), vn.data_ptr(), nf, a0.data_ptr(), _stream()))
+        self.V = target.contiguous()
+        revert = torch.empty(nv, dtype=torch.uint8, device=self.dev)
+        n_bad = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        for _ in range(4):
+            _check(lib.drt_rm_move_check(self.F.data_ptr(), self.V.data_ptr(), old.data_ptr(), vn.data_ptr(), a0.data_ptr(), nf, nv,
+                                         revert.data_ptr(), n_bad.data_ptr(), _stream()))
+            if int(n_bad.item()) == 0:
+                break
+
+    def smooth_tangential(self):
+        vf_start, vf_face = self.csr()
+        target = torch.empty_like(self.V)
+        _check(_lib.lib().drt_rm_smooth_target(self.F.data_ptr(), self.V.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(), self.V.shape[0],
+                                               target.data_ptr(), _stream()))
+        self.move_vertices(target, vf_start, vf_face)
+
+    def project_to_surface(self):
+        if self.surface is None:
+            return
+        vf_start, vf_face = self.csr()
+        _, _, closest = self.surface.closest_point(self.V.contiguous(), want_face=False, want_point=True)
+        self.move_vertices(closest, vf_start, vf_face)
+
+    def compact(self):
+        """Drop the vertices no face uses (ascending order kept)."""
+        used = torch.zeros(self.V.shape[0], dtype=torch.bool, device=self.dev)
+        used[self.F.reshape(-1)] = True
+        remap = torch.cumsum(used.long(), 0) - 1
+        self.V = self.V[used].contiguous()
+        self.F = remap[self.F].contiguous()
+
+
+def isotropic_remesh_gpu(vertices, faces, target_len, surface=None, iterations=3, max_surf_dist=1.0, flags=ALL, return_stats=False):
+    """(vertices float64 [V,3], faces int64 [F,3]) on the device -> the same, re-tessellated to edge lengths around ``target_len``.
+    ``surface``: an ``optix_mesh`` holding the INPUT surface (closest-point queries for the projection step and MaxSurfDist); None skips
+    both.  Closed manifold in, closed manifold out."""
+    if not vertices.is_cuda:
+        raise RuntimeError("isotropic_remesh_gpu needs device tensors (drt_amd.remesh is the host version)")
+    w = _Work(vertices.detach().to(torch.float64), faces.to(torch.long), surface, float(max_surf_dist) if (flags & CHECK_DIST) and max_surf_dist > 0 else float("inf"))
+    min_len, max_len = 0.8 * target_len, 4.0 / 3.0 * target_len
+    stats = {"split": 0, "collapsed": 0, "flipped": 0, "iterations": 0}
+    with torch.no_grad(), torch.cuda.device(vertices.device):
+        for _ in range(iterations):
+            if flags & SPLIT:
+                for _k in range(3):
+                    n = w.split_long_edges(max_len)
+                    stats["split"] += n
+                    if not n:
+                        break
+            if flags & COLLAPSE:
+                stats["collapsed"] += w.collapse_short_edges(min_len, max_len)
+            if flags & FLIP:
+                stats["flipped"] += w.flip_edges(max_len)
+            if flags & SMOOTH:
+                w.smooth_tangential()
+            if flags & REPROJECT:
+                w.project_to_surface()
+            w.compact()
+            stats["iterations"] += 1
+    return (w.V, w.F, stats) if return_stats else (w.V, w.F)
+
+
+class GpuMeshlabserver:
+    """Same role and call shape as the reference class (optim.py:12-52); the mesh stays on the device (``Scene._set_topology``), positions
+    are rounded through float32 like the reference's PLY round trip."""
+
+    def __init__(self, iterations=3, max_surf_dist=1.0):
+        self.iterations, self.max_surf_dist = iterations, max_surf_dist
+
+    def remesh(self, scene, remesh_len):
+        V, F = isotropic_remesh_gpu(scene.vertices.detach(), scene.faces, remesh_len, surface=scene.optix_mesh, iterations=self.iterations,
+                                    max_surf_dist=self.max_surf_dist)
+        scene._set_topology(V.to(torch.float32).to(torch.float64), F)
+        return scene

@@ -245,6 +245,47 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
 int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double* d_dist, int32_t* d_face,
                       double* d_closest, void* stream);
 
+/* ---- remeshing between passes ON THE DEVICE: the geometric kernels of drt_amd/remesh_gpu.py (csrc/drt_remesh_gpu.hip) ----------
+ * The data-parallel form of drt_remesh_isotropic below (same algorithm and acceptance rules; every candidate operation evaluated at
+ * once, the ones whose neighbourhoods do not overlap applied together, in rounds).  d_faces int64 [F,3], d_verts float64 [V,3];
+ * d_vf_start int64 [V+1] / d_vf_face int64 [3F]: vertex -> incident faces (CSR, ascending face ids); d_vn float64 [V,3]: area-weighted
+ * vertex normals (drt_rm_vertex_normals).  All pointers are DEVICE pointers; everything is enqueued on `stream`.
+ *   drt_rm_split_faces      d_mid_of_edge int64 [E]: the midpoint vertex of every unique edge or -1; d_row2edge int32 [3F] (drt_edge_tables).
+ *                           Pass 1 (d_count non-null): faces each face becomes (1..4).  Pass 2 (d_faces_out non-null, d_offset = exclusive
+ *                           prefix sum of the counts, d_verts with the midpoints appended): the new faces (1 -> 2, 2 -> 3 by the shorter
+ *                           diagonal, 3 -> 4).
+ *   drt_rm_collapse_eval    candidates d_cand int64 [n] (indices into d_edges int64 [E,2]): ok uint8 [n] = every rule but the surface
+ *                           distance; d_query float64 [n, max_q, 3] / d_n_query int32 [n]: the points whose distance to the input surface
+ *                           the caller still has to check (midpoint, centroids of the faces that survive).
+ *   drt_rm_collapse_apply   claim (64-bit atomicMin of (length class, hash(edge, seed), edge index) on d_lock uint64 [V], preset to all ones;
+ *                           d_length float64 [E]: edge lengths at the start of the round) what each candidate with ok = 1 writes, and
+ *                           apply those that nobody with a higher priority contests: faces rewritten in place, d_f_alive / d_v_alive
+ *                           cleared for what dies, *d_n_done += number applied.
+ *   drt_rm_flip_eval/apply  the same for edge flips (d_edge_rows int64 [E,2]: the two directed-edge rows 3f+k of every edge; d_quad int64
+ *                           [E,6] = a b c d f1 f2 of a flip that passes; d_query float64 [E,3] the midpoint of the new edge; d_lock uint32 [V]).
+ *   drt_rm_smooth_target    tangential relaxation targets float64 [V,3].
+ *   drt_rm_face_agreement   cosine between each face normal and the consensus of its corners, float64 [F] (before a move).
+ *   drt_rm_move_check       after vertices moved: every face that degenerated or folded (against d_a0) takes its three vertices back from
+ *                           d_old; *d_n_bad = their number (the caller repeats, four rounds at most). */
+int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int32_t* d_row2edge, const int64_t* d_mid_of_edge, const double* d_verts,
+                       int64_t* d_count, const int64_t* d_offset, int64_t* d_faces_out, void* stream);
+int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
+                          double* d_vn, void* stream);
+int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d_edges, const int64_t* d_faces, const double* d_verts,
+                         const double* d_vn, const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, double max_len, int max_q,
+                         uint8_t* d_ok, int32_t* d_n_query, double* d_query, void* stream);
+int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
+                          const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, uint32_t seed, const double* d_length,
+                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, int32_t* d_n_done, void* stream);
+int drt_rm_flip_eval(const int64_t* d_edges, int64_t n_edges, const int64_t* d_edge_rows, const int64_t* d_faces, const double* d_verts, const double* d_vn,
+                     const int64_t* d_vf_start, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream);
+int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, uint32_t* d_lock, int32_t* d_n_done, void* stream);
+int drt_rm_smooth_target(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
+                         double* d_target, void* stream);
+int drt_rm_face_agreement(const int64_t* d_faces, const double* d_verts, const double* d_vn, int64_t n_faces, double* d_a0, void* stream);
+int drt_rm_move_check(const int64_t* d_faces, double* d_verts, const double* d_old, const double* d_vn, const double* d_a0, int64_t n_faces,
+                      int64_t n_verts, uint8_t* d_revert, int32_t* d_n_bad, void* stream);
+
 /* ---- remeshing between passes (host code; all pointers here are HOST pointers) -------------------------
  * drt_remesh_isotropic <- Meshlabserver.remesh (optim.py:12-52): MeshLab's "Remeshing: Isotropic Explicit
  * Remeshing" with Iterations=iterations (3), TargetLen=target_len, CheckSurfDist / MaxSurfDist=max_surf_dist

@@ -15,19 +15,23 @@ scan = Render.Scene("data/horse_scan.ply", 0)
 center, extent = views.mesh_frame(scan.mesh.vertices)
 data = captured_data.SyntheticData(scan, center, extent, res, res, num_view=72, name="horse")
 print("hull      : faces %6d  mean %.4f rms %.4f max %.3f" % ((scene.faces.shape[0],) + tuple(metrics.hausdorff(scene, scan)[k] for k in ("mean", "rms", "max"))))
-lc = optim.Loss_calculator(scene, data, hp, fused=True)
-ml = Meshlabserver()
+from drt_amd.remesh_gpu import GpuMeshlabserver
+ml = Meshlabserver() if os.environ.get("REMESH", "gpu") == "host" else GpuMeshlabserver()
+print("remesher:", type(ml).__name__)
 t0 = time.time()
+t_remesh = 0.0
+views_ray = views_sil = None
 for i_pass in range(hp["Pass"]):
     remesh_len = optim.interp_R(hp["start_len"], hp["end_len"], i_pass, hp["Pass"])
     lr = optim.interp_R(hp["start_lr"], hp["lr_decay"] * hp["start_lr"], i_pass, hp["Pass"])
+    torch.cuda.synchronize(); tr = time.time()
     ml.remesh(scene, remesh_len)
-    init_vertices, parameter, opt = optim.setup_opt(scene, lr, hp)
+    torch.cuda.synchronize(); t_remesh += time.time() - tr
+    stepper = optim.FusedIteration(scene, data, hp, lr)
+    if views_ray is not None:
+        stepper.ray_view, stepper.silh_view = views_ray, views_sil
+    views_ray, views_sil = stepper.ray_view, stepper.silh_view
     for it in range(hp["Iters"]):
-        opt.zero_grad()
-        scene.update_verticex(init_vertices + parameter)
-        loss, parts = lc.all_loss()
-        loss.backward()
-        opt.step()
+        total, parts = stepper.step()
     h = metrics.hausdorff(scene, scan)
-    print("pass %2d len %5.2f: faces %6d  mean %.4f rms %.4f max %.3f  %s  (%.1f s)" % (i_pass, remesh_len, scene.faces.shape[0], h["mean"], h["rms"], h["max"], optim.loss_string(parts), time.time() - t0))
+    print("pass %2d len %5.2f: faces %6d  mean %.4f rms %.4f max %.3f  %s  (%.1f s, remesh %.2f s so far)" % (i_pass, remesh_len, scene.faces.shape[0], h["mean"], h["rms"], h["max"], optim.loss_string(tuple(parts)), time.time() - t0, t_remesh))
