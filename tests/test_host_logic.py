@@ -1,0 +1,85 @@
+"""Host-side logic that needs no GPU: the lazily materialised silhouette edge set, the provenance stamp of the PMC counters that
+bench.py prices its roofline with, the C-ABI surface of the device remesher."""
+import importlib.util
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_silhouette_edges_behave_like_the_tensor_the_reference_returns():
+    """Scene.silhouette_edge returns Edges[flags] lazily (reference DiffRender.py:445-457 returns the tensor itself): whoever looks at it --
+    indexing, len, shape, torch functions, .cpu() -- sees exactly that tensor; until then nothing has been compacted."""
+    from drt_amd.diffrender import SilhouetteEdges
+    edges = torch.arange(40).reshape(20, 2)
+    flags = (torch.arange(20) % 3 == 0).to(torch.uint8)
+    ref = edges[flags.bool()]
+    s = SilhouetteEdges(edges, flags)
+    assert s._t is None                                  # nothing materialised by construction
+    assert s.shape == ref.shape and len(s) == len(ref) and s.dtype == torch.long
+    assert s._t is not None
+    assert torch.equal(s[2], ref[2]) and torch.equal(s[:, 1], ref[:, 1])
+    assert torch.equal(torch.sort(s, dim=0).values, torch.sort(ref, dim=0).values)       # torch functions unwrap it
+    assert torch.equal(torch.cat([s, s]), torch.cat([ref, ref]))
+    assert np.array_equal(s.cpu().numpy(), ref.numpy()) and [tuple(r.tolist()) for r in s] == [tuple(r.tolist()) for r in ref]
+    assert "SilhouetteEdges" in repr(s)
+
+
+def _load_bench():
+    spec = importlib.util.spec_from_file_location("bench_module_for_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pmc_counters_are_only_used_with_the_kernel_sources_they_were_collected_on(tmp_path, monkeypatch):
+    """profiles/pmc.json carries a sha256 of drt_amd/csrc + include (tools/make_pmc_json.py); bench.py recomputes it and refuses to mix
+    counters of other kernels with this run's launch times (`pmc_stale`)."""
+    from drt_amd import build
+    h = build.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{64}", h) and h == build.source_hash()
+    bench = _load_bench()
+    fake_root = tmp_path
+    (fake_root / "profiles").mkdir()
+    rec = {"workload": "horse res 1024 views 72 streams default", "dropin": {"k_trace<false, 0>": {"SQ_INSTS_VALU": 1.5e8, "launches": 4}},
+           "source_sha256": h, "git_head": "abc"}
+    (fake_root / "profiles" / "pmc.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(fake_root))
+    pmc, prov = bench._pmc("dropin", rec["workload"])
+    assert pmc and prov["stale"] is False and prov["source_sha256"] == h
+    pmc2, _ = bench._pmc("dropin", "another workload")
+    assert pmc2 == {}                                     # counters of another workload are not used at all
+    rec["source_sha256"] = "0" * 64
+    (fake_root / "profiles" / "pmc.json").write_text(json.dumps(rec))
+    pmc3, prov3 = bench._pmc("dropin", rec["workload"])
+    assert prov3["stale"] is True and prov3["sources_now_sha256"] == h
+    (fake_root / "profiles" / "pmc.json").unlink()
+    assert bench._pmc("dropin", rec["workload"])[1]["stale"] is True
+
+
+def test_make_pmc_json_stamps_the_sources(tmp_path):
+    src = tmp_path / "run"
+    src.mkdir()
+    (src / "pmc_sq1.txt").write_text("void k_trace<false, 0>  launches=4\n   SQ_INSTS_VALU total=6e8 per_launch=1.5e8\n")
+    dst = tmp_path / "pmc.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_pmc_json.py"), str(src), str(dst), "dropin"], stdout=subprocess.DEVNULL)
+    rec = json.loads(dst.read_text())
+    from drt_amd import build
+    assert rec["source_sha256"] == build.source_hash() and rec["dropin"]["k_trace<false, 0>"]["SQ_INSTS_VALU"] == 1.5e8
+
+
+def test_fused_terms_and_weights_host_arithmetic():
+    """loss_weights mirrors reference optim.py:127-129; interp_R / interp_L the pass schedule (optim.py:145-153)."""
+    from drt_amd import optim as O
+    hp = dict(O.HyperParams)
+    w = O.loss_weights(hp, 960, 2.5)
+    assert w == (40 * 217.5 / 960 / 960, 2e-3 * 217.5 / 960, 0.08 * 2.5 / 10)
+    assert O.interp_R(10, 1, 0, 20) == pytest.approx(10) and O.interp_R(10, 1, 19, 20) == pytest.approx(1)
+    assert O.interp_L(0.0, 1.9, 10, 20) == pytest.approx(1.0)

@@ -2,7 +2,7 @@
 # The measurement batch whose outputs go to profiles/ at the end of a round (run on the GPU box through gpurun).
 # usage: bash tools/final_runs.sh <prefix>      e.g. r02
 set -u
-P=${1:-r02}
+P=${1:-r03}
 O=gpurun_out/final_$P; mkdir -p $O
 {
   for cfg in "--mesh hand --res 512 --views 72" "--mesh mouse --res 1024 --views 72" "--mesh horse --res 1024 --views 72" "--mesh monkey --res 1024 --views 72" "--mesh monkey --res 1024 --views 144"; do
@@ -18,10 +18,26 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg ::', d['ms_
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
   done
-  python bench.py --views 9 --graph 1 --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
+  for v in 36 18 9; do
+    python bench.py --views $v --graph 1 --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views 9 whole-step hipGraph', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v whole-step hipGraph (what N > 1 runs)', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
+  done
+  # the RCCL path of a step with ONE rank (communicator, collective launch, its capture): DRT_DIST_FORCE
+  DRT_DIST_FORCE=1 python bench.py --views 9 --graph 1 --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views 9 whole-step hipGraph with the all-reduce issued through RCCL (one rank)', d['ms_per_step'], 'ms/step')"
+  # the one-kernel path (k_path, opt-in) at the same shares: the negative result of DESIGN.md section 6
+  for v in 18 9; do
+    DRT_MEGA_MAX_LOG2=25 DRT_BENCH_NOPROF=1 python bench.py --views $v --no-cpu-baseline --no-extras --steps 40 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager, DRT_MEGA_MAX_LOG2=25 (k_path)', d['ms_per_step'], 'ms/step')"
+  done
 } > $O/scaling_proxy.txt 2>&1
+python tools/ubench/trace_repeat.py 9 2>&1 | grep -v amdgpu > $O/trace_repeat.txt
+python tools/ubench/reorder_probe.py 2>&1 | grep -v amdgpu > $O/reorder_probe.txt
+for r in gpu host; do REMESH=$r python tools/recon_trend.py 2>&1 | grep -v amdgpu > $O/recon_trend_$r.txt; done
+python -m drt_amd.reconstruct --name monkey --views 144 --res 1024 2>&1 | grep -v amdgpu > $O/recon_monkey_144views.txt
 # the launch line of the driver's multi-GPU runs, two ranks on this box's one GPU (gloo instead of RCCL): functional check of bench.py's N > 1 path
 DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
