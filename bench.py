@@ -318,9 +318,9 @@ def main():
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it; 0: eager; "
-                         "-1 (default): graph when N > 1 -- a rank's share of the views is a chain of small launches whose host enqueue and launch "
-                         "gaps a replay removes (9 views: 0.69 vs 0.73 ms) -- eager at N = 1, where the live per-kernel timing wants events "
-                         "inside the timed region; falls back to eager if the capture fails")
+                         "-1 (default): graph when N > 1 AND the rank's share is below 2^24 camera rays -- a chain of small launches whose host enqueue "
+                         "and launch gaps a replay removes (9 views: 0.69 vs 0.72 ms; at 36 views a replay is 13 %% slower than eager) -- eager otherwise; "
+                         "falls back to eager if the capture fails")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras after the timed region (fused-mode comparison, traversal statistics); "
@@ -396,8 +396,12 @@ def main():
         return O.full_batch_step(scene, local_views, init_vertices, parameter, opt, w_ray, fused=args.mode == "fused")
 
     if args.graph < 0:
-        # (not over gloo -- the functional two-ranks-on-one-GPU check: its all-reduce goes through the host and cannot be captured)
-        args.graph = 1 if world > 1 and os.environ.get("DRT_BENCH_GRAPH", "1") != "0" and os.environ.get("DRT_DIST_BACKEND") != "gloo" else 0
+        # Measured per share on one GPU (profiles/r03_scaling_proxy.txt): a replay beats the eager step only where the step is a chain of small
+        # launches -- 9 views: 0.69 vs 0.72 ms; 18: 0.93 vs 0.92; 36: 1.64 vs 1.45 (a replayed graph overlaps the internal streams worse
+        # than eager launches do, and the ahead-of-time fills are not part of a capture).  So: shares below 2^24 camera rays only.
+        # (Not over gloo -- the functional two-ranks-on-one-GPU check: its all-reduce goes through the host and cannot be captured.)
+        small = len(my_views) * P < (1 << 24)
+        args.graph = 1 if world > 1 and small and os.environ.get("DRT_BENCH_GRAPH", "1") != "0" and os.environ.get("DRT_DIST_BACKEND") != "gloo" else 0
     graph = None
     if args.graph:
         # The step has no host-side data dependence (every list size lives on the device), so it can be
@@ -558,7 +562,7 @@ def main():
 
         def tight_step():
             return O.full_batch_step(scene, tight_views, init_vertices, parameter, opt, w_ray, fused=False)
-        for _ in range(3):
+        for _ in range(6):            # (establish + read back the verdict of the new ray tensors, grow the lists to this hit fraction, settle the allocator)
             lt = tight_step()
         scene.optix_mesh.profile_enable(1); scene.optix_mesh.profile_read()
         tight_step()

@@ -1310,10 +1310,12 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     // the scene's build stream is idle once the tree is built (before the cull stage): it carries the late fills, so that the
     // library stays within the four hardware queues a process gets by default (more streams would share queues with these)
     hipStream_t fs = s->prof_serial ? st : s->build_stream;
-    {   // under stream capture (a whole step recorded as a hipGraph) the fills stay on the sub-batch's own stream: re-entering the build
-        // stream after it has joined faults inside the capture of ROCm 7.2, and a replayed graph has no launch gaps to hide anyway
+    {   // under stream capture (a whole step recorded as a hipGraph) the fills go to the CALLER's stream -- the origin of the capture, idle
+        // between the fork and the join of this call -- instead of the build stream: re-entering the build stream after it has joined
+        // faults inside the capture of ROCm 7.2.  (They were issued on the sub-batch's own stream at first, in line with its kernels: a
+        // 36-view share then replayed 13 % SLOWER than it ran eagerly, 1.61 vs 1.42 ms.)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (fs != st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) fs = st;
+        if (fs != st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) fs = aux ? aux : st;
     }
     const int64_t image = (int64_t)tile_w * tile_h;
     if (raster_on(s, n, tile_w, tile_h)) {
@@ -1372,14 +1374,19 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
       } else {
           k_cull<FUSED><<<n_patches, kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
       } }
-    if (late_fill && !mega) {      // (StageTimer scopes must not nest: this one follows the cull stage's)
+    // the late fills: issued behind the cull stage (beside k_shade1 and the second traversal) or, DRT_FILL_AFTER_SHADE1, behind k_shade1
+    // (beside the second traversal only: the latency-bound first shading then does not share the memory system with 2 GB of memsets)
+    auto issue_late_fills = [&]() -> int {
         if (fs != st) { HIP_TRY(hipEventRecord(w.fill_fork, st)); HIP_TRY(hipStreamWaitEvent(fs, w.fill_fork, 0)); }
         { StageTimer tf(s, fs, kStageFill);
           if (!pre_ori) (void)hipMemsetAsync(out_ori, 0, sizeof(double) * 3 * n, fs);
           if (!pre_dir) (void)hipMemsetAsync(out_dir, 0, sizeof(double) * 3 * n, fs);
           if (!pre_mask) (void)hipMemsetAsync(mask, 0, 3 * n, fs); }
         if (fs != st) HIP_TRY(hipEventRecord(w.fill_join, fs));
-    }
+        return DRT_OK;
+    };
+    const bool fills_after_shade1 = s->fill_after_shade1 && fs != st;
+    if (late_fill && !mega && !fills_after_shade1) { int rc = issue_late_fills(); if (rc) return rc; }      // (StageTimer scopes must not nest: this one follows the cull stage's)
     if (rz.views && grid_mode == DRT_GRID_ESTABLISH)      // what later DRT_GRID_TRUST calls with the same rays may rely on
         k_store_models<<<(int)(n / ((int64_t)tile_w * tile_h) + 63) / 64, 64, 0, st>>>(w.vmodel, grid_cache, (int)(n / ((int64_t)tile_w * tile_h)));
     { StageTimer t(s, st, kStageTrace1);
@@ -1400,6 +1407,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     }
     { StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill, r64); }
+    if (late_fill && !mega && fills_after_shade1) { int rc = issue_late_fills(); if (rc) return rc; }
     if (tree_late) {
         int rc = wait_build(s, st); if (rc) return rc;
         StageTimer t(s, st, kStageTrace1);
