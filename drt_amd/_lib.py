@@ -51,6 +51,8 @@ SIGNATURES = {
     "drt_edge_tables": (_c.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "drt_subdivide_midpoint": (_c.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _c.c_int, _P, _P, _P]),
     "drt_limit_sgd_step": (_c.c_int, [_P, _P, _P, _I64, _D, _D, _c.c_int, _c.c_int, _D, _P]),
+    "drt_limit_sgd_step3": (_c.c_int, [_P, _P, _P, _I64, _D, _D, _c.c_int, _c.c_int, _D, _P, _P, _P, _P, _P]),
+    "drt_internal_stream": (_c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
     "drt_closest_point": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "drt_vh_loss_fused": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "drt_remesh_isotropic": (_c.c_int, [_P, _I64, _P, _I64, _D, _c.c_int, _D, _c.c_uint, _c.POINTER(_P)]),

@@ -178,6 +178,13 @@ int drt_profile_read(drt_scene_t* s, double* ms_out, int64_t* launches_out, int6
     return DRT_OK;
 }
 
+int drt_internal_stream(drt_scene_t* s, int which, void** out) {
+    if (!s || !out) return fail(DRT_E_INVALID, "null pointer argument");
+    if (which == 0) { *out = (void*)s->build_stream; return DRT_OK; }
+    if (which >= 1 && which <= s->n_sub) { *out = (void*)s->sub[which - 1].stream; return DRT_OK; }
+    return fail(DRT_E_INVALID, "no internal stream %d (0 = build, 1..%d = pipelines)", which, s->n_sub);
+}
+
 int drt_check_violations(int64_t* out4) {
     if (!out4) return fail(DRT_E_INVALID, "null pointer argument");
 #if defined(DRT_CHECK)

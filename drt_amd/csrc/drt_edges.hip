@@ -207,13 +207,21 @@ __global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const doub
 // sanitised in place (NaN -> 0, clamp to +-max_abs: what the reference's hook does to parameter.grad), the momentum buffer and
 // the parameter follow torch.optim.SGD (dampening 0, no weight decay): buf = g on the first step, momentum * buf + g after;
 // step = g + momentum * buf with nesterov, buf without; param -= lr * step.  Replaces ~8 elementwise launches per iteration.
+// `terms` / `w` / `loss_*` (optional): grad[i] is first formed as w[0] * terms[i] + w[1] * terms[n + i] + w[2] * terms[2 n + i] -- the weighted
+// sum of the three loss terms' vertex gradients of reference optim.py:127-129, in that order of operations -- and thread 0 leaves the weighted
+// total of the three losses in *loss_total: the all_loss arithmetic of an iteration without its five scalar kernels.
 __global__ void __launch_bounds__(256) k_limit_sgd(double* __restrict__ param, double* __restrict__ grad, double* __restrict__ buf, int64_t n,
-                                                   double lr, double momentum, int nesterov, int first, double max_abs) {
+                                                   double lr, double momentum, int nesterov, int first, double max_abs,
+                                                   const double* __restrict__ terms, const double* __restrict__ w, const double* __restrict__ loss_parts,
+                                                   double* __restrict__ loss_total) {
+    if (loss_total && blockIdx.x == 0 && threadIdx.x == 0) *loss_total = (w[0] * loss_parts[0] + w[1] * loss_parts[1]) + w[2] * loss_parts[2];
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        double g = grad[i];
+        double g = terms ? (w[0] * terms[i] + w[1] * terms[n + i]) + w[2] * terms[2 * n + i] : grad[i];
         if (max_abs > 0.0) {
             g = g != g ? 0.0 : g;
             g = g > max_abs ? max_abs : (g < -max_abs ? -max_abs : g);
+            grad[i] = g;
+        } else if (terms) {
             grad[i] = g;
         }
         double step = g;
@@ -298,7 +306,6 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
     if (n_edges == 0 || n_views == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_e2f || !d_cameras || !d_origins || !d_soft_masks || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    { int rc = wait_build(s, st); if (rc) return rc; }
     { int rc = ensure_slow_stack(s); if (rc) return rc; }
     const int64_t need = n_edges * std::min(kVhViews, n_views);
     if (need > s->vh_cap) {
@@ -315,6 +322,9 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
         }
         HIP_TRY(hipMemsetAsync(s->vcount + 1, 0, sizeof(unsigned), st));
         k_vh_cull<<<grid_for(n_edges * nv, kPathBlock, 4 * s->n_cu), kPathBlock, 0, st>>>(d_verts, d_e2f, n_edges, nv, vw, s->vh_list, s->vcount + 1);
+        // (the silhouette flags need the vertices only; the probe rays are the first thing that needs the tree: the flags of eight views
+        // are found while the asynchronous build finishes)
+        { int rc = wait_build(s, st); if (rc) return rc; }
         k_vh_fused<<<4 * s->n_cu, kTraceBlock, 0, st>>>(trace_ctx(s), d_verts, d_edges, (uint32_t)n_edges, s->vh_list, s->vcount + 1,
                                                         vw, resx, resy, detach_depth, d_loss, d_grad_verts);
     }
@@ -328,7 +338,18 @@ int drt_limit_sgd_step(double* d_param, double* d_grad, double* d_buf, int64_t n
     if (n < 0) return fail(DRT_E_INVALID, "negative size");
     if (n == 0) return DRT_OK;
     if (!d_param || !d_grad || (momentum != 0.0 && !d_buf)) return fail(DRT_E_INVALID, "null pointer argument");
-    k_limit_sgd<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_buf, n, lr, momentum, nesterov, first, max_abs);
+    k_limit_sgd<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_buf, n, lr, momentum, nesterov, first, max_abs, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_limit_sgd_step3(double* d_param, double* d_grad, double* d_buf, int64_t n, double lr, double momentum, int nesterov, int first,
+                        double max_abs, const double* d_terms, const double* d_w3, const double* d_loss_parts, double* d_loss_total, void* stream) {
+    if (n < 0) return fail(DRT_E_INVALID, "negative size");
+    if (n == 0) return DRT_OK;
+    if (!d_param || !d_grad || (momentum != 0.0 && !d_buf) || !d_terms || !d_w3 || ((d_loss_parts == nullptr) != (d_loss_total == nullptr)))
+        return fail(DRT_E_INVALID, "null pointer argument");
+    k_limit_sgd<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_buf, n, lr, momentum, nesterov, first, max_abs, d_terms, d_w3, d_loss_parts, d_loss_total);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

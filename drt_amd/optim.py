@@ -201,11 +201,22 @@ class FusedIteration:
         self.parameter = torch.zeros_like(self.init_vertices)
         self.grads = torch.zeros((3,) + tuple(self.init_vertices.shape), dtype=Float, device=dev)
         self.losses = torch.zeros(3, dtype=Float, device=dev)
+        self.total = torch.zeros((), dtype=Float, device=dev)
         self.total_grad = torch.empty_like(self.init_vertices)
         self.buf = torch.empty_like(self.init_vertices) if HyperParams["momentum"] != 0 else None
         self.first = True
         self.lr, self.momentum = float(lr), float(HyperParams["momentum"])
-        self.side = torch.cuda.Stream(device=dev) if concurrent else None
+        # The side stream of the silhouette / smoothness terms must not share a hardware queue with the caller's stream: a process gets four
+        # queues, further streams are multiplexed onto them, and a stream that lands in the caller's queue sits BEHIND the barrier with
+        # which the caller's stream waits for the refraction term -- the terms then run one after the other whatever the streams say
+        # (rocprofv3: the fresh torch stream shared queue 1 with stream 0).  The library's second pipeline stream is idle during a call of
+        # this size and has a queue of its own.
+        self.side = None
+        if concurrent:
+            import ctypes
+            h = ctypes.c_void_p()
+            rc = _lib.lib().drt_internal_stream(scene.optix_mesh._h, 2, ctypes.byref(h))
+            self.side = torch.cuda.ExternalStream(h.value, device=dev) if rc == 0 and h.value else torch.cuda.Stream(device=dev)
         self._w = None
 
     def step(self):
@@ -236,6 +247,9 @@ class FusedIteration:
                                                     *R._tile_hint(n), grid[0], ptr(grid[1]), _stream()))
             ctx = torch.cuda.stream(self.side) if self.side is not None else torch.no_grad()
             with ctx:
+                if hp["sm_w"] != 0:        # (first: it needs no tree, so it runs while the build finishes; the silhouette probes wait for the tree)
+                    check(lib.drt_sm_loss_fused(vertices.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], self.losses[2:].data_ptr(),
+                                                self.grads[2].data_ptr(), _stream()))
                 if hp["vh_w"] != 0:
                     import ctypes
                     k = self.N_SILHOUETTE_VIEWS
@@ -248,19 +262,17 @@ class FusedIteration:
                         cams[j], orgs[j], softs[j] = cam.data_ptr(), o3.data_ptr(), sm_.data_ptr()
                     check(lib.drt_vh_loss_fused(h, vertices.data_ptr(), scene.Edges.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], k,
                                                 cams, orgs, softs, int(data.resx), int(data.resy), 1, self.losses[1:].data_ptr(), self.grads[1].data_ptr(), _stream()))
-                if hp["sm_w"] != 0:
-                    check(lib.drt_sm_loss_fused(vertices.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], self.losses[2:].data_ptr(),
-                                                self.grads[2].data_ptr(), _stream()))
             if self.side is not None:
                 main.wait_stream(self.side)
             w = loss_weights(hp, data.resy, scene.mean_len)
             if self._w is None or self._w[0] != w:
                 self._w = (w, torch.tensor(w, dtype=Float, device=dev))
             wv = self._w[1]
-            torch.matmul(wv.view(1, 3), self.grads.view(3, -1), out=self.total_grad.view(1, -1))        # d total / d vertices = d total / d parameter
-            total = torch.dot(wv, self.losses)
-            check(lib.drt_limit_sgd_step(self.parameter.data_ptr(), self.total_grad.data_ptr(), ptr(self.buf), self.parameter.numel(), self.lr,
-                                         self.momentum, 1, int(self.first), 1.0, _stream()))
+            # d total / d vertices (= d total / d parameter) = the weighted sum of the three terms' gradients, limit_hook, SGD(nesterov): one kernel
+            check(lib.drt_limit_sgd_step3(self.parameter.data_ptr(), self.total_grad.data_ptr(), ptr(self.buf), self.parameter.numel(), self.lr,
+                                          self.momentum, 1, int(self.first), 1.0, self.grads.data_ptr(), wv.data_ptr(), self.losses.data_ptr(),
+                                          self.total.data_ptr(), _stream()))
+            total = self.total
             self.first = False
             self._vertices = vertices          # (alive until the next step: kernels enqueued above read it)
         return total, self.losses

@@ -313,6 +313,16 @@ void drt_mesh_buf_free(drt_mesh_buf_t* b);
  * elements of the parameter. */
 int drt_limit_sgd_step(double* d_param, double* d_grad, double* d_buf, int64_t n, double lr, double momentum,
                        int nesterov, int first, double max_abs, void* stream);
+/* The same with the weighted sum of the three loss terms in front (all_loss, optim.py:127-129): d_terms float64 [3, n] = d ray / d vertices,
+ * d vh / d vertices, d sm / d vertices; d_w3 float64 [3] (device) the weights; grad[i] = (w0 t0[i] + w1 t1[i]) + w2 t2[i] before the limit;
+ * optional (both or neither) d_loss_parts float64 [3] -> *d_loss_total = (w0 l0 + w1 l1) + w2 l2. */
+int drt_limit_sgd_step3(double* d_param, double* d_grad, double* d_buf, int64_t n, double lr, double momentum, int nesterov, int first,
+                        double max_abs, const double* d_terms, const double* d_w3, const double* d_loss_parts, double* d_loss_total, void* stream);
+/* The library's own HIP streams (which = 0: the build stream, idle once the tree is built; 1 .. DRT_STREAMS: the pipeline streams, of which
+ * a call below 2^25 rays uses only the first).  A process gets four hardware queues and further streams are multiplexed onto them: a
+ * caller that wants side work to run BESIDE a render call -- not behind the barrier with which the caller's own stream waits for it in
+ * the same hardware queue -- enqueues it on one of these (optim.FusedIteration: the silhouette and smoothness terms on pipeline stream 2). */
+int drt_internal_stream(drt_scene_t* s, int which, void** out);
 
 /* ---- topology: Scene.init_edge (DiffRender.py:338-355; trimesh group_rows / edges_face on the host in the reference) and
  * the 1 -> 4 midpoint refinement of a level-of-detail step, on the device ---------------------------------------
