@@ -574,6 +574,8 @@ class SilhouetteEdges:
         return self._t
 
     def __getattr__(self, name):                     # (only reached for names this object does not define itself)
+        if name.startswith("_"):                     # (its own fields, before __init__ has run -- copy / pickle probe for them: no recursion)
+            raise AttributeError(name)
         return getattr(self.tensor(), name)
 
     def __getitem__(self, k):

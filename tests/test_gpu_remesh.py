@@ -132,3 +132,36 @@ def test_device_remesh_on_a_sphere_and_inside_the_loop():
     assert bad == 0
     m = scene.mesh
     assert m.is_watertight and len(m.faces) == scene.faces.shape[0]
+
+
+def _torus(R=40.0, r=12.0, nu=96, nv=40):
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+    v = np.linspace(0, 2 * np.pi, nv, endpoint=False)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    V = np.stack([(R + r * np.cos(vv)) * np.cos(uu), (R + r * np.cos(vv)) * np.sin(uu), r * np.sin(vv)], -1).reshape(-1, 3)
+    idx = lambda i, j: (i % nu) * nv + (j % nv)
+    F = []
+    for i in range(nu):
+        for j in range(nv):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            F += [[a, b, c], [a, c, d]]
+    return mesh_io.TriMesh(V.astype(np.float32).astype(np.float64), np.array(F, dtype=np.int64))
+
+
+@pytest.mark.parametrize("L", [5.0, 2.0])
+def test_device_remesh_keeps_the_genus_of_a_torus(L):
+    """A handle must survive: the link condition of the collapses and the existing-edge test of the flips are what keeps a genus-1 surface
+    a genus-1 manifold (V - E + F = 0); coarsening (L = 5, from 2.6 / 1.9 mm edges) and refining (L = 2 splits the long diagonals) alike."""
+    t = _torus()
+    assert t.is_watertight and len(t.vertices) - len(t.faces) // 2 == 0
+    dev, st = _gpu_remesh(t, L)
+    host = remesh.isotropic_remesh(t, L)
+    assert dev.is_watertight and _oriented_closed(dev)
+    assert len(dev.vertices) - len(dev.faces) // 2 == 0 and len(host.vertices) - len(host.faces) // 2 == 0
+    el = _edge_len(dev)
+    assert ((el > 0.8 * L) & (el < 4.0 / 3.0 * L)).mean() > 0.9
+    assert abs(len(dev.faces) / len(host.faces) - 1) < 0.05
+    rho = np.hypot(np.hypot(dev.vertices[:, 0], dev.vertices[:, 1]) - 40.0, dev.vertices[:, 2])
+    assert abs(rho.mean() - 12.0) < 0.15 and rho.min() > 11.0 and rho.max() < 12.2       # still the tube of radius 12 (vertices on the input polyhedron)
+    assert abs(_volume(dev) / _volume(t) - 1) < 0.03
+
