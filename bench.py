@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--views", type=int, default=72)
     ap.add_argument("--mesh", default="horse")
+    ap.add_argument("--distance-factor", type=float, default=2.5,
+                    help="camera distance in mesh extents (views.turntable_cameras; 2.5 = SURVEY 8d's framing, the headline; 1.1 = the object fills the image: for stage tables of that case)")
     ap.add_argument("--subdiv", type=int, default=None, help="midpoint subdivisions of the input hull (default: 1 for horse/mouse)")
     ap.add_argument("--batch-views", type=int, default=0,
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
@@ -363,7 +365,7 @@ def main():
         gt, target_src = views.displaced_ground_truth(mesh, sigma=0.3, seed=0), "hull displaced along vertex normals, sigma 0.3"
     gt_scene = Render.Scene(gt, local_rank)
     my_views = ddist.shard_views(args.views, rank, world)
-    cams = views.turntable_cameras(center, extent, args.views, res, res)
+    cams = views.turntable_cameras(center, extent, args.views, res, res, distance_factor=args.distance_factor)
     data = []
     with torch.no_grad():
         for k in my_views:
@@ -481,7 +483,8 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32 traversal + f64 shading/gradients", "data": "synthetic",
         "config": {"workload": f"{mesh_src} = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
-                               f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD",
+                               f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD"
+                               + ("" if args.distance_factor == 2.5 else f", cameras at {args.distance_factor} extents"),
                    "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
                    "final_loss": float(loss.item())},
     }

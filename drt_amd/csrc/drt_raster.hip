@@ -129,9 +129,16 @@ __global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris,
                 const int ny = box.y1 - box.y0 + 1;
                 const int64_t cnt = (int64_t)me.nx * ny;
                 if (cnt > kRasterMaxPerLane) {
-                    const unsigned slot = atomicAdd(big_count, 1u);
-                    if (slot < big_cap) big[slot] = BigItem{view, k, me.x0, me.y0, me.nx, ny};
-                    else __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // list full: BVH path for this image
+                    // listed for k_raster_big, one WAVE per entry: in bands of whole rows of at most kRasterBandPixels pixel centres
+                    const int rows_per = max(1, kRasterBandPixels / me.nx), n_bands = (ny + rows_per - 1) / rows_per;
+                    const unsigned slot = atomicAdd(big_count, (unsigned)n_bands);
+                    if (slot <= big_cap && (unsigned)n_bands <= big_cap - slot) {
+                        for (int b = 0; b < n_bands; ++b)
+                            big[slot + b] = BigItem{view, k, me.x0, me.y0 + b * rows_per, me.nx, min(rows_per, ny - b * rows_per)};
+                    } else {
+                        __hip_atomic_store(&views[view].ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // list full: BVH path for this image
+                        for (unsigned q = slot; q < big_cap; ++q) big[q] = BigItem{view, k, 0, 0, 0, 0};      // (what was reserved below the cap: empty entries)
+                    }
                 } else {
                     count = (int)cnt;
                 }
@@ -166,21 +173,28 @@ __global__ void __launch_bounds__(256) k_raster(const TriRec* __restrict__ tris,
     }
 }
 
-// Triangles whose box holds more pixels than one lane should loop over: one block per list entry.
+// Triangles whose box holds more pixels than one lane should loop over: one WAVE per list entry (a band of rows of the box).  With the object
+// filling the image a third of the camera-facing triangles are such entries, 50-300 pixel centres each: one BLOCK per entry on 2 blocks per
+// CU -- the first form, written for the odd large triangle -- kept 512 entries in flight and took 0.4-0.7 ms per launch, twice the main
+// kernel; a wave per entry on a full grid keeps 8192.
 __global__ void __launch_bounds__(256) k_raster_big(const TriRec* __restrict__ tris, const ViewModel* __restrict__ views,
                                                     const double* __restrict__ dir, int w, int h,
                                                     unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask,
                                                     const BigItem* __restrict__ big, const unsigned* __restrict__ big_count, unsigned big_cap) {
-    const unsigned n = min(*big_count, big_cap);
-    for (unsigned e = blockIdx.x; e < n; e += gridDim.x) {
+    const unsigned n = min(*big_count, big_cap);          // (an overfull list was cut at an entry boundary: k_raster wrote whole triangles only)
+    const unsigned n_waves = gridDim.x * 4u;
+    const int lane = threadIdx.x & 63;
+    for (unsigned e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); e < n; e += n_waves) {
         const BigItem it = big[e];
         const ViewModel& vm = views[it.view];
         const TriRec t = tris[it.tri];
         const f3 o32 = to_f32(d3{vm.o[0], vm.o[1], vm.o[2]});
         const int64_t base = (int64_t)it.view * w * h;
-        const int64_t cnt = (int64_t)it.nx * it.ny;
-        for (int64_t p = threadIdx.x; p < cnt; p += 256) {
-            const int y = it.y0 + (int)(p / it.nx), x = it.x0 + (int)(p % it.nx);
+        const int cnt = it.nx * it.ny;
+        for (int p = lane; p < cnt; p += 64) {
+            const int row = (int)(((float)p + 0.5f) / (float)it.nx);        // exact for p < 2^22
+            int y = it.y0 + row, x = it.x0 + (p - row * it.nx);
+            if (x >= it.x0 + it.nx) { x -= it.nx; ++y; } else if (x < it.x0) { x += it.nx; --y; }     // (belt and braces for bands of one very long row)
             raster_test(t, o32, dir, base + (int64_t)y * w + x, raster_slot((unsigned)x, (unsigned)(it.view * h + y), (unsigned)w), zbuf, zmask);
         }
     }
@@ -227,12 +241,12 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
             k_raster<<<dim3((n + 255) / 256, n_views), 256, 0, st>>>(s->tris_flat, n, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                                       reinterpret_cast<BigItem*>(w.big), w.big_count, drt_scene::kBigCap, pass);
             if (pass == 0) {   // the large triangles of the first launch before the second one reads the keys
-                k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris_flat, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+                k_raster_big<<<8 * s->n_cu, 256, 0, st>>>(s->tris_flat, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                            reinterpret_cast<const BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
                 HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
             }
         }
-        k_raster_big<<<2 * s->n_cu, 256, 0, st>>>(s->tris_flat, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
+        k_raster_big<<<8 * s->n_cu, 256, 0, st>>>(s->tris_flat, w.vmodel, d_dir, iw, ih, w.zbuf, w.zmask,
                                                    reinterpret_cast<const BigItem*>(w.big), w.big_count, drt_scene::kBigCap);
     }
     HIP_TRY(hipGetLastError());

@@ -129,6 +129,14 @@ def test_camera_inside_the_object_and_huge_triangles(Render):
     o, d = views.generate_ray(256, 256, cam[3], cam[2], device="cuda")
     prof, f1 = _check(Render, scene, o, d, 256, 256)
     assert prof["trace1"][2] == 0 and (f1 >= 0).float().mean().item() > 0.3
+    # the hand filling a 768^2 image: a third of its triangles cover 50-300 pixel centres (one wave per triangle), three views in one call
+    hand = mesh_io.read_ply(data_path("hand_vh.ply"))
+    hscene = Render.Scene(hand, 0)
+    c, ext = views.mesh_frame(hand.vertices)
+    cams = views.turntable_cameras(c, ext, 72, 768, 768, distance_factor=1.1)
+    rays = [views.generate_ray(768, 768, cams[k][3], cams[k][2], device="cuda") for k in (2, 31, 55)]
+    prof, f1 = _check(Render, hscene, torch.cat([r[0] for r in rays]), torch.cat([r[1] for r in rays]), 768, 768)
+    assert prof["trace1"][2] == 0 and (f1 >= 0).float().mean().item() > 0.15
     # a mesh of two triangles, one of them degenerate, and an empty mesh
     flat = mesh_io.TriMesh(np.array([[-30.0, -30, 0], [30, -30, 0], [0, 40, 0]]), np.array([[0, 1, 2], [0, 0, 0]]))
     from drt_amd.optix_mesh import optix_mesh
