@@ -92,7 +92,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_edge_sample_fwd(TraceCtx c, con
         edge_sample(cm, pa, pb, o, s);
         const int mine = live && traverse<true>(c.nodes, c.tris, c.n_tris, to_f32(o), to_f32(side == 0 ? s.dir_up : s.dir_lo), st).face >= 0 ? 1 : 0;
         const int other = __shfl_xor(mine, 1);
-        if (!live || side != 0) continue;
+        if (side != 0 || e >= n) continue;
+        if (!live) {                                  // an unflagged edge of the all-edges form: a dropped row (the caller need not zero anything)
+            f_out[e] = 0.0f;
+            if (keep) keep[e] = 0;
+            continue;
+        }
         f_out[e] = (float)mine - (float)other;        // hit(up) - hit(lo)
         const int64_t x = (int64_t)s.midx, y = (int64_t)s.midy;       // truncation toward zero, like Tensor.to(torch.long)
         index[2 * e] = x;
@@ -283,6 +288,38 @@ int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t
     { int rc = ensure_slow_stack(s); if (rc) return rc; }
     k_edge_sample_fwd<<<grid_for(2 * n_edges, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(
         trace_ctx(s), d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_origin3, d_index, d_f, d_keep, resx, resy, d_flags);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+// The same for the KEPT rows only: rows[k] = edge row of the k-th kept sample, g[k] = d loss / d output of that sample in the float32 of
+// `output` -- what the caller has after its one boolean index; spares it a zero-filled float64 [Es] coefficient vector, a cast and a scatter.
+__global__ void __launch_bounds__(256) k_edge_sample_bwd_rows(const double* __restrict__ verts, const int64_t* __restrict__ edges, const Camera* __restrict__ cam,
+                                                              const float* __restrict__ f, const int64_t* __restrict__ rows, int64_t n_rows,
+                                                              const float* __restrict__ g, int detach_depth, double* grad_verts) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n_rows) return;
+    const int64_t e = rows[k];
+    const double w = (double)f[e] * (double)g[k];
+    if (w == 0.0) return;
+    const Camera cm = *cam;
+    const int64_t ia = edges[2 * e], ib = edges[2 * e + 1];
+    Projected pa, pb;
+    project_endpoint(cm, load_d3(verts, ia), pa);
+    project_endpoint(cm, load_d3(verts, ib), pb);
+    const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
+    const AtomicAdd3 add{grad_verts};
+    add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
+    add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
+}
+
+int drt_edge_sample_backward_rows(const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera, const float* d_f,
+                                  const int64_t* d_rows, int64_t n_rows, const float* d_g, int detach_depth, double* d_grad_verts, void* stream) {
+    if (n_edges < 0 || n_rows < 0) return fail(DRT_E_INVALID, "negative count");
+    if (n_edges == 0 || n_rows == 0) return DRT_OK;
+    if (!d_verts || !d_edges || !d_camera || !d_f || !d_rows || !d_g || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    k_edge_sample_bwd_rows<<<(unsigned)((n_rows + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        d_verts, d_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_rows, n_rows, d_g, detach_depth, d_grad_verts);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

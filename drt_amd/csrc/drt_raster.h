@@ -40,7 +40,10 @@ static_assert(sizeof(ViewModel) == 104, "DRT_GRID_CACHE_BYTES of include/drt_hip
 
 constexpr double kRasterPad = 0.0625;         // pixels added on every side of a projected triangle's bounding box
 constexpr double kRasterVerifyTol = 1e-3;    // a ray belongs to the grid if its direction projects within this of its pixel
-constexpr int kRasterMaxPerLane = 48;        // larger boxes are handed to k_raster_big (one wave per band of rows of the box)
+#ifndef DRT_RASTER_MAX_PER_LANE
+#define DRT_RASTER_MAX_PER_LANE 48
+#endif
+constexpr int kRasterMaxPerLane = DRT_RASTER_MAX_PER_LANE;        // larger boxes are handed to k_raster_big (one wave per band of rows of the box)
 constexpr int kRasterBandPixels = 1024;      // pixel centres per band (a band is at least one row)
 
 // Solve the model from the rays of the four image corners (unit or not, only their directions matter):

@@ -84,16 +84,18 @@ class Loss_calculator:
         exit_o, exit_d, exit_mask = self.scene.render_transparent(origin, ray_dir)
         return Render.ray_loss(exit_o, exit_d, exit_mask, target, valid)
 
-    # The three terms of an iteration are independent given the mesh.  With the one-pass kernels (fused=True: no host synchronisation inside a
-    # term) the silhouette and smoothness terms are enqueued on a SIDE stream and run beside the refraction term -- at the reference's
-    # iteration size (one 960x1280 view, ~50 k primary hits) each term is a chain of small launches that leaves most of the chip idle, so
-    # the iteration costs the longest chain instead of their sum.  Values are unchanged (same kernels, same inputs).
+    # The three terms of an iteration are independent given the mesh.  The silhouette and smoothness terms are enqueued on a SIDE stream and
+    # run beside the refraction term -- at the reference's iteration size (one 960x1280 view, ~50 k primary hits) each term is a chain of
+    # small launches that leaves most of the chip idle, so the iteration costs the longest chain instead of their sum.  With the drop-in
+    # methods (fused=False) the silhouette term synchronises with the host once per view (its outputs are dynamically sized): on its own
+    # stream that wait covers its own launches only, not the refraction term enqueued before it.  Values are unchanged (same kernels, same
+    # inputs).
     CONCURRENT_TERMS = True
 
     def all_loss(self):
         hp = self.HyperParams
         none = torch.zeros((), dtype=Float, device=self.scene.vertices.device)
-        if self.fused and self.CONCURRENT_TERMS and self.scene.vertices.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if self.CONCURRENT_TERMS and self.scene.vertices.is_cuda and not torch.cuda.is_current_stream_capturing():
             main = torch.cuda.current_stream()
             side = getattr(self, "_side_stream", None)
             if side is None:

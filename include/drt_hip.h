@@ -210,12 +210,14 @@ int drt_sm_loss_fused(const double* d_verts, const int64_t* d_e2f, int64_t n_edg
  * |f| > 1e-5 (DiffRender.py:244) and in-view indices (:478): d_keep (uint8 [Es], may be NULL) = exactly that test for a
  * resx x resy image, so that the caller needs one boolean index instead of ten elementwise launches.
  * d_flags (uint8 [Es], may be NULL): d_edges is then the list of ALL unique edges and only the flagged ones (drt_silhouette_flags)
- * are silhouette edges -- the others are skipped (their rows of index / f / keep are left untouched: zero them first) -- which
+ * are silhouette edges -- the others are skipped (f = 0, keep = 0 are written for them, their index rows are left untouched) -- which
  * spares the caller the device->host round trip of compacting Edges[flags] between the two calls.
  * drt_edge_sample_backward <- primary_edge_sample.backward (DiffRender.py:263-267) chained through the
  * projection (depth row detached when detach_depth != 0, DiffRender.py:470-471):
  * grad_verts [V,3] += sum_e coef[e] * f[e] * d(-N_e . E_pos)/dV, coef float64 [Es] = incoming
- * d loss / d output per edge (0 for dropped edges). */
+ * d loss / d output per edge (0 for dropped edges).
+ * drt_edge_sample_backward_rows: the same sum over the kept rows only -- d_rows int64 [n_rows] = edge row of the k-th kept sample
+ * (the caller's boolean index), d_g float32 [n_rows] = d loss / d output of that sample, as autograd hands it over. */
 int drt_silhouette_flags(const double* d_verts, const int64_t* d_e2f, int64_t n_edges,
                          const double* d_origin3, uint8_t* d_flags, void* stream);
 int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t* d_edges, int64_t n_edges,
@@ -224,6 +226,9 @@ int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t
 int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int64_t n_edges,
                              const double* d_camera, const float* d_f, const double* d_coef,
                              int detach_depth, double* d_grad_verts, void* stream);
+int drt_edge_sample_backward_rows(const double* d_verts, const int64_t* d_edges, int64_t n_edges,
+                                  const double* d_camera, const float* d_f, const int64_t* d_rows, int64_t n_rows,
+                                  const float* d_g, int detach_depth, double* d_grad_verts, void* stream);
 
 /* drt_vh_loss_fused <- Loss_calculator.vh_loss (optim.py:73-78) for n_views views: silhouette_edge +
  * primary_visibility + sum |soft_mask[y, x] - output| and its vertex gradient, entirely on the device

@@ -294,6 +294,23 @@ def test_silhouette_branch_vs_golden(Render, hand, name):
     ref = g["grad_vh"]
     assert np.abs(g_vh.cpu().numpy() - ref).max() <= 1e-5
     np.testing.assert_allclose(g_vh.cpu().numpy(), ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+    # the dense-coefficient entry point of the C ABI (coef float64 [Es], 0 for dropped edges) gives the same gradient as the row-list one autograd used
+    from drt_amd import _lib
+    edges_all, flags = scene.Edges.contiguous(), scene.silhouette_edge(origin3)._flags
+    n_e = edges_all.shape[0]
+    idx2 = torch.empty((n_e, 2), dtype=torch.long, device="cuda"); f_all = torch.full((n_e,), 7.0, dtype=torch.float32, device="cuda")
+    keep = torch.full((n_e,), 9, dtype=torch.uint8, device="cuda")
+    camp = Render.pack_camera(cam); Vd = V.detach().contiguous(); st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, Vd.data_ptr(), edges_all.data_ptr(), n_e, camp.data_ptr(), origin3.data_ptr(),
+                                                  idx2.data_ptr(), f_all.data_ptr(), keep.data_ptr(), res, res, flags.data_ptr(), st))
+    assert int(keep.max()) <= 1 and float(f_all.abs().max()) <= 1.0              # every row written, dropped ones as zeros
+    rows = torch.nonzero(keep).squeeze(1)
+    assert torch.equal(idx2[rows], index)
+    g_out = -torch.sign(soft.view((res, res))[index[:, 1], index[:, 0]] - output.detach().double())
+    coef = torch.zeros(n_e, dtype=torch.float64, device="cuda"); coef[rows] = g_out
+    gd = torch.zeros_like(Vd)
+    _lib.check(_lib.lib().drt_edge_sample_backward(Vd.data_ptr(), edges_all.data_ptr(), n_e, camp.data_ptr(), f_all.data_ptr(), coef.data_ptr(), 1, gd.data_ptr(), st))
+    np.testing.assert_allclose(gd.cpu().numpy(), ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
     # fused one-kernel form of the same loss and gradient (no host sync)
     V3 = V.detach().clone().requires_grad_(True)
     scene.update_verticex(V3)
