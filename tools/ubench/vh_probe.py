@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from drt_amd import diffrender as Render, mesh_io, optim as O, views
 resx, resy, n_views = 1280, 960, 16
 base = mesh_io.subdivide_midpoint(mesh_io.read_ply("data/horse_vh.ply"))
