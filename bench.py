@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--views", type=int, default=72)
     ap.add_argument("--mesh", default="horse")
+    ap.add_argument("--no-grid-cache", action="store_true",
+                    help="diffrender.GRID_CACHE = False for the whole run (every call fits and verifies every image again: the `establish_mode` extra as the main line, for its stage table)")
     ap.add_argument("--distance-factor", type=float, default=2.5,
                     help="camera distance in mesh extents (views.turntable_cameras; 2.5 = SURVEY 8d's framing, the headline; 1.1 = the object fills the image: for stage tables of that case)")
     ap.add_argument("--subdiv", type=int, default=None, help="midpoint subdivisions of the input hull (default: 1 for horse/mouse)")
@@ -353,6 +355,8 @@ def main():
     P = res * res
     Render.intIOR = IOR
     Render.resx = Render.resy = res
+    if args.no_grid_cache:
+        Render.GRID_CACHE = False
 
     # ---- synthetic capture (untimed): targets from a displaced ground-truth mesh through the same path
     scene = Render.Scene(mesh, local_rank)
@@ -484,7 +488,8 @@ def main():
         "vs_baseline": None, "dtype": "f32 traversal + f64 shading/gradients", "data": "synthetic",
         "config": {"workload": f"{mesh_src} = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD"
-                               + ("" if args.distance_factor == 2.5 else f", cameras at {args.distance_factor} extents"),
+                               + ("" if args.distance_factor == 2.5 else f", cameras at {args.distance_factor} extents")
+                               + (", no grid verdict cache" if args.no_grid_cache else ""),
                    "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
                    "final_loss": float(loss.item())},
     }
