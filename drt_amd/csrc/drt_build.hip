@@ -264,7 +264,7 @@ __global__ void k_refit(const uint32_t* __restrict__ sorted_idx, const int32_t* 
     if (k >= n) return;
     const int32_t face = (int32_t)sorted_idx[k];
     const f3 a = ld_vert(verts, faces[3 * face]), b = ld_vert(verts, faces[3 * face + 1]), c = ld_vert(verts, faces[3 * face + 2]);
-    tris[k] = make_tri(a, b, c, face);
+    tris[k] = make_tri(a, b, c, face, hit_margin(bp->pad));
     Box box = box_of_tri(a, b, c, bp->pad);
     int32_t link = parent_leaf[k];
     while (link >= 0) {
@@ -414,7 +414,7 @@ static int rebuild_impl(drt_scene* s, hipStream_t st, const uint32_t* acc) {
     const int table = kRadix * tiles;
     const int drop = fused_sort ? 6 : 0;               // 24-bit keys, three radix passes (see k_morton)
     const int last_pass = fused_sort ? 2 : 3;
-    if (!acc) k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params, s->hist, fused_sort ? 4 * table : 0);
+    // (without `acc` the scene box -- s->params -- and the zeroed histograms come from k_bounds, launched by rebuild() in front of the fork)
     k_morton<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->params, acc, s->keys[0], s->idx[0], fused_sort ? s->hist : nullptr, tiles, drop);
     int cur = 0;
     for (int shift = drop, pass = 0; shift < 30; shift += 8, ++pass) {
@@ -446,12 +446,22 @@ static int rebuild_impl(drt_scene* s, hipStream_t st, const uint32_t* acc) {
 // The records carry their face id, so any order gives the same result; a spatially coherent one lets the wave-aggregated
 // tile binning of the projection pass (drt_raster.hip) issue a few list atomics per wave instead of one per triangle --
 // and the vertices move little between two steps of an optimisation.
+// The records carry the margin of the hit-point test (drt_tri.h), a function of the scene box: from k_cast_verts' accumulators (`acc`,
+// float64 vertices) or from the BuildParams k_bounds has just written on the same stream (`bp`, float32 vertices) -- the same number
+// k_refit puts into the tree's records a few launches later.
 __global__ void k_tri_flat(const int32_t* __restrict__ faces, const float* __restrict__ verts, int n, TriRec* __restrict__ tris,
-                           const uint32_t* __restrict__ order) {
+                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ acc, const BuildParams* __restrict__ bp) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    float pad;
+    if (acc) {
+        const float ex = f32_unordered(acc[3]) - f32_unordered(acc[0]), ey = f32_unordered(acc[4]) - f32_unordered(acc[1]), ez = f32_unordered(acc[5]) - f32_unordered(acc[2]);
+        pad = pad_for_extent(fmaxf(ex, fmaxf(ey, ez)));
+    } else {
+        pad = bp->pad;
+    }
     const int f = order ? (int)order[k] : k;
-    tris[k] = make_tri(ld_vert(verts, faces[3 * f]), ld_vert(verts, faces[3 * f + 1]), ld_vert(verts, faces[3 * f + 2]), f);
+    tris[k] = make_tri(ld_vert(verts, faces[3 * f]), ld_vert(verts, faces[3 * f + 1]), ld_vert(verts, faces[3 * f + 2]), f, hit_margin(pad));
 }
 
 // The LBVH build is ten small dependent launches (~0.17 ms at 50 k triangles, launch-latency bound).  It runs on the
@@ -462,7 +472,13 @@ int rebuild(drt_scene* s, hipStream_t st, const uint32_t* acc) {
     const int n = (int)s->n_faces;
     // (the previous build's sorted ids are still in idx[sorted_buf]: this launch precedes the fork of the build stream, whose k_morton /
     // sort passes overwrite them)
-    if (n > 0) k_tri_flat<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->tris_flat, s->order_valid ? s->idx[s->sorted_buf] : nullptr);
+    if (n > 0) {
+        if (!acc) {      // float32 vertices: the scene box by one block, in front of the records that need it (and of the fork: the build reads it too)
+            const int tiles = (n + kSortTile - 1) / kSortTile;
+            k_bounds<<<1, 1024, 0, st>>>(s->verts, s->n_verts, s->params, s->hist, tiles <= kSortFusedTiles ? 4 * kRadix * tiles : 0);
+        }
+        k_tri_flat<<<(n + 255) / 256, 256, 0, st>>>(s->faces, s->verts, n, s->tris_flat, s->order_valid ? s->idx[s->sorted_buf] : nullptr, acc, s->params);
+    }
     hipStream_t bs = s->async_build ? s->build_stream : st;
     if (bs != st) {
         HIP_TRY(hipEventRecord(s->build_fork, st));

@@ -64,6 +64,8 @@ DRT_HD Box node_child_box(const Node& n, int slot) {
 // largest scene extent (0.024 mm on a 200 mm object) is two orders above that and
 // also covers the rounding of the slab arithmetic in the traversal.
 DRT_HD float pad_for_extent(float ext) { return ext * (1.0f / 8192.0f); }
+// margin of the hit-point test of drt_tri.h: half the leaf padding (the other half is the slab test's)
+DRT_HD float hit_margin(float pad) { return 0.5f * pad; }
 
 DRT_HD uint32_t expand_bits10(uint32_t v) {
     v = (v * 0x00010001u) & 0xFF0000FFu;

@@ -574,7 +574,7 @@ __device__ __forceinline__ bool path_leaf(const TriRec* __restrict__ tris, TravS
         const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
         const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
         float t;
-        if (tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
+        if (tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, p1.w, t)) {     // (this kernel has the registers)
             int32_t face;
             memcpy(&face, &p0.w, 4);
             if (any) { s.best_t = t; s.best_face = face; return true; }

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) k_bruteforce(const TriRec* __restrict__ t
         for (int j = 0; j < m; ++j) {
             const TriRec t = tile[j];
             float tt;
-            if (tri_hit(o, d, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) {
+            if (tri_hit(o, d, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, t.margin, tt)) {
                 if (tt < best || (tt == best && t.face < best_face)) { best = tt; best_face = t.face; }
             }
         }

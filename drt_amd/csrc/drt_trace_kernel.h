@@ -21,6 +21,7 @@ constexpr int32_t kGuardPoison = 0x5A5A5A5A;
 #else
 constexpr int kGuardRows = 0;
 #endif
+constexpr int32_t kFinished = INT32_MIN + 1;      // TravState::cur of a ray that is done and waits to be emitted (never a node: a leaf reference this large has no slot)
 
 // Where a finished ray's result goes.  Pipeline: out.face[list slot].  B1 (`idx` non-null): the list holds ray numbers;
 // the float32 ray is read from rays[idx[slot]] and T / ID (closest) or the hit flag (any) are written at that ray number.
@@ -42,6 +43,12 @@ __device__ __forceinline__ void trace_emit(const TraceOut& out, int32_t slot, fl
     out.t[i] = best_face >= 0 ? best_t : -1.0f;
     out.face[i] = best_face;
 }
+// Set bits of a wave mask below this lane (v_mbcnt: no (1 << lane) - 1 held in two registers through the kernel -- the traversal loop runs
+// at 64 of 64 registers, and loop-invariant values are what the compiler spills first).
+__device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 template <int MODE>
 __device__ __forceinline__ const float* trace_ray(const float* __restrict__ rays, const TraceOut& out, unsigned slot) {
     return rays + 6 * (int64_t)(MODE != 0 ? out.idx[slot] : (int32_t)slot);
@@ -81,10 +88,21 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
     TravState s;
     unsigned long long wave_steps = 0, lane_steps = 0, leaf_steps = 0;   // wave-uniform diagnostics (scalar registers)
     for (;;) {
-        const unsigned long long idle = __ballot(slot < 0);
-        if (idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull)) {
+        // Finished rays leave here, in ONE place between the phases (where only the ray's own state is alive) and only when the wave
+        // refills anyway, or is through: the deferred hit-point condition on the winner (trav_leaf<ANY, true>) reads the winner's record
+        // again -- a round trip the whole wave would wait for if it were paid whenever some lane finishes -- then the result, or, for a
+        // winner that fails it, the exact second pass.
+        const bool fin = slot >= 0 && s.cur == kFinished;
+        const unsigned long long idle = __ballot(slot < 0 || fin);
+        const bool refill = idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull);
+        if ((refill || idle == ~0ull) && fin) {
+            if (trav_winner_ok(c.tris, s)) trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
+            else redo_list[atomicAdd(redo_count, 1u)] = slot;
+            slot = -1;
+        }
+        if (refill) {
             if (slot < 0) {
-                const unsigned j = taken + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                const unsigned j = taken + lanes_below(idle);
                 const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
                 if (j < my_rays && k < n) {
                     const float* e = trace_ray<MODE>(rays, out, k);
@@ -103,7 +121,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             const bool at_inner = slot >= 0 && s.cur >= 0;
             const unsigned long long mi = __ballot(at_inner);
             if (mi == 0) break;
-            if ((int)__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0) != 0) break;
+            if ((int)__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0 && s.cur != kFinished) != 0) break;
             ++wave_steps;
             lane_steps += (unsigned long long)__popcll(mi);
             if (at_inner) {
@@ -112,21 +130,17 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                     redo_list[atomicAdd(redo_count, 1u)] = slot;
                     slot = -1;
                 } else if (done) {
-                    trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
-                    slot = -1;
+                    s.cur = kFinished;          // (emitted at the top of the loop)
                 }
             }
         }
         // leaf phase
-        const bool at_leaf = slot >= 0 && s.cur < 0;
+        const bool at_leaf = slot >= 0 && s.cur < 0 && s.cur != kFinished;
         const unsigned long long ml = __ballot(at_leaf);
         if (ml != 0) {
             ++wave_steps; ++leaf_steps;
             lane_steps += (unsigned long long)__popcll(ml);
-            if (at_leaf && trav_leaf<ANY>(c.tris, s, st)) {
-                trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
-                slot = -1;
-            }
+            if (at_leaf && trav_leaf<ANY, true>(c.tris, s, st)) s.cur = kFinished;
         }
     }
 #if defined(DRT_CHECK)

@@ -122,6 +122,7 @@ struct TravState {
     int32_t cur;
     float best_t;
     int32_t best_face;
+    int32_t best_slot;    // record of best_face in `tris` (trav_leaf<ANY, true> only: see there)
 };
 
 template <class STACK>
@@ -133,6 +134,7 @@ DRT_HD void trav_init(TravState& s, STACK& st, f3 o, f3 d) {
     s.cur = 0;
     s.best_t = INFINITY;
     s.best_face = -1;
+    s.best_slot = -1;
     st.reset();
 }
 
@@ -248,7 +250,13 @@ DRT_HD bool trav_inner(const Node4Q* __restrict__ nodes, TravState& s, STACK& st
 }
 
 // Test the triangles of the leaf s.cur (< 0).  Returns true when the ray is finished.
-template <bool ANY, class STACK>
+// DEFER (the persistent kernel, which has no registers to keep a triangle alive through its own test): candidates are taken on the
+// barycentric conditions alone and the record of the best one is remembered; the hit-point condition of drt_tri.h is applied ONCE, to the
+// winner, when the ray is done (trav_winner_ok) -- and a ray whose winner fails it is traversed again by the exact form.  That is the
+// same result: until the end the bound best_t is never below the final winner's t, so every triangle with an ACCEPTABLE hit at or in front
+// of the winner had its box visited and its hit taken; a winner that passes is therefore the closest acceptable hit (lowest id among
+// equals), and one that does not is caught.  (A ray without any candidate has pruned nothing by distance: a miss is a miss.)
+template <bool ANY, bool DEFER = false, class STACK>
 DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, STACK& st) {
     if (s.cur == kEmptyChild) return trav_pop(s, st);      // see trav_inner
     const int32_t ref = ~s.cur;
@@ -257,14 +265,27 @@ DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, STACK& st) 
         const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
         const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
         float t;
-        if (tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
+        const bool hit = DEFER ? tri_hit_mt(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)
+                               : tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, p1.w, t);
+        if (hit) {
             int32_t face;
             memcpy(&face, &p0.w, 4);
-            if (ANY) { s.best_t = t; s.best_face = face; return true; }
-            if (t < s.best_t || (t == s.best_t && face < s.best_face)) { s.best_t = t; s.best_face = face; }
+            if (ANY || t < s.best_t || (t == s.best_t && face < s.best_face)) {
+                s.best_t = t; s.best_face = face;
+                if (DEFER) s.best_slot = first + j;
+                if (ANY) return true;
+            }
         }
     }
     return trav_pop(s, st);
+}
+
+// The deferred hit-point condition of a finished ray (trav_leaf<ANY, true>): false = traverse it again with the exact form.
+DRT_HD bool trav_winner_ok(const TriRec* __restrict__ tris, const TravState& s) {
+    if (s.best_face < 0) return true;
+    const F4* tp = reinterpret_cast<const F4*>(tris + s.best_slot);
+    const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+    return hit_point_in_box(s.o, s.d, s.best_t, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, p1.w);
 }
 
 // One node visit, inner or leaf.  Returns true when the ray is finished (result in best_face /

@@ -20,8 +20,10 @@ typedef struct { float lo[3], hi[3]; int32_t left, right, first, count; } node_t
 typedef struct {
     const int32_t *faces; const float *verts;
     int32_t *order; node_t *nodes; int32_t n_nodes;
-    float pad;
+    float pad, margin;
 } bvh_t;
+
+float oracle_hit_margin(const float *verts, int64_t n_verts);      /* tracer.c */
 
 static float centroid(const bvh_t *b, int32_t f, int axis) {
     const int32_t *t = b->faces + 3 * (int64_t)f;
@@ -86,7 +88,14 @@ static int tri_hit(const bvh_t *b, int32_t f, const float o[3], const float d[3]
     const float v = ((d[0] * qx + d[1] * qy) + d[2] * qz) * inv;
     const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
     *t_out = t;
-    return (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f);
+    if (!((u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f))) return 0;
+    /* the hit-point test of tracer.c (same operations, same margin) */
+    const float m = b->margin;
+    const float hx = o[0] + t * d[0], hy = o[1] + t * d[1], hz = o[2] + t * d[2];
+    const float bx = v0[0] + e1x, by = v0[1] + e1y, bz = v0[2] + e1z, cx = v0[0] + e2x, cy = v0[1] + e2y, cz = v0[2] + e2z;
+    return (hx >= fminf(v0[0], fminf(bx, cx)) - m) & (hx <= fmaxf(v0[0], fmaxf(bx, cx)) + m) &
+           (hy >= fminf(v0[1], fminf(by, cy)) - m) & (hy <= fmaxf(v0[1], fmaxf(by, cy)) + m) &
+           (hz >= fminf(v0[2], fminf(bz, cz)) - m) & (hz <= fmaxf(v0[2], fmaxf(bz, cz)) + m);
 }
 
 int oracle_trace_closest_bvh(const int32_t *faces, int64_t n_faces, const float *verts, int64_t n_verts,
@@ -97,7 +106,8 @@ int oracle_trace_closest_bvh(const int32_t *faces, int64_t n_faces, const float 
     if (n_faces > 0) {
         float lo = INFINITY, hi = -INFINITY;
         for (int64_t i = 0; i < 3 * n_verts; ++i) { if (verts[i] < lo) lo = verts[i]; if (verts[i] > hi) hi = verts[i]; }
-        b.pad = 1e-4f * (hi - lo) + 1e-30f;
+        b.pad = 1e-4f * (hi - lo) + 1e-30f;                 /* >= 1.6 x the margin below: an accepted hit point is inside its leaf's box */
+        b.margin = oracle_hit_margin(verts, n_verts);
         b.order = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_faces);
         b.nodes = (node_t *)malloc(sizeof(node_t) * (size_t)(2 * n_faces));
         if (!b.order || !b.nodes) { free(b.order); free(b.nodes); return -1; }

@@ -19,6 +19,10 @@
  *     s = o - v0, u = (s . p) * inv, q = s x e1, v = (d . q) * inv, t = (e2 . q) * inv
  *     dot(a,b) = (a0*b0 + a1*b1) + a2*b2 ; cross(a,b) = (a1*b2 - a2*b1, a2*b0 - a0*b2, a0*b1 - a1*b0)
  *     hit  <=>  u >= 0 && v >= 0 && u + v <= 1 && t > 0      (NaN/inf from det == 0 fail the tests)
+ *               && the hit point (ox + t*dx, ...) lies in the box of (v0, v0 + e1, v0 + e2) grown by `margin`
+ *     margin = 0.5 * (largest extent of the box of ALL vertices) / 8192   (float32; the product's drt_tri.h / drt_lbvh.h state why:
+ *     a ray inside a triangle's plane has det = rounding noise and can pass the first four tests anywhere along itself; the fifth
+ *     keeps "closest hit over every face" something that does not depend on which faces an acceleration structure visits)
  * Closest hit = minimum t; equal t -> lowest face id.  Miss -> T = -1, ID = -1.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
@@ -46,10 +50,19 @@ static int soa_alloc(soa_t *s, int64_t n) {
     return 0;
 }
 
+/* margin of the hit-point test: half of (largest extent of the box of all vertices) / 8192, in float32 */
+float oracle_hit_margin(const float *verts, int64_t n_verts) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n_verts; ++i)
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], verts[3 * i + a]); hi[a] = fmaxf(hi[a], verts[3 * i + a]); }
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return 0.5f * (fmaxf(ex, fmaxf(ey, ez)) * (1.0f / 8192.0f));
+}
+
 /* t of the hit of one ray against triangles [j0, j1), +inf where there is no hit. */
 __attribute__((target_clones("avx2", "default")))
 static void block_t(const soa_t *s, int64_t j0, int64_t j1,
-                    float ox, float oy, float oz, float dx, float dy, float dz, float *tt) {
+                    float ox, float oy, float oz, float dx, float dy, float dz, float margin, float *tt) {
     for (int64_t j = j0; j < j1; ++j) {
         const float e1x = s->e1x[j], e1y = s->e1y[j], e1z = s->e1z[j];
         const float e2x = s->e2x[j], e2y = s->e2y[j], e2z = s->e2z[j];
@@ -65,7 +78,13 @@ static void block_t(const soa_t *s, int64_t j0, int64_t j1,
         const float qz = sx * e1y - sy * e1x;
         const float v = ((dx * qx + dy * qy) + dz * qz) * inv;
         const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
-        const int hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f);
+        const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+        const float ax = s->v0x[j], ay = s->v0y[j], az = s->v0z[j];
+        const float bx = ax + e1x, by = ay + e1y, bz = az + e1z, cx = ax + e2x, cy = ay + e2y, cz = az + e2z;
+        const int inbox = (hx >= fminf(ax, fminf(bx, cx)) - margin) & (hx <= fmaxf(ax, fmaxf(bx, cx)) + margin) &
+                          (hy >= fminf(ay, fminf(by, cy)) - margin) & (hy <= fmaxf(ay, fmaxf(by, cy)) + margin) &
+                          (hz >= fminf(az, fminf(bz, cz)) - margin) & (hz <= fmaxf(az, fmaxf(bz, cz)) + margin);
+        const int hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & inbox;
         tt[j - j0] = hit ? t : INFINITY;
     }
 }
@@ -76,7 +95,7 @@ static void block_t(const soa_t *s, int64_t j0, int64_t j1,
  */
 int oracle_trace_closest(const int32_t *faces, int64_t n_faces, const float *verts, int64_t n_verts,
                          const float *rays, int64_t n_rays, float *T, int32_t *ID) {
-    (void)n_verts;
+    const float margin = oracle_hit_margin(verts, n_verts);
     soa_t s;
     if (soa_alloc(&s, n_faces) != 0) return -1;
     for (int64_t j = 0; j < n_faces; ++j) {
@@ -95,7 +114,7 @@ int oracle_trace_closest(const int32_t *faces, int64_t n_faces, const float *ver
         int32_t best_id = -1;
         for (int64_t j0 = 0; j0 < n_faces; j0 += BLK) {
             const int64_t j1 = j0 + BLK < n_faces ? j0 + BLK : n_faces;
-            block_t(&s, j0, j1, r[0], r[1], r[2], r[3], r[4], r[5], tt);
+            block_t(&s, j0, j1, r[0], r[1], r[2], r[3], r[4], r[5], margin, tt);
             for (int64_t j = j0; j < j1; ++j) {
                 if (tt[j - j0] < best) { best = tt[j - j0]; best_id = (int32_t)j; }
             }

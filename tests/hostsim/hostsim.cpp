@@ -81,7 +81,7 @@ static void build(HsScene& s) {
     for (int k = 0; k < n; ++k) {
         const int32_t face = (int32_t)s.idx[k];
         const f3 a = vert(s, s.faces[3 * face]), b = vert(s, s.faces[3 * face + 1]), c = vert(s, s.faces[3 * face + 2]);
-        s.tris[k] = make_tri(a, b, c, face);
+        s.tris[k] = make_tri(a, b, c, face, hit_margin(s.pad));
         Box box = box_of_tri(a, b, c, s.pad);
         int32_t link = s.parent_leaf[k];
         while (link >= 0) {
@@ -411,7 +411,7 @@ int64_t hs_raster(void* hnd, const double* model14, const double* origin, const 
                 const int64_t i = (int64_t)y * w + x;
                 ++tests;
                 float tt;
-                if (tri_hit(o32, to_f32(load_d3(dir, i)), f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) {
+                if (tri_hit(o32, to_f32(load_d3(dir, i)), f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, t.margin, tt)) {
                     const unsigned long long k = raster_key(tt, t.face);
                     if (k < key[i]) key[i] = k;
                 }

@@ -1,0 +1,123 @@
+"""Differential fuzzing of boundary B1 (optix_mesh.intersect / intersect_any, reference optix_extend.cpp:29-57): random and
+adversarial meshes and rays through the BVH path, against the exhaustive test on the GPU and against oracle/tracer.c -- T and ID
+bit for bit.  What is aimed at: the tie rule (equal t -> lowest face id) on shared edges, shared vertices and coplanar duplicates;
+degenerate faces; direction components that are exactly zero; origins on the surface; rays inside a triangle's plane; coordinates
+from 1e-2 to 1e3; meshes from one triangle to a few thousand (every leaf / collapse shape of a small tree)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffrender_oracle as orc
+
+
+
+def _soup(rng, n_tri, scale):
+    nv = max(3, int(n_tri * rng.uniform(0.6, 2.0)))
+    V = (rng.uniform(-1, 1, (nv, 3)) * scale).astype(np.float32)
+    F = rng.integers(0, nv, (n_tri, 3)).astype(np.int32)            # repeated indices happen: degenerate faces
+    return V, F
+
+
+def _grid(rng, n, scale):
+    """A wavy height field of 2 n^2 triangles on exactly representable x / y coordinates: rays through grid points and along grid
+    lines hit two to six triangles at the same t."""
+    xs = (np.arange(n + 1, dtype=np.float32) - n / 2) * np.float32(scale / n)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    Z = (np.float32(0.1 * scale) * np.sin(3.0 * X / scale) * np.cos(2.0 * Y / scale)).astype(np.float32) if rng.random() < 0.7 else np.zeros_like(X)
+    V = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
+    idx = lambda i, j: i * (n + 1) + j
+    F = []
+    for i in range(n):
+        for j in range(n):
+            F += [[idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)], [idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)]]
+    F = np.array(F, np.int32)
+    return V, F[rng.permutation(len(F))]                              # face ids in random order: the tie rule is about ids
+
+
+def _stack(rng, n_tri, scale):
+    """Coplanar duplicates and near-duplicates of a few triangles: same t for several faces."""
+    base_v, base_f = _soup(rng, max(1, n_tri // 4), scale)
+    F = np.concatenate([base_f] * 4)[:max(1, n_tri)]
+    return base_v, F[rng.permutation(len(F))].astype(np.int32)
+
+
+def _rays(rng, V, F, n, scale):
+    tri = V[F]                                                       # [F, 3, 3]
+    out = []
+    # random rays from around the scene
+    o = rng.uniform(-2, 2, (n, 3)) * scale
+    d = rng.normal(size=(n, 3))
+    out.append(np.concatenate([o, d], 1))
+    # axis-aligned directions (two components exactly zero) and planar ones (one zero)
+    d2 = np.zeros((n, 3)); d2[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+    out.append(np.concatenate([rng.uniform(-1, 1, (n, 3)) * scale, d2], 1))
+    d3 = rng.normal(size=(n, 3)); d3[np.arange(n), rng.integers(0, 3, n)] = 0.0
+    out.append(np.concatenate([rng.uniform(-1.5, 1.5, (n, 3)) * scale, d3], 1))
+    # aimed at vertices, edge midpoints and interior points of random faces (float32 arithmetic: through or next to the feature)
+    f = rng.integers(0, len(F), n)
+    w = rng.dirichlet([1, 1, 1], n)
+    kind = rng.integers(0, 3, n)
+    w[kind == 0] = np.eye(3)[rng.integers(0, 3, (kind == 0).sum())]
+    e = rng.integers(0, 3, (kind == 1).sum()); we = np.full(((kind == 1).sum(), 3), 0.5); we[np.arange(len(e)), e] = 0.0; w[kind == 1] = we
+    target = (tri[f].astype(np.float64) * w[:, :, None]).sum(1)
+    o = rng.uniform(-2, 2, (n, 3)) * scale
+    out.append(np.concatenate([o, target - o], 1))
+    # axis-aligned rays through vertices (grid meshes: exactly through grid points and along grid lines)
+    v = V[rng.integers(0, len(V), n)].astype(np.float64)
+    ax = rng.integers(0, 3, n)
+    o = v.copy(); o[np.arange(n), ax] += rng.choice([-1.0, 1.0], n) * 1.5 * scale
+    out.append(np.concatenate([o, v - o], 1))
+    # origins ON the surface (t = 0 is not a hit, the far side is) and rays inside a triangle's plane
+    o = target
+    out.append(np.concatenate([o, rng.normal(size=(n, 3))], 1))
+    a = tri[f, 1].astype(np.float64) - tri[f, 0]; b = tri[f, 2].astype(np.float64) - tri[f, 0]
+    inplane = a * rng.normal(size=(n, 1)) + b * rng.normal(size=(n, 1))
+    out.append(np.concatenate([target - 3.0 * inplane, inplane], 1))
+    r = np.concatenate(out).astype(np.float32)
+    r[~np.isfinite(r)] = 0.0
+    bad = np.abs(r[:, 3:]).sum(1) == 0                               # a zero direction is no ray: give it one
+    r[bad, 3] = 1.0
+    return np.ascontiguousarray(r)
+
+
+def scene(seed, n_rays=600):
+    """(V float32 [nv,3], F int32 [nf,3], rays float32 [7 n_rays, 6]) of one fuzz case."""
+    rng = np.random.default_rng(1000 + seed)
+    scale = float(10.0 ** rng.uniform(-2, 3))
+    kind = seed % 4
+    if kind == 0:
+        V, F = _soup(rng, int(rng.choice([1, 2, 3, 5, 9, 17, 64, 257, 1000, 4000])), scale)
+    elif kind == 1:
+        V, F = _grid(rng, int(rng.choice([1, 2, 5, 16, 40])), scale)
+    elif kind == 2:
+        V, F = _stack(rng, int(rng.choice([4, 12, 100, 800])), scale)
+    else:                                                             # a soup with slivers and far outliers
+        V, F = _soup(rng, int(rng.choice([30, 300, 2000])), scale)
+        V[rng.integers(0, len(V), max(1, len(V) // 20))] *= 50.0
+        V[:, rng.integers(0, 3)] *= 1e-3
+    return V, F, _rays(rng, V, F, n_rays, scale), scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_random_meshes_and_adversarial_rays_bit_exact(seed):
+    from drt_amd.optix_mesh import optix_mesh
+    V, F, rays, scale = scene(seed)
+    t = optix_mesh(0)
+    t.update_mesh(torch.tensor(F, device="cuda"), torch.tensor(V, device="cuda"))
+    assert t.check()[0] == 0
+    R = torch.tensor(rays, device="cuda")
+    T, ID = t.intersect(R)
+    Tb, IDb = t.intersect_bruteforce(R)
+    assert torch.equal(ID, IDb) and torch.equal(T, Tb)
+    To, IDo = orc.trace_closest(F, V, rays, bvh=False)                # the CPU restatement of the same contract (exhaustive)
+    assert np.array_equal(ID.cpu().numpy(), IDo) and np.array_equal(T.cpu().numpy(), To)
+    assert (IDo >= 0).sum() > 0 or len(F) < 3
+    hit = t.intersect_any(R)
+    assert torch.equal(hit.bool(), ID >= 0)
+    # the same after a refit to moved vertices (update_vert keeps the topology, rebuilds the tree)
+    V2 = (V * np.float32(1.25) + np.float32(0.1 * scale)).astype(np.float32)
+    t.update_vert(torch.tensor(V2, device="cuda"))
+    T2, ID2 = t.intersect(R)
+    To2, IDo2 = orc.trace_closest(F, V2, rays, bvh=False)
+    assert np.array_equal(ID2.cpu().numpy(), IDo2) and np.array_equal(T2.cpu().numpy(), To2)

@@ -76,6 +76,7 @@ def test_inner_visit_reads_bounds_as_float16_subnormals_and_issues_four_loads():
     assert len(kernels) >= 2
     for name, text in kernels:
         body = [ln.split(";")[0].strip() for ln in text.splitlines() if ln.strip() and not ln.strip().startswith((";", "."))]
+        body = [ln for ln in body if not ln.startswith("s_nop")]          # (hazard padding between two loads is not a separation)
         assert sum(ln.startswith("v_fma_mix_f32") for ln in body) >= 24, name
         assert sum(ln.startswith("v_perm_b32") for ln in body) >= 12, name
         assert not any(ln.startswith("v_cvt_f32_ubyte") for ln in body), name

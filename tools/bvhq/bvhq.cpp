@@ -61,7 +61,7 @@ double bvhq_visits(const int32_t* faces, int64_t n_faces, const float* verts, in
     for (int k = 0; k < n; ++k) {
         const int32_t f = order[k];
         const f3 a = V(faces[3 * f]), b = V(faces[3 * f + 1]), c = V(faces[3 * f + 2]);
-        t.tris[k] = make_tri(a, b, c, f);
+        t.tris[k] = make_tri(a, b, c, f, hit_margin(pad));
         leaf[k] = box_of_tri(a, b, c, pad);
     }
     refit(t, 0, leaf);
@@ -137,7 +137,7 @@ extern "C" void bvhq_visits_wide(const int32_t* faces, int64_t n_faces, const fl
     for (int k = 0; k < n; ++k) {
         const int32_t f = (int32_t)idx[k];
         const f3 a = V(faces[3 * f]), b = V(faces[3 * f + 1]), c = V(faces[3 * f + 2]);
-        t.tris[k] = make_tri(a, b, c, f);
+        t.tris[k] = make_tri(a, b, c, f, hit_margin(pad));
         leaf[k] = box_of_tri(a, b, c, pad);
     }
     refit(t, 0, leaf);
@@ -184,7 +184,7 @@ extern "C" void bvhq_visits_wide(const int32_t* faces, int64_t n_faces, const fl
                 ++vl;
                 const TriRec& tr = t.tris[~cur];
                 float tt;
-                if (tri_hit(o, d, f3{tr.v0x, tr.v0y, tr.v0z}, f3{tr.e1x, tr.e1y, tr.e1z}, f3{tr.e2x, tr.e2y, tr.e2z}, tt))
+                if (tri_hit(o, d, f3{tr.v0x, tr.v0y, tr.v0z}, f3{tr.e1x, tr.e1y, tr.e1z}, f3{tr.e2x, tr.e2y, tr.e2z}, tr.margin, tt))
                     if (tt < best_t || (tt == best_t && tr.face < best_face)) { best_t = tt; best_face = tr.face; }
             }
             if (stack.empty()) break;
