@@ -394,3 +394,38 @@ def test_many_sub_batches_on_two_streams(extra):
                         "-m", "gpu", "-x", "-q", "-k", sel], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_axis_aligned_box_seen_along_its_faces(Render):
+    """A box with axis-aligned faces and cameras that sit IN the planes of its faces and look along the axes: whole image rows and columns
+    of rays run inside a face's plane (direction component exactly zero, origin exactly on the plane) -- the rays for which a float32
+    triangle test alone does not define a closest hit (drt_tri.h's hit-point condition does).  Projection pass, tree and exhaustive test
+    must agree on every pixel, and the whole path must equal the oracle's."""
+    from oracle import diffrender_oracle as orc
+    c = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], np.float64) * [40.0, 30.0, 20.0]
+    f = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]])
+    box = mesh_io.TriMesh(c, f)
+    for _ in range(3):
+        box = mesh_io.subdivide_midpoint(box)                       # 768 faces on exactly representable coordinates
+    scene = Render.Scene(box, 0)
+    res = 128
+    K = np.array([[1.2 * res, 0, res / 2], [0, 1.2 * res, res / 2], [0, 0, 1.0]])        # principal point ON a pixel centre: one row and one column with a zero component
+    Kinv = np.linalg.inv(K)
+    total_hits = 0
+    for eye, fwd, up in (([-200.0, 30.0, 20.0], [1, 0, 0], [0, 0, 1]),     # in the planes y = +30 and z = +20
+                         ([40.0, -150.0, -20.0], [0, 1, 0], [0, 0, 1]),     # in the planes x = +40 and z = -20
+                         ([0.0, 0.0, 160.0], [0, 0, -1], [0, 1, 0]),        # on two symmetry planes: rays along the grid lines of the top face
+                         ([40.0, 30.0, 100.0], [0, 0, -1], [1, 0, 0])):     # straight above a corner
+        fwd, up = np.array(fwd, float), np.array(up, float)
+        right = np.cross(fwd, up)
+        Rinv = np.eye(4); Rinv[:3, 0], Rinv[:3, 1], Rinv[:3, 2], Rinv[:3, 3] = right, up, fwd, eye
+        o, d = views.generate_ray(res, res, Kinv, Rinv, device="cuda")
+        prof, f1 = _check(Render, scene, o, d, res, res)
+        total_hits += int((f1 >= 0).sum())
+        with torch.no_grad():
+            oo, od, mk = scene.render_transparent(o, d)
+        ro, rd, rm = orc.render_transparent(orc.Mesh(box.faces, torch.tensor(box.vertices)), o.cpu(), d.cpu(), IOR)
+        assert torch.equal(mk.cpu(), rm)
+        np.testing.assert_allclose(oo.cpu().numpy(), ro.numpy(), rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(od.cpu().numpy(), rd.numpy(), rtol=1e-10, atol=1e-11)
+    assert total_hits > 1000
