@@ -121,3 +121,69 @@ def test_random_meshes_and_adversarial_rays_bit_exact(seed):
     T2, ID2 = t.intersect(R)
     To2, IDo2 = orc.trace_closest(F, V2, rays, bvh=False)
     assert np.array_equal(ID2.cpu().numpy(), IDo2) and np.array_equal(T2.cpu().numpy(), To2)
+
+
+def _shape(rng):
+    """A random closed surface: a noisy, anisotropically scaled icosphere (star-shaped, with creases and near-tangent facets), sometimes
+    two of them merged into one mesh (an inner and an outer shell, or two lobes side by side: rays leave one and enter the other)."""
+    from drt_amd import mesh_io
+    def one(sub, radius, noise, seed):
+        m = mesh_io.icosphere(sub, radius=radius, noise=noise, seed=seed)
+        return m.vertices * rng.uniform(0.5, 1.5, 3), m.faces
+    V, F = one(int(rng.integers(1, 4)), float(rng.uniform(20, 60)), float(rng.choice([0.0, 0.05, 0.2])), int(rng.integers(1 << 30)))
+    if rng.random() < 0.4:
+        V2, F2 = one(int(rng.integers(1, 3)), float(rng.uniform(5, 15)), 0.1, int(rng.integers(1 << 30)))
+        V2 = V2 + (rng.uniform(-1, 1, 3) * rng.choice([3.0, 80.0]))          # inside the first one, or beside it
+        V, F = np.concatenate([V, V2]), np.concatenate([F, F2 + len(V)])
+    V = V + rng.uniform(-30, 30, 3)
+    return mesh_io.TriMesh(V.astype(np.float32).astype(np.float64), F)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_cameras_and_ior_through_the_whole_path(seed):
+    """render_transparent + ray_loss + backward on random closed shapes, cameras (far, close, inside the object, non-square images) and
+    indices of refraction, against the oracle: mask and both face ids exact, rays to 1e-10, loss to 1e-10, gradient to 1e-9 relative;
+    the one-pass loss and a call without the image-size hint (tree for every primary ray) give the same."""
+    from conftest import IOR
+    from drt_amd import diffrender as Render, views
+    rng = np.random.default_rng(7000 + seed)
+    mesh = _shape(rng)
+    ior = float(rng.choice([IOR, 1.1, 1.33, 2.4]))
+    Render.intIOR = ior
+    try:
+        scene = Render.Scene(mesh, 0)
+        w, h = [(64, 64), (96, 48), (48, 80), (128, 64)][seed % 4]
+        c, ext = views.mesh_frame(mesh.vertices)
+        dist = float(rng.choice([2.5, 1.2, 0.8, 0.3], p=[0.3, 0.4, 0.2, 0.1]))  # 0.8: grazing close-up; 0.3: the camera is inside (or on the edge of) the object
+        R, K, Rinv, Kinv = views.turntable_cameras(c, ext, 72, w, h, distance_factor=dist)[int(rng.integers(72))]
+        o, d = views.generate_ray(h, w, Kinv, Rinv)
+        sp = torch.tensor(rng.standard_normal(o.shape) * 40.0 + np.asarray(c))
+        valid = torch.tensor(rng.random(len(o)) > 0.2)
+        wgt = torch.tensor(rng.standard_normal(o.shape))
+        Vc = torch.tensor(mesh.vertices, dtype=torch.float64, requires_grad=True)
+        oo, od, mk, aux = orc.render_transparent(orc.Mesh(mesh.faces, Vc), o, d, ior, return_aux=True)
+        ref = orc.ray_loss(oo, od, mk, sp, valid)
+        (ref + (od * wgt).sum() + (oo * wgt).sum()).backward()
+        for hint in ((w, h), (7, 7)):                                         # projection pass where the rays verify / the tree for every ray
+            Render.resx, Render.resy = hint
+            V = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+            scene.update_verticex(V)
+            out_ori, out_dir, mask = scene.render_transparent(o.cuda(), d.cuda())
+            assert torch.equal(mask.cpu(), mk)
+            assert torch.equal(scene.last_face1.cpu().long(), aux["face1"])
+            f2 = aux["face2"].clone(); f2[~mk[:, 0]] = -1
+            assert torch.equal(scene.last_face2.cpu().long(), f2)
+            torch.testing.assert_close(out_dir.detach().cpu(), od.detach(), rtol=1e-10, atol=1e-11)
+            torch.testing.assert_close(out_ori.detach().cpu(), oo.detach(), rtol=1e-10, atol=1e-9)
+            loss = Render.ray_loss(out_ori, out_dir, mask, sp.cuda(), valid.cuda())
+            assert loss.item() == pytest.approx(ref.item(), rel=1e-10, abs=1e-12)
+            (loss + (out_dir * wgt.cuda()).sum() + (out_ori * wgt.cuda()).sum()).backward()
+            err = (V.grad.cpu() - Vc.grad).abs().max().item()
+            assert err <= 1e-5 and err <= 1e-9 * max(1.0, Vc.grad.abs().max().item()), err
+            V2 = V.detach().clone().requires_grad_(True)
+            scene.update_verticex(V2)
+            lf = scene.ray_loss_fused(o.cuda(), d.cuda(), sp.cuda(), valid.cuda())
+            assert lf.item() == pytest.approx(ref.item(), rel=1e-10, abs=1e-12)
+    finally:
+        Render.intIOR = IOR
