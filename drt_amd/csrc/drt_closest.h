@@ -16,9 +16,29 @@
 
 namespace drt {
 
-// Closest point of triangle abc to p, by the Voronoi region of p (vertex, edge or face region).
+DRT_HD d3 closest_on_segment(d3 p, d3 a, d3 b) {
+    const d3 ab = b - a;
+    const double ee = dot(ab, ab);
+    if (!(ee > 0.0)) return a;
+    const double t = fmin(fmax(dot(p - a, ab) / ee, 0.0), 1.0);
+    return a + ab * t;
+}
+
+// Closest point of triangle abc to p, by the Voronoi region of p (vertex, edge or face region).  A triangle without area -- two equal
+// indices, three points on a line -- is the segment (or point) its vertices span: the closest of its three edges.  (The region
+// formulas divide by edge lengths and by the area; face [a, a, c] used to come out as NaN and count for nothing, found by
+// tests/test_gpu_fuzz.py.  In a closed mesh the edges of such a face belong to its neighbours as well, so nothing changed there.)
 DRT_HD d3 closest_on_triangle(d3 p, d3 a, d3 b, d3 c) {
     const d3 ab = b - a, ac = c - a, ap = p - a;
+    {
+        const d3 n = cross(ab, ac);
+        if (!(dot(n, n) > 1e-24 * (dot(ab, ab) * dot(ac, ac)))) {
+            const d3 q1 = closest_on_segment(p, a, b), q2 = closest_on_segment(p, a, c), q3 = closest_on_segment(p, b, c);
+            const d3 r1 = p - q1, r2 = p - q2, r3 = p - q3;
+            const double e1 = dot(r1, r1), e2 = dot(r2, r2), e3 = dot(r3, r3);
+            return e1 <= e2 ? (e1 <= e3 ? q1 : q3) : (e2 <= e3 ? q2 : q3);
+        }
+    }
     const double d1 = dot(ab, ap), d2 = dot(ac, ap);
     if (d1 <= 0.0 && d2 <= 0.0) return a;
     const d3 bp = p - b;
@@ -83,7 +103,7 @@ DRT_HD Closest closest_point(const Node4Q* __restrict__ nodes, const TriRec* __r
                 const d3 q = closest_on_triangle(p, a, b, c);
                 const d3 r = p - q;
                 const double dd = dot(r, r);
-                if (dd < best.dist2) best = Closest{dd, face, q};      // NaN (degenerate triangle) never wins
+                if (dd < best.dist2) best = Closest{dd, face, q};      // (NaN -- non-finite vertices -- never wins)
             }
         }
         if (st.empty()) break;

@@ -187,3 +187,94 @@ def test_random_shapes_cameras_and_ior_through_the_whole_path(seed):
             assert lf.item() == pytest.approx(ref.item(), rel=1e-10, abs=1e-12)
     finally:
         Render.intIOR = IOR
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_through_the_silhouette_and_smoothness_terms(seed):
+    """silhouette_edge + primary_visibility + |soft mask - 0.5| (reference optim.py:67-80) and -log(1 + cos dihedral) (optim.py:82-89) on
+    random closed shapes and cameras against the oracle: the silhouette edge set and the sample pixels exact, the losses to 1e-12, the
+    gradients to 1e-8 relative -- through the drop-in methods and through the one-kernel forms."""
+    from drt_amd import diffrender as Render, views
+    rng = np.random.default_rng(9000 + seed)
+    mesh = _shape(rng)
+    scene = Render.Scene(mesh, 0)
+    res_x, res_y = [(64, 64), (96, 48), (48, 80), (128, 64)][seed % 4]
+    Render.resx, Render.resy = res_x, res_y
+    c, ext = views.mesh_frame(mesh.vertices)
+    dist = float(rng.choice([2.5, 1.2, 0.8]))
+    cam_np = views.turntable_cameras(c, ext, 72, res_x, res_y, distance_factor=dist)[int(rng.integers(72))]
+    cam = tuple(torch.tensor(np.asarray(m), dtype=torch.float64) for m in cam_np)
+    origin3 = cam[2][:3, 3].contiguous()
+    soft = torch.tensor(rng.random(res_x * res_y))
+    Edges, E2F = scene.Edges.cpu(), scene.E2F.cpu()
+    Vc = torch.tensor(mesh.vertices, dtype=torch.float64, requires_grad=True)
+    om = orc.Mesh(mesh.faces, Vc)
+    sil_ref = orc.silhouette_edges(Vc, Edges, E2F, origin3)
+    idx_ref, out_ref = orc.primary_visibility(om, sil_ref, cam, origin3, res_x, res_y, detach_depth=True)
+    vh_ref = orc.vh_loss_view(om, Edges, E2F, cam, origin3, soft, res_x, res_y)
+    sm_ref = orc.sm_loss(Vc, E2F)
+    g_vh, = torch.autograd.grad(vh_ref, Vc, retain_graph=True)
+    g_sm, = torch.autograd.grad(sm_ref, Vc)
+
+    V = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    camd = tuple(m.cuda() for m in cam)
+    sil = scene.silhouette_edge(origin3.cuda())
+    assert torch.equal(sil.cpu(), sil_ref)
+    index, output = scene.primary_visibility(sil, camd, origin3.cuda(), detach_depth=True)
+    assert torch.equal(index.cpu(), idx_ref) and torch.equal(output.detach().cpu().double(), out_ref.double())
+    vh = (soft.cuda().view((res_y, res_x))[index[:, 1], index[:, 0]] - output).abs().sum()
+    assert vh.item() == pytest.approx(vh_ref.item(), rel=1e-12, abs=1e-12)
+    sm = (-torch.log(1 + scene.dihedral_angle())).sum()
+    assert sm.item() == pytest.approx(sm_ref.item(), rel=1e-10)
+    gv, = torch.autograd.grad(vh, V, retain_graph=True, allow_unused=True)
+    gs, = torch.autograd.grad(sm, V)
+    gv = torch.zeros_like(V) if gv is None else gv
+    scale_vh, scale_sm = max(1e-30, g_vh.abs().max().item()), max(1e-30, g_sm.abs().max().item())
+    assert (gv.cpu() - g_vh).abs().max().item() <= 1e-8 * scale_vh + 1e-12
+    assert (gs.cpu() - g_sm).abs().max().item() <= 1e-8 * scale_sm
+    # the one-kernel forms
+    V2 = V.detach().clone().requires_grad_(True)
+    scene.update_verticex(V2)
+    vhf = scene.vh_loss_fused(camd, origin3.cuda(), soft.cuda())
+    smf = scene.sm_loss_fused()
+    assert vhf.item() == pytest.approx(vh_ref.item(), rel=1e-12, abs=1e-12) and smf.item() == pytest.approx(sm_ref.item(), rel=1e-10)
+    (vhf + smf).backward()
+    ref = g_vh + g_sm
+    assert (V2.grad.cpu() - ref).abs().max().item() <= 1e-8 * max(1e-30, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_soups_closest_point(seed):
+    """drt_closest_point (the vertex-to-scan metric) on random triangle soups -- degenerate faces, slivers, coplanar duplicates
+    included -- against the oracle's independent brute force: distances to 1e-9 of the scene size, the returned point on the returned
+    face's plane at that distance.  Points: random, far away, exactly on vertices, on edges, on faces."""
+    from drt_amd.optix_mesh import optix_mesh
+    rng = np.random.default_rng(4000 + seed)
+    scale = float(10.0 ** rng.uniform(-1, 2))
+    if seed % 2:
+        V, F = _soup(rng, int(rng.choice([1, 2, 8, 60, 500, 3000])), scale)
+    else:
+        V, F = _stack(rng, int(rng.choice([4, 40, 400])), scale)
+    tri = V[F].astype(np.float64)
+    n = 300
+    f = rng.integers(0, len(F), n)
+    w = rng.dirichlet([1, 1, 1], n)
+    on_face = (tri[f] * w[:, :, None]).sum(1)
+    on_vert = tri[f, rng.integers(0, 3, n)]
+    on_edge = 0.5 * (tri[f, 0] + tri[f, 1])
+    pts = np.concatenate([rng.uniform(-1.5, 1.5, (n, 3)) * scale, rng.uniform(-40, 40, (n, 3)) * scale, on_face, on_vert, on_edge,
+                          on_face + rng.normal(size=(n, 3)) * 1e-4 * scale])
+    t = optix_mesh(0)
+    t.update_mesh(torch.tensor(F, device="cuda"), torch.tensor(V, device="cuda"))
+    dist, face, closest = t.closest_point(torch.tensor(pts, device="cuda"), want_face=True, want_point=True)
+    ref_d, _ = orc.point_mesh_distance(pts, V, F)
+    size = np.abs(pts).max() + scale
+    np.testing.assert_allclose(dist.cpu().numpy(), ref_d, rtol=1e-9, atol=1e-9 * size)
+    # the returned point is at the returned distance and no closer to the surface than rounding
+    np.testing.assert_allclose(np.linalg.norm(closest.cpu().numpy() - pts, axis=1), dist.cpu().numpy(), rtol=1e-9, atol=1e-9 * size)
+    d_back, _ = orc.point_mesh_distance(closest.cpu().numpy(), V, F)
+    assert d_back.max() <= 1e-6 * size
+    assert int(face.min()) >= 0 and int(face.max()) < len(F)
