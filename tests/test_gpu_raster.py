@@ -429,3 +429,22 @@ def test_axis_aligned_box_seen_along_its_faces(Render):
         np.testing.assert_allclose(oo.cpu().numpy(), ro.numpy(), rtol=1e-10, atol=1e-9)
         np.testing.assert_allclose(od.cpu().numpy(), rd.numpy(), rtol=1e-10, atol=1e-11)
     assert total_hits > 1000
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_image_sizes_and_view_counts(Render, seed):
+    """Image sizes that are no multiple of anything (the projection pass wants whole 64 x 4 patches: other sizes take the tree, or the
+    patch path with cut tiles), one to four images per call, hints that match and hints that do not: always the exhaustive test's ids."""
+    rng = np.random.default_rng(300 + seed)
+    hand = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(hand, 0)
+    c, ext = views.mesh_frame(hand.vertices)
+    for _ in range(4):
+        w = int(rng.choice([rng.integers(5, 200), 64 * rng.integers(1, 4), 4 * rng.integers(2, 50)]))
+        h = int(rng.choice([rng.integers(5, 200), 4 * rng.integers(2, 50), 16 * rng.integers(1, 12)]))
+        nv = int(rng.integers(1, 5))
+        cams = views.turntable_cameras(c, ext, 72, w, h, distance_factor=float(rng.choice([2.5, 1.3])))
+        rays = [views.generate_ray(h, w, cams[k][3], cams[k][2], device="cuda") for k in rng.integers(0, 72, nv)]
+        o = torch.cat([r[0] for r in rays]).contiguous(); d = torch.cat([r[1] for r in rays]).contiguous()
+        _check(Render, scene, o, d, w, h)
+        _check(Render, scene, o, d, h, w)                # a wrong hint
