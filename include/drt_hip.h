@@ -52,8 +52,11 @@ int drt_update_vert(drt_scene_t* s, const float* d_verts, int64_t n_verts, void*
 int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, void* stream);
 
 /* drt_intersect <- optix_mesh::intersect(Ray float32 [N,6]) -> T float32 [N], ID int32 [N],
- * optix_extend.cpp:29-57.  Closest hit with t > 0; miss: T = -1, ID = -1.  Outputs are
- * caller-owned contiguous arrays (the reference returns strided aliases of one buffer).
+ * optix_extend.cpp:29-57.  Closest hit with t > 0 (equal t: the lowest face id); miss: T = -1, ID = -1.  What a hit is:
+ * the float32 Moller-Trumbore test of drt_amd/csrc/drt_tri.h -- the transcription of the reference's own JIT_Dintersect --
+ * plus "the hit point lies in the triangle's bounding box grown by 2^-14 of the scene extent", which is what makes the
+ * closest hit over ALL triangles computable by a tree for rays that run inside a triangle's plane.
+ * Outputs are caller-owned contiguous arrays (the reference returns strided aliases of one buffer).
  * drt_intersect_any writes only a hit flag (uint8) -- what Scene.optix_intersect's callers
  * at DiffRender.py:426 and :224 use. */
 int drt_intersect(drt_scene_t* s, const float* d_rays, int64_t n_rays,
