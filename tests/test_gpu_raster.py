@@ -448,3 +448,32 @@ def test_random_image_sizes_and_view_counts(Render, seed):
         o = torch.cat([r[0] for r in rays]).contiguous(); d = torch.cat([r[1] for r in rays]).contiguous()
         _check(Render, scene, o, d, w, h)
         _check(Render, scene, o, d, h, w)                # a wrong hint
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_intrinsics_and_poses(Render, seed):
+    """Pinhole models nobody would build on purpose: unequal and negative focal lengths (mirrored images), skew, a principal point far off
+    the image, fields of view from 2 to 150 degrees, cameras rolled about their axis, a few extents away, skimming the surface or inside
+    the object, looking away from it; a fine mesh and one whose triangles cover a fifth of the image.  The fitted model either verifies --
+    then the projection pass must find the exhaustive test's ids -- or it does not, and the tree answers."""
+    rng = np.random.default_rng(500 + seed)
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply")) if seed % 2 else mesh_io.icosphere(int(rng.integers(0, 3)), radius=50.0, noise=0.1, seed=seed)
+    scene = Render.Scene(mesh, 0)
+    c, ext = views.mesh_frame(mesh.vertices)
+    c = np.asarray(c, float)
+    for _ in range(5):
+        w, h = int(rng.choice([64, 128, 192])), int(rng.choice([64, 96, 128]))
+        f = w / (2 * np.tan(np.radians(rng.choice([2, 20, 60, 110, 150])) / 2))
+        K = np.array([[f * rng.choice([1, -1]), f * rng.choice([0, 0, 0.3]), w / 2 + rng.choice([0, 0, 3 * w]) * rng.choice([-1, 1])],
+                      [0, f * rng.uniform(0.5, 2.0) * rng.choice([1, 1, -1]), h / 2 + rng.choice([0, 0.5, -2 * h])], [0, 0, 1.0]])
+        # a random rotation (QR of a Gaussian matrix, made proper) and a position at 0.2 - 4 extents, usually looking at the object
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] *= -1
+        dist = float(rng.choice([0.2, 0.6, 1.0, 2.5, 4.0])) * float(np.max(ext))
+        eye = c + Q[:, 2] * (-dist if rng.random() < 0.8 else dist)
+        Rinv = np.eye(4); Rinv[:3, :3] = Q; Rinv[:3, 3] = eye
+        o, d = views.generate_ray(h, w, np.linalg.inv(K), Rinv, device="cuda")
+        if not bool(torch.isfinite(d).all()):
+            continue
+        _check(Render, scene, o, d, w, h)
