@@ -458,10 +458,13 @@ def test_stack_overflow_paths_with_a_tiny_lds_stack(tmp_path):
     from drt_amd import build
     so = str(tmp_path / "libdrt_hip_stack3.so")
     build.build(force=True, out=so, extra_flags=("-DDRT_STACK_FAST=3",))
-    sel = "test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or test_silhouette_branch_vs_golden"
+    sel = ("test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or test_silhouette_branch_vs_golden or "
+           "test_random_meshes_and_adversarial_rays or test_random_shapes_cameras_and_ior")
+    fuzz = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_fuzz.py")
     for extra in ({}, {"DRT_MEGA_MAX_LOG2": "24"}):          # (the staged kernels' redo passes; k_path's redo pass)
         env = dict(os.environ, DRT_HIP_LIB=so, **extra)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", sel if not extra else "test_render_transparent_vs_golden or test_two_optimisation_steps"],
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), fuzz, "-m", "gpu", "-x", "-q", "-k",
+                            sel if not extra else "test_render_transparent_vs_golden or test_two_optimisation_steps or test_random_shapes_cameras_and_ior"],
                            env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
         assert " passed" in r.stdout
@@ -538,9 +541,10 @@ def test_lds_stack_invariants_hold_in_a_checked_build(tmp_path, flags, extra):
     env = dict(os.environ, DRT_HIP_LIB=so, DRT_EXPECT_CHECKED="1", **extra)
     here = os.path.dirname(os.path.abspath(__file__))
     sel = ("test_b1_intersect_equals_oracle_bruteforce or test_render_transparent_vs_golden or test_full_size_traversal or "
-           "test_silhouette_branch_vs_golden or test_two_optimisation_steps or test_zz_check_counters")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_configs.py"), os.path.join(here, "test_gpu_zz_check.py"),
-                        "-m", "gpu", "-x", "-q", "-k", sel], env=env, capture_output=True, text=True, timeout=1500)
+           "test_silhouette_branch_vs_golden or test_two_optimisation_steps or test_random_meshes_and_adversarial_rays or "
+           "test_random_shapes_cameras_and_ior or test_zz_check_counters")         # (the fuzz scenes: soups and stacks of duplicates make the deepest, most lopsided trees)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_configs.py"), os.path.join(here, "test_gpu_fuzz.py"),
+                        os.path.join(here, "test_gpu_zz_check.py"), "-m", "gpu", "-x", "-q", "-k", sel], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "test_zz_check_counters" not in r.stdout.split("short test summary")[-1]
 
