@@ -123,16 +123,16 @@ def test_random_meshes_and_adversarial_rays_bit_exact(seed):
     assert np.array_equal(ID2.cpu().numpy(), IDo2) and np.array_equal(T2.cpu().numpy(), To2)
 
 
-def _shape(rng):
+def _shape(rng, noises=(0.0, 0.05, 0.2)):
     """A random closed surface: a noisy, anisotropically scaled icosphere (star-shaped, with creases and near-tangent facets), sometimes
     two of them merged into one mesh (an inner and an outer shell, or two lobes side by side: rays leave one and enter the other)."""
     from drt_amd import mesh_io
     def one(sub, radius, noise, seed):
         m = mesh_io.icosphere(sub, radius=radius, noise=noise, seed=seed)
         return m.vertices * rng.uniform(0.5, 1.5, 3), m.faces
-    V, F = one(int(rng.integers(1, 4)), float(rng.uniform(20, 60)), float(rng.choice([0.0, 0.05, 0.2])), int(rng.integers(1 << 30)))
+    V, F = one(int(rng.integers(1, 4)), float(rng.uniform(20, 60)), float(rng.choice(noises)), int(rng.integers(1 << 30)))
     if rng.random() < 0.4:
-        V2, F2 = one(int(rng.integers(1, 3)), float(rng.uniform(5, 15)), 0.1, int(rng.integers(1 << 30)))
+        V2, F2 = one(int(rng.integers(1, 3)), float(rng.uniform(5, 15)), min(0.1, max(noises)), int(rng.integers(1 << 30)))
         V2 = V2 + (rng.uniform(-1, 1, 3) * rng.choice([3.0, 80.0]))          # inside the first one, or beside it
         V, F = np.concatenate([V, V2]), np.concatenate([F, F2 + len(V)])
     V = V + rng.uniform(-30, 30, 3)

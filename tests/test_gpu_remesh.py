@@ -165,3 +165,40 @@ def test_device_remesh_keeps_the_genus_of_a_torus(L):
     assert abs(rho.mean() - 12.0) < 0.15 and rho.min() > 11.0 and rho.max() < 12.2       # still the tube of radius 12 (vertices on the input polyhedron)
     assert abs(_volume(dev) / _volume(t) - 1) < 0.03
 
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_remesh_on_random_shapes(seed):
+    """Random closed shapes (tests/test_gpu_fuzz.py::_shape: noisy stretched icospheres, some with a second component inside or beside
+    them), coarsened and refined: a closed oriented manifold comes out, with the input's Euler characteristic (2 per component), on the
+    input surface, without folds or degenerate faces, edge lengths around the target -- and the host version agrees on the size."""
+    from test_gpu_fuzz import _shape
+    rng = np.random.default_rng(100 + seed)
+    mesh = _shape(rng, noises=(0.0, 0.03, 0.06))          # (bumps well below the edge length: what a visual hull or an optimised mesh looks like)
+    chi = len(mesh.vertices) - len(mesh.faces) // 2
+    assert chi in (2, 4)
+    mean_len = float(_edge_len(mesh).mean())
+    for factor in (1.6, 0.6):
+        L = factor * mean_len
+        dev, st = _gpu_remesh(mesh, L)
+        assert dev.is_watertight and _oriented_closed(dev)
+        assert len(dev.vertices) - len(dev.faces) // 2 == chi
+        assert len(np.unique(dev.faces)) == len(dev.vertices)
+        tri = dev.vertices[dev.faces]
+        area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+        assert area.min() > 1e-6 * L * L
+        el = _edge_len(dev)
+        assert el.max() <= 4.0 / 3.0 * L * 1.25
+        if factor < 1:        # (coarsening a bumpy surface stops where a collapse would leave the input surface by more than MaxSurfDist)
+            assert ((el > 0.8 * L) & (el < 4.0 / 3.0 * L)).mean() > 0.7, ((el > 0.8 * L) & (el < 4.0 / 3.0 * L)).mean()
+        d_new, _ = orc.point_mesh_distance(dev.vertices, mesh.vertices, mesh.faces)
+        # on the input surface -- but for the few vertices whose projection would have folded a face: those stay where the relaxation put them
+        assert np.quantile(d_new, 0.97) < 1e-3 * max(1.0, np.abs(mesh.vertices).max() / 50.0) and d_new.max() < 0.25 * L, (np.quantile(d_new, 0.97), d_new.max(), L)
+        e2f = mesh_io.edge_tables(dev)[1]
+        t2 = dev.vertices[e2f]
+        n = np.cross(t2[:, :, 1] - t2[:, :, 0], t2[:, :, 2] - t2[:, :, 0])
+        n /= np.linalg.norm(n, axis=2, keepdims=True)
+        assert (n[:, 0] * n[:, 1]).sum(1).min() > -0.95
+        assert abs(_volume(dev) / _volume(mesh) - 1) < 0.15
+        host = remesh.isotropic_remesh(mesh, L)
+        assert abs(len(dev.faces) / len(host.faces) - 1) < 0.08, (len(dev.faces), len(host.faces))
