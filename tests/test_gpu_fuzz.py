@@ -278,3 +278,92 @@ def test_random_soups_closest_point(seed):
     d_back, _ = orc.point_mesh_distance(closest.cpu().numpy(), V, F)
     assert d_back.max() <= 1e-6 * size
     assert int(face.min()) >= 0 and int(face.max()) < len(F)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_interleaved_scenes_and_streams(seed):
+    """Three scenes, three caller streams, eighty operations in random order -- vertex updates, drop-in calls of one to three images, one-pass
+    losses, backward passes, with the ahead-of-time fills forced on at every size and two sub-batches per call -- each result compared with
+    the same operation done alone on a fresh scene: forward outputs bit for bit, losses to 1e-12, gradients to 1e-10.  (The library's internal
+    streams, events and workspaces belong to a scene; the caller's stream may be any; nothing may leak from one call into another.)"""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import IOR, data_path
+from drt_amd import diffrender as Render, mesh_io, views
+seed = %d
+Render.intIOR = IOR
+rng = np.random.default_rng(50 + seed)
+meshes = [mesh_io.read_ply(data_path("hand_vh.ply")), mesh_io.icosphere(3, radius=60.0, noise=0.05, seed=3), mesh_io.subdivide_midpoint(mesh_io.icosphere(2, radius=40.0, noise=0.1, seed=5))]
+res = 128
+Render.resx = Render.resy = res
+cams = [views.turntable_cameras(*views.mesh_frame(m.vertices), 72, res, res, distance_factor=1.6) for m in meshes]
+def rays(k, ids):
+    r = [views.generate_ray(res, res, cams[k][i][3], cams[k][i][2], device="cuda") for i in ids]
+    return torch.cat([x[0] for x in r]).contiguous(), torch.cat([x[1] for x in r]).contiguous()
+ops = []
+for _ in range(80):
+    k = int(rng.integers(3)); kind = str(rng.choice(["update", "render", "fused", "render"]))
+    ids = [int(i) for i in rng.integers(0, 72, int(rng.integers(1, 4)))]
+    ops.append((k, kind, ids, float(rng.uniform(0.97, 1.03)), int(rng.integers(3)), int(rng.integers(1 << 30))))
+def run(op, scene, V_state, stream):
+    k, kind, ids, scale, _, s2 = op
+    with torch.cuda.stream(stream):
+        if kind == "update":
+            V_state[k] = (torch.tensor(meshes[k].vertices, device="cuda") * scale).requires_grad_(True)
+            scene.update_verticex(V_state[k])
+            return None
+        o, d = rays(k, ids)
+        g = torch.Generator(device="cuda").manual_seed(s2)
+        sp = torch.randn(o.shape, dtype=torch.float64, device="cuda", generator=g) * 30.0
+        valid = torch.rand(len(o), device="cuda", generator=g) < 0.7
+        V = V_state[k].detach().clone().requires_grad_(True)
+        scene.update_verticex(V)
+        if kind == "render":
+            oo, od, mk = scene.render_transparent(o, d)
+            loss = Render.ray_loss(oo, od, mk, sp, valid)
+            loss.backward()
+            return [oo.detach().clone(), od.detach().clone(), mk.clone(), loss.detach().clone(), V.grad.clone()]
+        loss = scene.ray_loss_fused(o, d, sp, valid)
+        loss.backward()
+        return [loss.detach().clone(), V.grad.clone()]
+# reference: every operation alone, on a fresh scene in its current vertex state, default stream
+ref = []
+V_state = [torch.tensor(m.vertices, device="cuda").requires_grad_(True) for m in meshes]
+for op in ops:
+    sc = Render.Scene(meshes[op[0]], 0)
+    ref.append(run(op, sc, V_state, torch.cuda.current_stream()))
+    torch.cuda.synchronize()
+# the interleaved run: one scene per mesh, operations issued on three streams without synchronising in between
+scenes = [Render.Scene(m, 0) for m in meshes]
+streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+V_state = [torch.tensor(m.vertices, device="cuda").requires_grad_(True) for m in meshes]
+got = []
+last = [None, None, None]                     # the stream that last touched scene k: a caller orders ITS OWN uses of one scene
+for op in ops:
+    st = streams[op[4]]
+    if last[op[0]] is not None and last[op[0]] is not st:
+        st.wait_stream(last[op[0]])
+    got.append(run(op, scenes[op[0]], V_state, st))
+    last[op[0]] = st
+torch.cuda.synchronize()
+bad = 0
+for a, b, op in zip(ref, got, ops):
+    if a is None:
+        continue
+    if op[1] == "render":
+        ok = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        ok = ok and abs(a[3].item() - b[3].item()) <= 1e-12 * max(1.0, abs(a[3].item())) and (a[4] - b[4]).abs().max().item() <= 1e-10 * max(1.0, a[4].abs().max().item())
+    else:
+        ok = abs(a[0].item() - b[0].item()) <= 1e-12 * max(1.0, abs(a[0].item())) and (a[1] - b[1]).abs().max().item() <= 1e-10 * max(1.0, a[1].abs().max().item())
+    bad += not ok
+print("operations", len(ops), "mismatches", bad)
+sys.exit(1 if bad else 0)
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), seed)
+    env = dict(os.environ, DRT_PREFILL_MIN_RAYS="0", DRT_MIN_SUB_LOG2="13")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
