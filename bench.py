@@ -421,7 +421,7 @@ def main():
         torch.cuda.synchronize()
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # (the process group's watchdog thread may query events meanwhile)
                 static_loss = step(False)
             graph.replay()
             torch.cuda.synchronize()
