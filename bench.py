@@ -491,7 +491,7 @@ def main():
                                + ("" if args.distance_factor == 2.5 else f", cameras at {args.distance_factor} extents")
                                + (", no grid verdict cache" if args.no_grid_cache else ""),
                    "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
-                   "final_loss": float(loss.item())},
+                   "final_loss": float(ddist.allreduce_sum_(loss.detach().clone().reshape(1).double()).item())},     # (summed over the ranks: the loss of all views)
     }
     prof_live = scene.optix_mesh.profile_read() if live_profile else None
     scene.optix_mesh.profile_select(None)
