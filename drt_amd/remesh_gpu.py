@@ -63,9 +63,8 @@ class _Work:
         flat = self.F.reshape(-1)
         order = torch.argsort(flat, stable=True)
         vf_face = (order // 3).contiguous()
-        counts = torch.bincount(flat, minlength=self.V.shape[0])
-        vf_start = torch.zeros(self.V.shape[0] + 1, dtype=torch.long, device=self.dev)
-        torch.cumsum(counts, 0, out=vf_start[1:])
+        # (the start of every vertex's run in the sorted list: one search, no histogram -- torch.bincount asks the device for the maximum first)
+        vf_start = torch.searchsorted(flat[order], torch.arange(self.V.shape[0] + 1, device=self.dev))
         return vf_start, vf_face
 
     def vertex_normals(self, vf_start, vf_face):
