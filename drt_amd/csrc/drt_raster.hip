@@ -77,9 +77,11 @@ __device__ __forceinline__ void raster_test(const TriRec& t, f3 o32, const doubl
                                             unsigned long long* __restrict__ zbuf, uint32_t* __restrict__ zmask) {
     const f3 d32 = to_f32(load_d3(dir, i));
     float tt;
-    if (!tri_hit(o32, d32, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, t.margin, tt)) return;
+    // (tri_hit's conditions with the cheap ones first: the barycentric test, "would this key win", and only then the hit-point test)
+    if (!tri_hit_mt(o32, d32, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, tt)) return;
     const unsigned long long key = raster_key(tt, t.face);
     if (key >= zbuf[slot]) return;
+    if (!hit_point_in_box(o32, d32, tt, f3{t.v0x, t.v0y, t.v0z}, f3{t.e1x, t.e1y, t.e1z}, f3{t.e2x, t.e2y, t.e2z}, t.margin)) return;
     atomicMin(&zbuf[slot], key);
     // one bit per 64 consecutive rays: k_cull reads keys only there.  Thousands of hits share a word, and atomics on ONE
     // address are served one at a time: set the bit only when a (possibly stale) read does not show it yet
