@@ -45,6 +45,8 @@ bash tools/profile.sh $P > $O/profile.log 2>&1
 PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 DRT_PREFILL_NEXT=0 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
 # the bench lines LAST, with this build's own counters: bench.py prices k_trace's live launch time against SQ_INSTS_VALU of profiles/pmc.json
 python tools/make_pmc_json.py gpurun_out/$P profiles/pmc.json dropin > /dev/null && cp profiles/pmc.json $O/pmc.json
+# (measured twice: right after the counter passes above the same box runs the step 3 % slower -- 2.40 vs 2.33 ms -- than in a call of its own; let it settle)
+sleep 30
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --mode fused --no-cpu-baseline > $O/bench_fused.json 2> /dev/null
 tail -n 3 $O/configs.txt $O/scaling_proxy.txt $O/iter_bench.txt; python tools/benchsum.py $O/bench.json | head -3
