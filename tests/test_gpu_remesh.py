@@ -199,6 +199,7 @@ def test_device_remesh_on_random_shapes(seed):
         n = np.cross(t2[:, :, 1] - t2[:, :, 0], t2[:, :, 2] - t2[:, :, 0])
         n /= np.linalg.norm(n, axis=2, keepdims=True)
         assert (n[:, 0] * n[:, 1]).sum(1).min() > -0.95
-        assert abs(_volume(dev) / _volume(mesh) - 1) < 0.15
         host = remesh.isotropic_remesh(mesh, L)
         assert abs(len(dev.faces) / len(host.faces) - 1) < 0.08, (len(dev.faces), len(host.faces))
+        # (chords cut corners: an 80-face shape coarsened loses 15 % of its volume -- in both versions alike)
+        assert abs(_volume(dev) / _volume(mesh) - 1) < 0.25 and abs(_volume(dev) / _volume(host) - 1) < 0.03, (_volume(dev) / _volume(mesh), _volume(host) / _volume(mesh))
