@@ -447,7 +447,8 @@ def test_random_image_sizes_and_view_counts(Render, seed):
         rays = [views.generate_ray(h, w, cams[k][3], cams[k][2], device="cuda") for k in rng.integers(0, 72, nv)]
         o = torch.cat([r[0] for r in rays]).contiguous(); d = torch.cat([r[1] for r in rays]).contiguous()
         _check(Render, scene, o, d, w, h)
-        _check(Render, scene, o, d, h, w)                # a wrong hint
+        if w != h:                                       # (the same call again would be a trusting one: face ids of dead rays are then not written)
+            _check(Render, scene, o, d, h, w)            # a wrong hint
 
 
 @pytest.mark.parametrize("seed", range(8))
