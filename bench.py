@@ -402,11 +402,12 @@ def main():
         return O.full_batch_step(scene, local_views, init_vertices, parameter, opt, w_ray, fused=args.mode == "fused")
 
     if args.graph < 0:
-        # Measured per share on one GPU (profiles/r03_scaling_proxy.txt): a replay beats the eager step only where the step is a chain of small
-        # launches -- 9 views: 0.69 vs 0.72 ms; 18: 0.93 vs 0.92; 36: 1.64 vs 1.45 (a replayed graph overlaps the internal streams worse
-        # than eager launches do, and the ahead-of-time fills are not part of a capture).  So: shares below 2^24 camera rays only.
+        # Measured per share on one GPU (profiles/r03_scaling_proxy.txt): a replay beats the eager step where the step is a chain of small
+        # launches -- 9 views: 0.68 vs 0.72 ms; 18: 0.88 vs 0.92; 36: 1.55 vs 1.40 (a replayed graph overlaps the internal streams worse
+        # than eager launches do, and the ahead-of-time fills of calls of >= 2^25 rays are not part of a capture).  So: shares below 2^25
+        # camera rays only.
         # (Not over gloo -- the functional two-ranks-on-one-GPU check: its all-reduce goes through the host and cannot be captured.)
-        small = len(my_views) * P < (1 << 24)
+        small = len(my_views) * P < (1 << 25)
         args.graph = 1 if world > 1 and small and os.environ.get("DRT_BENCH_GRAPH", "1") != "0" and os.environ.get("DRT_DIST_BACKEND") != "gloo" else 0
     graph = None
     if args.graph:
