@@ -30,4 +30,11 @@ for seed in range(first, first + count):
         d = int(((ID.cpu().numpy() != IDo) | (T.cpu().numpy() != To)).sum()); d2 = int((~torch.eq(ID, IDb)).sum())
         print(f"seed {seed}: MISMATCH tree vs oracle {d}, tree vs exhaustive {d2} (tris {len(F)}, scale {scale:.3g})")
 print(f"{count} scenes, {rays_total} rays, {bad} scenes with a mismatch, {time.time() - t0:.0f} s")
+import ctypes
+from drt_amd import _lib
+out = (ctypes.c_int64 * 4)()
+_lib.check(_lib.lib().drt_check_violations(out))
+if out[0] >= 0:                                # a -DDRT_CHECK=1 build (DRT_HIP_LIB): its LDS-stack violation counters
+    print("checked build: stores above the rows / pops of an empty stack / guard rows overwritten / illegal stack at a visit =", list(out))
+    bad += sum(out)
 sys.exit(1 if bad else 0)
