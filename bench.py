@@ -156,7 +156,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
         ms = sum(stages[m]["ms_per_step"] for m in members) * args.steps
         rec = next((pmc[q] for q in PMC_NAMES.get(name, ()) if q in pmc), None)
         out = {"kernel": name, "bound": "valu-issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK / 1e9, 1), "avg_launch_ms": round(ms / max(1, launches), 4),
-               "achieved": None, "frac": None, "valu_instr_per_launch": None, "pmc_stale": pmc_prov["stale"], "pmc": pmc_prov}
+               "achieved": None, "frac": None, "traffic": None, "valu_instr_per_launch": None, "pmc_stale": pmc_prov["stale"], "pmc": pmc_prov}
         # live estimate: wave-steps of one (untimed, statistics-mode) step x the static instruction counts of a wave-step
         ws = [wave_steps[m] for m in members if wave_steps and m in wave_steps]
         est = None
@@ -178,7 +178,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
             out.update(achieved=round(ach / 1e9, 1), frac=round(ach / VALU_PEAK, 4), valu_instr_per_launch=int(rec["SQ_INSTS_VALU"]),
                        valu_busy_quadcycles_per_launch=rec.get("SQ_ACTIVE_INST_VALU"), salu_instr_per_launch=rec.get("SQ_INSTS_SALU"),
                        l2_hit=round(rec["TCC_HIT_sum"] / (rec["TCC_HIT_sum"] + rec["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in rec and "TCC_MISS_sum" in rec else None,
-                       hbm_bytes_per_launch=rec.get("hbm_bytes_per_launch"))
+                       hbm_bytes_per_launch=rec.get("hbm_bytes_per_launch"), traffic=rec.get("hbm_bytes_per_launch"))     # (`traffic`: the contract's name for the PMC bytes)
             if rec.get("SQ_ACTIVE_INST_VALU") and rec.get("GRBM_GUI_ACTIVE"):
                 # share of the launch during which a SIMD's vector ALU is occupied: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
                 # 1024 SIMDs, GRBM_GUI_ACTIVE the launch's cycles summed over the 8 XCDs (both from the serialised PMC passes)
