@@ -13,8 +13,14 @@ int fail(int code, const char* fmt, ...) {
 // Overflow area of the one-thread-per-item queries (B1's redo pass, closest point, silhouette probes): [blocks * kTraceBlock *
 // kStackSlowDev] with blocks = the largest grid that indexes it.  0.35 GB that only those queries ever touch (and only on overflow), so
 // it is allocated by the first of them, not by drt_create: a scene that only renders (a ground-truth scene, most tests) never pays.
-int ensure_slow_stack(drt_scene* s) {
+// hipMalloc synchronises the device and is illegal while a stream is being captured: a first use under capture is refused with a message
+// that says what to do (one eager call of the same entry point before the capture), instead of an opaque capture error.
+int ensure_slow_stack(drt_scene* s, hipStream_t st) {
     if (s->slow_stack) return DRT_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(DRT_E_INVALID, "the first silhouette / closest-point / intersect query of a scene allocates its overflow area and cannot run inside a "
+                                   "stream capture: issue one such call eagerly before capturing");
     int blocks = s->grid_trace;
     if (blocks < 4 * s->n_cu) blocks = 4 * s->n_cu;
     if (blocks < kRedoGrid) blocks = kRedoGrid;

@@ -24,13 +24,14 @@ constexpr uint32_t kOrdPosInf = 0xFF800000u, kOrdNegInf = 0x007FFFFFu;      // f
 
 // float64 -> float32 vertices (Scene.update_verticex, reference DiffRender.py:379) AND, in the same pass, the scene box the Morton keys are
 // normalised with: every block reduces its elements and folds them into six accumulators, so that the build needs no single-block
-// pass over the vertices (k_bounds: 16 us of latency in front of a ~0.15 ms build).  `acc`: this build's accumulators, `acc_next`: the
-// other half, reset here for the NEXT build (the previous build, which read it, has been waited for); `hist_zero`: the digit
-// histograms of the fused sort.
-__global__ void __launch_bounds__(256) k_cast_verts(const double* __restrict__ v64, float* __restrict__ v32, int64_t n3, uint32_t* acc, uint32_t* acc_next,
+// pass over the vertices (k_bounds: 16 us of latency in front of a ~0.15 ms build).  `acc`: the accumulators, found at their identity
+// (+inf / -inf): the build that reads them puts them back (k_hierarchy, two launches behind the last reader k_morton), and the next
+// update waits for that build (begin_update) -- the reset is part of the enqueued work, not of host state, so a captured step
+// replays it (a host-side double buffer did not: every replay folded its vertices into the same half and the box could only grow).
+// `hist_zero`: the digit histograms of the fused sort.
+__global__ void __launch_bounds__(256) k_cast_verts(const double* __restrict__ v64, float* __restrict__ v32, int64_t n3, uint32_t* acc,
                                                     uint32_t* __restrict__ hist_zero, int hist_entries) {
     __shared__ float red[6][4];
-    if (blockIdx.x == 0 && threadIdx.x < 6 && acc_next) acc_next[threadIdx.x] = threadIdx.x < 3 ? kOrdPosInf : kOrdNegInf;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hist_entries; i += (int64_t)gridDim.x * blockDim.x) hist_zero[i] = 0u;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     // a thread takes whole vertices (three consecutive values), so that its three running bounds are per axis
@@ -212,9 +213,10 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_pass_fused(const uint32_t* 
 // ---- hierarchy ---------------------------------------------------------------------------
 __global__ void k_hierarchy(const uint32_t* __restrict__ keys, int n, Node* __restrict__ nodes,
                             int32_t* __restrict__ parent_inner, int32_t* __restrict__ parent_leaf,
-                            uint32_t* __restrict__ flags, int32_t* __restrict__ range_lo, int32_t* __restrict__ range_hi) {
+                            uint32_t* __restrict__ flags, int32_t* __restrict__ range_lo, int32_t* __restrict__ range_hi, uint32_t* acc_reset) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) parent_inner[0] = -1;
+    if (acc_reset && i < 6) acc_reset[i] = i < 3 ? kOrdPosInf : kOrdNegInf;      // k_cast_verts' scene-box accumulators: read by k_tri_flat and k_morton, both done
     if (n == 1) {   // degenerate: one triangle under a root whose second child is an empty box
         if (i == 0) {
             Node nd;
@@ -430,7 +432,7 @@ static int rebuild_impl(drt_scene* s, hipStream_t st, const uint32_t* acc) {
     }
     // (four passes end in buffer 0, three in buffer 1)
     const int inner = n > 1 ? n - 1 : 1;
-    k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags, s->range_lo, s->range_hi);
+    k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags, s->range_lo, s->range_hi, const_cast<uint32_t*>(acc));
     k_refit<<<(n + 255) / 256, 256, 0, st>>>(s->idx[cur], s->faces, s->verts, n, s->params, s->tris, s->nodes,
                                              s->parent_inner, s->parent_leaf, s->flags);
     k_collapse4<<<(inner + 255) / 256, 256, 0, st>>>(s->nodes, s->parent_inner, s->range_lo, s->range_hi, n, s->wide);
@@ -545,11 +547,9 @@ int drt_update_vert_f64(drt_scene_t* s, const double* d_verts, int64_t n_verts, 
         // the cast also gathers the scene box and zeroes the fused sort's histograms (both otherwise k_bounds' job, a single-block kernel)
         const int tiles = (int)((s->n_faces + kSortTile - 1) / kSortTile);
         const bool fused_sort = s->n_faces > 0 && tiles <= kSortFusedTiles;
-        uint32_t* mine = s->bounds_acc + 6 * s->bounds_par;
-        k_cast_verts<<<grid_for(n_verts, 256, 256), 256, 0, st>>>(d_verts, s->verts, 3 * n_verts, mine, s->bounds_acc + 6 * (s->bounds_par ^ 1),
+        acc = s->n_faces > 0 ? s->bounds_acc : nullptr;       // (no faces: no build that would read the box and put the accumulators back)
+        k_cast_verts<<<grid_for(n_verts, 256, 256), 256, 0, st>>>(d_verts, s->verts, 3 * n_verts, const_cast<uint32_t*>(acc),
                                                                  s->hist, fused_sort ? 4 * kRadix * tiles : 0);
-        s->bounds_par ^= 1;
-        acc = mine;
     }
     return rebuild(s, st, acc);
 }

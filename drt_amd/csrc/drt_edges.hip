@@ -285,7 +285,7 @@ int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t
     if (n_edges == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_camera || !d_origin3 || !d_index || !d_f) return fail(DRT_E_INVALID, "null pointer argument");
     { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
-    { int rc = ensure_slow_stack(s); if (rc) return rc; }
+    { int rc = ensure_slow_stack(s, (hipStream_t)stream); if (rc) return rc; }
     k_edge_sample_fwd<<<grid_for(2 * n_edges, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(
         trace_ctx(s), d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_origin3, d_index, d_f, d_keep, resx, resy, d_flags);
     HIP_TRY(hipGetLastError());
@@ -343,7 +343,7 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
     if (n_edges == 0 || n_views == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_e2f || !d_cameras || !d_origins || !d_soft_masks || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    { int rc = ensure_slow_stack(s); if (rc) return rc; }
+    { int rc = ensure_slow_stack(s, (hipStream_t)stream); if (rc) return rc; }
     const int64_t need = n_edges * std::min(kVhViews, n_views);
     if (need > s->vh_cap) {
         (void)hipFree(s->vh_list); s->vh_list = nullptr; s->vh_cap = 0;

@@ -88,8 +88,7 @@ struct drt_scene {
     bool build_pending = false;    // a build was enqueued on build_stream: consumers of the tree wait for build_done
     bool order_valid = false;      // idx[sorted_buf] holds the Morton order of the last build over the CURRENT faces (k_tri_flat's order)
     int sorted_buf = 0;            // which of keys[] / idx[] the last sort ended in (three radix passes end in 1, four in 0)
-    uint32_t* bounds_acc = nullptr;  // [2][6] scene-box accumulators of drt_update_vert_f64's cast kernel (order-preserving uint encodings; double-buffered)
-    int bounds_par = 0;            // which half the NEXT cast accumulates into (the other one is reset by it)
+    uint32_t* bounds_acc = nullptr;  // [6] scene-box accumulators of drt_update_vert_f64's cast kernel (order-preserving uint encodings; put back to +-inf by the build that read them)
     bool async_build = true;       // DRT_ASYNC_BUILD=0: build on the caller's stream
     uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
     uint32_t* hist = nullptr;      // [kRadix * tiles]
@@ -188,7 +187,7 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
                   ViewModel* trusted);
 
 // defined in drt_api.hip
-int ensure_slow_stack(drt_scene* s);
+int ensure_slow_stack(drt_scene* s, hipStream_t st);
 // -DDRT_CHECK=1: the stack-invariant counters of the two translation units that instantiate the traversal kernels
 int check_counters_pipeline(unsigned long long* out4);
 int check_counters_trace(unsigned long long* out4);

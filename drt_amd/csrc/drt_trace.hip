@@ -89,7 +89,7 @@ static int b1_query(drt_scene* s, const float* d_rays, int64_t n_rays, float* d_
         s->b1_cap = n_rays;
     }
     if (!s->b1_count) HIP_TRY(hipMalloc(&s->b1_count, sizeof(unsigned) * 2));
-    { int rc = ensure_slow_stack(s); if (rc) return rc; }
+    { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(s->b1_count, 0, sizeof(unsigned) * 2, st));
     const TraceCtx tc = trace_ctx(s);
     const TraceOut out{d_ID, d_T, d_hit, s->b1_list};
@@ -132,7 +132,7 @@ int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double*
     if (n == 0) return DRT_OK;
     if (!d_points || !d_dist) return fail(DRT_E_INVALID, "null pointer argument");
     { int rc = wait_build(s, (hipStream_t)stream); if (rc) return rc; }
-    { int rc = ensure_slow_stack(s); if (rc) return rc; }
+    { int rc = ensure_slow_stack(s, (hipStream_t)stream); if (rc) return rc; }
     k_closest_point<<<grid_for(n, kTraceBlock, s->grid_trace), kTraceBlock, 0, (hipStream_t)stream>>>(trace_ctx(s), s->faces, s->verts, d_points, n, d_dist, d_face, d_closest);
     HIP_TRY(hipGetLastError());
     return DRT_OK;

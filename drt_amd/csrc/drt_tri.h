@@ -38,16 +38,23 @@ DRT_HD TriRec make_tri(f3 a, f3 b, f3 c, int32_t face, float margin) {
     return r;
 }
 
-// Returns true and sets t on a hit.
-// The hit point in the triangle's own frame, r = (o - v0) + t d, inside the box of (0, e1, e2) grown by margin: one rounding per
-// operation, like the rest.
+// The hit point in the triangle's own frame, r = (o - v0) + t d, inside the box of (0, e1, e2) grown by
+//     m = max(margin, 2^-18 * max|o - v0|),
+// one rounding per operation, like the rest (oracle/hit_point.h is the same expression).  The second term lets the tolerance grow with
+// the distance between the ray's origin and the triangle, as the float32 error of the reconstructed point does (about 1e-6 of the
+// ray's length for a well-conditioned t): it takes over from 16 scene extents on, so a camera hundreds of extents away -- or a small
+// object in a large scene box -- keeps its legitimate hits.  Up to 16 extents an accepted hit lies inside its leaf's box by
+// construction (above); beyond, only a ray inside a triangle's plane can still be accepted by the exhaustive test with a point the
+// tree's padding does not cover.
 DRT_HD bool hit_point_in_box(f3 o, f3 d, float t, f3 v0, f3 e1, f3 e2, float margin) {
-    const float rx = (o.x - v0.x) + t * d.x;
-    bool in = (rx + margin >= fminf(0.0f, fminf(e1.x, e2.x))) & (rx - margin <= fmaxf(0.0f, fmaxf(e1.x, e2.x)));
-    const float ry = (o.y - v0.y) + t * d.y;
-    in &= (ry + margin >= fminf(0.0f, fminf(e1.y, e2.y))) & (ry - margin <= fmaxf(0.0f, fmaxf(e1.y, e2.y)));
-    const float rz = (o.z - v0.z) + t * d.z;
-    in &= (rz + margin >= fminf(0.0f, fminf(e1.z, e2.z))) & (rz - margin <= fmaxf(0.0f, fmaxf(e1.z, e2.z)));
+    const f3 s = o - v0;
+    const float m = fmaxf(margin, fmaxf(fabsf(s.x), fmaxf(fabsf(s.y), fabsf(s.z))) * 0x1p-18f);
+    const float rx = s.x + t * d.x;
+    bool in = (rx + m >= fminf(0.0f, fminf(e1.x, e2.x))) & (rx - m <= fmaxf(0.0f, fmaxf(e1.x, e2.x)));
+    const float ry = s.y + t * d.y;
+    in &= (ry + m >= fminf(0.0f, fminf(e1.y, e2.y))) & (ry - m <= fmaxf(0.0f, fmaxf(e1.y, e2.y)));
+    const float rz = s.z + t * d.z;
+    in &= (rz + m >= fminf(0.0f, fminf(e1.z, e2.z))) & (rz - m <= fmaxf(0.0f, fmaxf(e1.z, e2.z)));
     return in;
 }
 

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "hit_point.h"
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -89,13 +90,8 @@ static int tri_hit(const bvh_t *b, int32_t f, const float o[3], const float d[3]
     const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
     *t_out = t;
     if (!((u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f))) return 0;
-    /* the hit-point test of tracer.c (same operations, same margin) */
-    const float m = b->margin;
-    const float hx = o[0] + t * d[0], hy = o[1] + t * d[1], hz = o[2] + t * d[2];
-    const float bx = v0[0] + e1x, by = v0[1] + e1y, bz = v0[2] + e1z, cx = v0[0] + e2x, cy = v0[1] + e2y, cz = v0[2] + e2z;
-    return (hx >= fminf(v0[0], fminf(bx, cx)) - m) & (hx <= fmaxf(v0[0], fmaxf(bx, cx)) + m) &
-           (hy >= fminf(v0[1], fminf(by, cy)) - m) & (hy <= fmaxf(v0[1], fmaxf(by, cy)) + m) &
-           (hz >= fminf(v0[2], fminf(bz, cz)) - m) & (hz <= fmaxf(v0[2], fmaxf(bz, cz)) + m);
+    /* the hit-point test of tracer.c (hit_point.h: same operations, same margin) */
+    return oracle_hit_point_in_box(o[0], o[1], o[2], d[0], d[1], d[2], t, v0[0], v0[1], v0[2], e1x, e1y, e1z, e2x, e2y, e2z, b->margin);
 }
 
 int oracle_trace_closest_bvh(const int32_t *faces, int64_t n_faces, const float *verts, int64_t n_verts,

@@ -19,10 +19,13 @@
  *     s = o - v0, u = (s . p) * inv, q = s x e1, v = (d . q) * inv, t = (e2 . q) * inv
  *     dot(a,b) = (a0*b0 + a1*b1) + a2*b2 ; cross(a,b) = (a1*b2 - a2*b1, a2*b0 - a0*b2, a0*b1 - a1*b0)
  *     hit  <=>  u >= 0 && v >= 0 && u + v <= 1 && t > 0      (NaN/inf from det == 0 fail the tests)
- *               && the hit point (ox + t*dx, ...) lies in the box of (v0, v0 + e1, v0 + e2) grown by `margin`
+ *               && the hit point, in the triangle's frame r = (o - v0) + t*d, lies in the box of (0, e1, e2) grown by
+ *                  m = max(margin, 2^-18 * max|o - v0|)                                  (hit_point.h: the exact expression)
  *     margin = 0.5 * (largest extent of the box of ALL vertices) / 8192   (float32; the product's drt_tri.h / drt_lbvh.h state why:
  *     a ray inside a triangle's plane has det = rounding noise and can pass the first four tests anywhere along itself; the fifth
  *     keeps "closest hit over every face" something that does not depend on which faces an acceleration structure visits)
+ * The four inequalities run in the vectorised block loop; the fifth is applied in the scalar reduction, only to a candidate that
+ * would become the new closest hit (a candidate that fails it is skipped, exactly as if it had failed in the block loop).
  * Closest hit = minimum t; equal t -> lowest face id.  Miss -> T = -1, ID = -1.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
@@ -34,6 +37,8 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+#include "hit_point.h"
 
 #define BLK 512
 
@@ -59,10 +64,10 @@ float oracle_hit_margin(const float *verts, int64_t n_verts) {
     return 0.5f * (fmaxf(ex, fmaxf(ey, ez)) * (1.0f / 8192.0f));
 }
 
-/* t of the hit of one ray against triangles [j0, j1), +inf where there is no hit. */
+/* t of one ray against triangles [j0, j1) where the four inequalities hold, +inf elsewhere (the fifth condition: the caller). */
 __attribute__((target_clones("avx2", "default")))
 static void block_t(const soa_t *s, int64_t j0, int64_t j1,
-                    float ox, float oy, float oz, float dx, float dy, float dz, float margin, float *tt) {
+                    float ox, float oy, float oz, float dx, float dy, float dz, float *tt) {
     for (int64_t j = j0; j < j1; ++j) {
         const float e1x = s->e1x[j], e1y = s->e1y[j], e1z = s->e1z[j];
         const float e2x = s->e2x[j], e2y = s->e2y[j], e2z = s->e2z[j];
@@ -78,13 +83,7 @@ static void block_t(const soa_t *s, int64_t j0, int64_t j1,
         const float qz = sx * e1y - sy * e1x;
         const float v = ((dx * qx + dy * qy) + dz * qz) * inv;
         const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
-        const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
-        const float ax = s->v0x[j], ay = s->v0y[j], az = s->v0z[j];
-        const float bx = ax + e1x, by = ay + e1y, bz = az + e1z, cx = ax + e2x, cy = ay + e2y, cz = az + e2z;
-        const int inbox = (hx >= fminf(ax, fminf(bx, cx)) - margin) & (hx <= fmaxf(ax, fmaxf(bx, cx)) + margin) &
-                          (hy >= fminf(ay, fminf(by, cy)) - margin) & (hy <= fmaxf(ay, fmaxf(by, cy)) + margin) &
-                          (hz >= fminf(az, fminf(bz, cz)) - margin) & (hz <= fmaxf(az, fmaxf(bz, cz)) + margin);
-        const int hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f) & inbox;
+        const int hit = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f);
         tt[j - j0] = hit ? t : INFINITY;
     }
 }
@@ -114,9 +113,13 @@ int oracle_trace_closest(const int32_t *faces, int64_t n_faces, const float *ver
         int32_t best_id = -1;
         for (int64_t j0 = 0; j0 < n_faces; j0 += BLK) {
             const int64_t j1 = j0 + BLK < n_faces ? j0 + BLK : n_faces;
-            block_t(&s, j0, j1, r[0], r[1], r[2], r[3], r[4], r[5], margin, tt);
+            block_t(&s, j0, j1, r[0], r[1], r[2], r[3], r[4], r[5], tt);
             for (int64_t j = j0; j < j1; ++j) {
-                if (tt[j - j0] < best) { best = tt[j - j0]; best_id = (int32_t)j; }
+                if (tt[j - j0] < best &&
+                    oracle_hit_point_in_box(r[0], r[1], r[2], r[3], r[4], r[5], tt[j - j0], s.v0x[j], s.v0y[j], s.v0z[j],
+                                            s.e1x[j], s.e1y[j], s.e1z[j], s.e2x[j], s.e2y[j], s.e2z[j], margin)) {
+                    best = tt[j - j0]; best_id = (int32_t)j;
+                }
             }
         }
         T[i] = best_id >= 0 ? best : -1.0f;
