@@ -584,5 +584,16 @@ int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream) {
     return DRT_OK;
 }
 
+int drt_build_params(drt_scene_t* s, float* out7, void* stream) {
+    CHECK_BUILT(s);
+    if (!out7) return fail(DRT_E_INVALID, "out7 is null");
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = wait_build(s, st); if (rc) return rc; }
+    BuildParams bp;
+    HIP_TRY(hipMemcpyAsync(&bp, s->params, sizeof(bp), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    out7[0] = bp.lox; out7[1] = bp.loy; out7[2] = bp.loz; out7[3] = bp.ix; out7[4] = bp.iy; out7[5] = bp.iz; out7[6] = bp.pad;
+    return DRT_OK;
+}
 
 }  // extern "C"

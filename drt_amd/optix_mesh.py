@@ -149,6 +149,13 @@ class optix_mesh:
         self.wide_depth = wide.value
         return v.value, hgt.value
 
+    def build_params(self):
+        """(lo[3], 1/extent[3], leaf padding) of the scene box the last build derived from the vertices; synchronises."""
+        out = (ctypes.c_float * 7)()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().drt_build_params(self._h, out, _stream()))
+        return list(out)
+
     def sorted_faces(self):
         out = torch.empty(self.n_faces, dtype=torch.int32, device=f"cuda:{self.device}")
         with torch.cuda.device(self.device):

@@ -73,6 +73,9 @@ int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays
 int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height, int32_t* wide_depth);
 /* Diagnostic: copy the Morton-sorted face order (int32 [F]) to d_order. */
 int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
+/* Diagnostic: the scene box the last build derived from the vertices -- out7 = lo[3], 1/extent[3], leaf padding (float32; the margin of
+ * the hit-point test is half the padding); host-synchronising.  What a replayed capture of an update must reproduce. */
+int drt_build_params(drt_scene_t* s, float* out7, void* stream);
 
 /* ---- B2: Scene.render_transparent, DiffRender.py:420-432 (trace2 :537-546, Dintersect
  * :492-501, refract_ray :503-535) -------------------------------------------------------

@@ -51,8 +51,7 @@ def _tracer_lib():
     if _LIB is not None:
         return _LIB
     so = os.path.join(_HERE, "_build", "liboracle_tracer.so")
-    src = os.path.join(_HERE, "tracer.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "bvh_tracer.c"))):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("tracer.c", "bvh_tracer.c", "hit_point.h")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     lib = ctypes.CDLL(so)
     lib.oracle_trace_closest.restype = ctypes.c_int
@@ -60,6 +59,8 @@ def _tracer_lib():
                                          ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     lib.oracle_trace_closest_bvh.restype = ctypes.c_int
     lib.oracle_trace_closest_bvh.argtypes = lib.oracle_trace_closest.argtypes
+    lib.oracle_trace_closest_mt_only.restype = ctypes.c_int
+    lib.oracle_trace_closest_mt_only.argtypes = lib.oracle_trace_closest.argtypes
     lib.oracle_num_threads.restype = ctypes.c_int
     _LIB = lib
     return lib
@@ -80,8 +81,9 @@ TORCH_THREADS = None   # restored after every tracer call when TRACER_THREADS is
 USE_BVH = False      # bench.py's second cpu_baseline figure flips this: same contract, tree instead of the loop over every face
 
 
-def trace_closest(faces_i32, verts_f32, rays_f32, bvh=None):
-    """Closest hit (brute force; oracle/bvh_tracer.c when ``bvh``/USE_BVH). faces i32 [F,3], verts f32 [V,3], rays f32 [N,6] -> (T f32 [N], ID i32 [N])."""
+def trace_closest(faces_i32, verts_f32, rays_f32, bvh=None, mt_only=False):
+    """Closest hit (brute force; oracle/bvh_tracer.c when ``bvh``/USE_BVH). faces i32 [F,3], verts f32 [V,3], rays f32 [N,6] -> (T f32 [N], ID i32 [N]).
+    ``mt_only``: the four inequalities without the hit-point condition (not the contract: the far-camera tests' comparison)."""
     faces = np.ascontiguousarray(faces_i32, dtype=np.int32)
     verts = np.ascontiguousarray(verts_f32, dtype=np.float32)
     rays = np.ascontiguousarray(rays_f32, dtype=np.float32)
@@ -90,6 +92,8 @@ def trace_closest(faces_i32, verts_f32, rays_f32, bvh=None):
     ID = np.empty(n, dtype=np.int32)
     if n:
         fn = _tracer_lib().oracle_trace_closest_bvh if (USE_BVH if bvh is None else bvh) else _tracer_lib().oracle_trace_closest
+        if mt_only:
+            fn = _tracer_lib().oracle_trace_closest_mt_only
         if TRACER_THREADS:
             # PyTorch and this library may share one OpenMP runtime (one thread-count setting): the C tracer scales to every
             # core, PyTorch's small float64 ops collapse with 256 threads (30 s instead of 0.14 s for a 512x512 view)

@@ -92,8 +92,8 @@ static void block_t(const soa_t *s, int64_t j0, int64_t j1,
  * faces i32 [F,3], verts f32 [V,3], rays f32 [N,6] (ox,oy,oz,dx,dy,dz) -> T f32 [N], ID i32 [N].
  * Returns 0, or -1 on allocation failure.
  */
-int oracle_trace_closest(const int32_t *faces, int64_t n_faces, const float *verts, int64_t n_verts,
-                         const float *rays, int64_t n_rays, float *T, int32_t *ID) {
+static int trace_closest(const int32_t *faces, int64_t n_faces, const float *verts, int64_t n_verts,
+                         const float *rays, int64_t n_rays, float *T, int32_t *ID, int fifth) {
     const float margin = oracle_hit_margin(verts, n_verts);
     soa_t s;
     if (soa_alloc(&s, n_faces) != 0) return -1;
@@ -116,8 +116,8 @@ int oracle_trace_closest(const int32_t *faces, int64_t n_faces, const float *ver
             block_t(&s, j0, j1, r[0], r[1], r[2], r[3], r[4], r[5], tt);
             for (int64_t j = j0; j < j1; ++j) {
                 if (tt[j - j0] < best &&
-                    oracle_hit_point_in_box(r[0], r[1], r[2], r[3], r[4], r[5], tt[j - j0], s.v0x[j], s.v0y[j], s.v0z[j],
-                                            s.e1x[j], s.e1y[j], s.e1z[j], s.e2x[j], s.e2y[j], s.e2z[j], margin)) {
+                    (!fifth || oracle_hit_point_in_box(r[0], r[1], r[2], r[3], r[4], r[5], tt[j - j0], s.v0x[j], s.v0y[j], s.v0z[j],
+                                            s.e1x[j], s.e1y[j], s.e1z[j], s.e2x[j], s.e2y[j], s.e2z[j], margin))) {
                     best = tt[j - j0]; best_id = (int32_t)j;
                 }
             }
@@ -127,6 +127,18 @@ int oracle_trace_closest(const int32_t *faces, int64_t n_faces, const float *ver
     }
     free(s.v0x);
     return 0;
+}
+
+int oracle_trace_closest(const int32_t *faces, int64_t n_faces, const float *verts, int64_t n_verts,
+                         const float *rays, int64_t n_rays, float *T, int32_t *ID) {
+    return trace_closest(faces, n_faces, verts, n_verts, rays, n_rays, T, ID, 1);
+}
+
+/* The four inequalities alone, no hit-point condition: NOT the contract -- what the far-camera tests compare it with, to show that
+ * the fifth condition keeps every well-conditioned hit of a ray that starts hundreds of extents away. */
+int oracle_trace_closest_mt_only(const int32_t *faces, int64_t n_faces, const float *verts, int64_t n_verts,
+                                 const float *rays, int64_t n_rays, float *T, int32_t *ID) {
+    return trace_closest(faces, n_faces, verts, n_verts, rays, n_rays, T, ID, 0);
 }
 
 int oracle_num_threads(void) {

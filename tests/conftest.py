@@ -100,13 +100,45 @@ def fixture_view(g):
     o, d = views.generate_ray(res, res, g["Kinv"], g["Rinv"])
     rng = np.random.default_rng(int(g["target_seed"]))
     P = res * res
-    center, _ = mesh_frame_hand()
+    center = fixture_frame(g)[0]
     sp = rng.standard_normal((P, 3)) * 40.0 + np.asarray(center) + np.array([0.0, 0.0, 150.0])
     valid = rng.random(P) > 0.1
     return o, d, torch.tensor(sp), torch.tensor(valid)
 
 
 _frame = {}
+_mesh = {}
+HEADLINE_FIXTURE = "horse50k_r256_v11"      # the reference's own Python on BASELINE.json's ~50k-triangle mesh (make_golden.py horse)
+
+
+def fixture_mesh(g):
+    """The mesh a render fixture was made on: hand_vh.ply, or -- fixtures that carry `mesh_sha256` -- horse_vh.ply after one midpoint
+    subdivision (50 248 triangles), rebuilt here exactly as make_golden.py built it and checked against the fixture's hash."""
+    from drt_amd import mesh_io
+    key = "horse" if "mesh_sha256" in g.files else "hand"
+    if key not in _mesh:
+        if key == "hand":
+            _mesh[key] = mesh_io.read_ply(data_path("hand_vh.ply"))
+        else:
+            import hashlib
+            import tempfile
+            hull = mesh_io.subdivide_midpoint(mesh_io.read_ply(data_path("horse_vh.ply")))
+            with tempfile.TemporaryDirectory() as tmp:
+                f = os.path.join(tmp, "horse_x4.ply")
+                mesh_io.write_ply(f, hull.vertices, hull.faces)
+                m = mesh_io.read_ply(f)
+            sha = hashlib.sha256(np.ascontiguousarray(m.vertices, np.float64).tobytes() + np.ascontiguousarray(m.faces, np.int64).tobytes()).hexdigest()
+            assert sha == str(g["mesh_sha256"]) and len(m.faces) == int(g["n_faces"]) == 50248
+            _mesh[key] = m
+    return _mesh[key]
+
+
+def fixture_frame(g):
+    from drt_amd import views
+    key = "horse" if "mesh_sha256" in g.files else "hand"
+    if key not in _frame:
+        _frame[key] = views.mesh_frame(fixture_mesh(g).vertices)
+    return _frame[key]
 
 
 def mesh_frame_hand():

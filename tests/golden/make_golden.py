@@ -416,6 +416,28 @@ def degenerate_fixture(DR, optim, mesh, center, extent):
           "NaN grad_sm rows", int(np.isnan(rec["grad_sm"]).any(axis=1).sum()), "sil", len(sil), "vh", vh.item(), "valid", len(vi), loss_str)
 
 
+def horse_fixture(DR, optim):
+    """The HEADLINE mesh (BASELINE.json's ~50k-triangle workload: horse_vh.ply after one midpoint subdivision = 50 248 triangles,
+    25 126 vertices), one view at 256x256, through the reference's own Python: per-bounce ids and terms, outputs, ray_loss and its
+    gradient, the silhouette branch.  The subdivided hull is written to a temporary PLY for the reference's Scene(path)."""
+    import hashlib
+    import tempfile
+    hull = mesh_io.subdivide_midpoint(mesh_io.read_ply(os.path.join(REPO, "data", "horse_vh.ply")))
+    center, extent = views.mesh_frame(hull.vertices)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "horse_x4.ply")
+        mesh_io.write_ply(path, hull.vertices, hull.faces)
+        mesh = mesh_io.read_ply(path)            # (float32 on disk: what Scene(path) sees)
+        scene = DR.Scene(path)
+        render_fixture(DR, optim, scene, mesh, center, extent, 256, 11, "horse50k_r256_v11")
+    f = os.path.join(OUT, "horse50k_r256_v11.npz")
+    rec = dict(np.load(f))
+    rec.update(n_faces=len(mesh.faces), n_vertices=len(mesh.vertices),
+               mesh_sha256=hashlib.sha256(np.ascontiguousarray(mesh.vertices, np.float64).tobytes() + np.ascontiguousarray(mesh.faces, np.int64).tobytes()).hexdigest())
+    np.savez_compressed(f, **rec)
+    print("horse fixture:", rec["n_faces"], "faces,", os.path.getsize(f), "bytes")
+
+
 def main():
     torch.manual_seed(0)
     np.random.seed(0)
@@ -427,6 +449,8 @@ def main():
     only = set(sys.argv[1:])                 # e.g. `make_golden.py degenerate`: regenerate one family of fixtures
     if only == {"degenerate"}:
         return degenerate_fixture(DR, optim, mesh, center, extent)
+    if only == {"horse"}:
+        return horse_fixture(DR, optim)
     scene = DR.Scene(path)
     np.savez_compressed(os.path.join(OUT, "hand_topology.npz"), Edges=scene.Edges.numpy(), E2F=scene.E2F.numpy(),
                         mean_len=scene.mean_len, n_vertices=len(mesh.vertices), n_faces=len(mesh.faces))
@@ -436,6 +460,7 @@ def main():
             render_fixture(DR, optim, scene, mesh, center, extent, res, view_id, f"hand_r{res}_v{view_id}")
     smooth_fixture(DR, optim, scene, mesh, center, extent)
     degenerate_fixture(DR, optim, mesh, center, extent)
+    horse_fixture(DR, optim)
 
 
 if __name__ == "__main__":

@@ -199,3 +199,66 @@ def test_rccl_step_with_one_rank_per_gpu(tmp_path, graph):
     if ref is not None:      # one rank: the same three views in one call as _graph_run -> same numbers up to the order of the atomics
         scale = np.abs(ref).max()
         assert np.abs(r[0]["param"] - ref).max() <= 1e-11 * scale
+
+
+def test_a_replayed_update_rebuilds_the_scene_box_from_the_vertices_of_the_replay():
+    """A captured `update_verticex` must gather the scene box from the vertices present at REPLAY time: the reset of the box
+    accumulators is enqueued work (a kernel of the build puts them back), not host state.  The mesh shrinks between the replays; the box
+    and the leaf padding of every replay equal those of an eager update with the same vertices (a box that can only grow -- what a
+    host-side double buffer gave -- fails at the second replay)."""
+    from drt_amd import diffrender as Render, mesh_io
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene, ref = Render.Scene(mesh, 0), Render.Scene(mesh, 0)
+    v0 = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda")
+    c = v0.mean(0)
+    static = v0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            scene.update_verticex(static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        scene.update_verticex(static)
+    pads = []
+    for scale in (1.0, 3.0, 0.5, 0.1, 0.7):              # grows once, then shrinks well below the first box
+        static.copy_(c + (v0 - c) * scale)
+        g.replay()
+        torch.cuda.synchronize()
+        got = scene.optix_mesh.build_params()
+        ref.update_verticex(static.clone())
+        want = ref.optix_mesh.build_params()
+        assert got == want, (scale, got, want)
+        assert scene.optix_mesh.check()[0] == 0
+        pads.append(got[6])
+    assert pads[3] < 0.2 * pads[0] < pads[1]
+
+
+def test_first_overflow_area_use_under_capture_is_refused_with_a_message():
+    """The overflow area of the one-thread-per-item queries is allocated by their first call; under stream capture that call is refused
+    with a message that says what to do, and works after one eager call."""
+    from drt_amd import diffrender as Render, mesh_io
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    scene = Render.Scene(mesh, 0)
+    pts = torch.tensor(mesh.vertices[:64], dtype=torch.float64, device="cuda") + 1.0
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="eagerly before capturing"):
+        with torch.cuda.graph(g):
+            scene.optix_mesh.closest_point(pts)
+    torch.cuda.synchronize()
+    eager = scene.optix_mesh.closest_point(pts)[0].clone()
+    g2 = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        scene.optix_mesh.closest_point(pts)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g2):
+        out = scene.optix_mesh.closest_point(pts)[0]
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)

@@ -123,6 +123,42 @@ def test_random_meshes_and_adversarial_rays_bit_exact(seed):
     assert np.array_equal(ID2.cpu().numpy(), IDo2) and np.array_equal(T2.cpu().numpy(), To2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("distance_factor", [20.0, 100.0, 1000.0])
+def test_far_camera_keeps_its_hits(distance_factor):
+    """A camera tens to a thousand extents away (focal length grown with the distance): tree == exhaustive test on the GPU ==
+    oracle, and none of the hits of the four inequalities alone is lost to the hit-point condition, whose tolerance grows with the
+    ray (drt_tri.h::hit_point_in_box); then the same camera through the whole path (projection pass included)."""
+    from conftest import IOR, data_path
+    from test_oracle_golden import far_camera_rays
+    from drt_amd import diffrender as Render, mesh_io, views
+    from drt_amd.optix_mesh import optix_mesh
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    F, V = mesh.faces.astype(np.int32), mesh.vertices.astype(np.float32)
+    rays = far_camera_rays(mesh, distance_factor, res=128)
+    t = optix_mesh(0)
+    t.update_mesh(torch.tensor(F, device="cuda"), torch.tensor(V, device="cuda"))
+    R = torch.tensor(rays, device="cuda")
+    T, ID = t.intersect(R)
+    Tb, IDb = t.intersect_bruteforce(R)
+    To, IDo = orc.trace_closest(F, V, rays)
+    T0, ID0 = orc.trace_closest(F, V, rays, mt_only=True)
+    assert (IDo >= 0).sum() > 1000
+    assert np.array_equal(IDo, ID0) and np.array_equal(To, T0)
+    assert np.array_equal(IDb.cpu().numpy(), IDo) and np.array_equal(Tb.cpu().numpy(), To)
+    assert np.array_equal(ID.cpu().numpy(), IDo) and np.array_equal(T.cpu().numpy(), To)
+    # the whole path from the same camera: mask and exit rays against the oracle
+    Render.intIOR = IOR
+    sc = Render.Scene(mesh, 0)
+    o, d = torch.tensor(rays[:, :3], dtype=torch.float64), torch.tensor(rays[:, 3:], dtype=torch.float64)
+    d = d / d.norm(dim=1, keepdim=True)
+    oo, od, mk = sc.render_transparent(o.cuda(), d.cuda())
+    om = orc.Mesh(mesh.faces, torch.tensor(mesh.vertices, dtype=torch.float64))
+    ro, rd, rm = orc.render_transparent(om, o, d, IOR)
+    assert torch.equal(mk.cpu(), rm) and rm[:, 0].sum() > 300
+    assert torch.allclose(od.cpu(), rd, atol=1e-9, rtol=0) and torch.allclose(oo.cpu(), ro, atol=1e-9 * distance_factor, rtol=0)
+
+
 def _shape(rng, noises=(0.0, 0.05, 0.2)):
     """A random closed surface: a noisy, anisotropically scaled icosphere (star-shaped, with creases and near-tangent facets), sometimes
     two of them merged into one mesh (an inner and an outer shell, or two lobes side by side: rays leave one and enter the other)."""

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import IOR, data_path, fixture_view, golden
+from conftest import HEADLINE_FIXTURE, IOR, data_path, fixture_mesh, fixture_view, golden
 from drt_amd import mesh_io, views
 from oracle import diffrender_oracle as orc
 
@@ -46,9 +46,10 @@ def test_unit_tables():
     close(u, g["mt_u"]); close(v, g["mt_v"]); close(t, g["mt_t"]); close(n, g["mt_n"])
 
 
-@pytest.mark.parametrize("name", FIXTURES)
-def test_render_path(hand, name):
+@pytest.mark.parametrize("name", FIXTURES + [HEADLINE_FIXTURE])
+def test_render_path(name):
     g = golden(name)
+    hand = fixture_mesh(g)            # (the headline fixture: horse_vh x4, 50 248 triangles)
     o, d, sp, valid = fixture_view(g)
     V = torch.tensor(hand.vertices, dtype=torch.float64, requires_grad=True)
     mesh = orc.Mesh(hand.faces, V)
@@ -90,10 +91,15 @@ def test_render_path(hand, name):
     close(g_lin, g["grad_lin"], rtol=1e-9, atol=1e-11 * np.abs(g["grad_lin"]).max())
 
 
-@pytest.mark.parametrize("name", FIXTURES)
-def test_silhouette_branch(hand, name):
+@pytest.mark.parametrize("name", FIXTURES + [HEADLINE_FIXTURE])
+def test_silhouette_branch(name):
     g = golden(name)
-    topo = golden("hand_topology")
+    hand = fixture_mesh(g)
+    if name == HEADLINE_FIXTURE:      # (edge tables: mesh_io's, pinned to the reference's on the hand hull by test_topology_tables)
+        e, e2f, _ = mesh_io.edge_tables(hand)
+        topo = {"Edges": e, "E2F": e2f}
+    else:
+        topo = golden("hand_topology")
     res = int(g["res"])
     o, d, _, _ = fixture_view(g)
     V = torch.tensor(hand.vertices, dtype=torch.float64, requires_grad=True)
@@ -205,6 +211,30 @@ def test_tracer_edge_cases():
     # un-normalised direction: t scales inversely (silhouette probes use such rays, DiffRender.py:222-224)
     T2, _ = orc.trace_closest(faces, verts, np.array([[0.2, 0.2, 1, 0, 0, -4]], np.float32))
     assert T2[0] == 0.25
+
+
+def far_camera_rays(mesh, distance_factor, res=96, view=3):
+    """Pinhole rays from a camera `distance_factor` extents away whose focal length grows with the distance (same image of the object)."""
+    c, ext = views.mesh_frame(mesh.vertices)
+    cam = views.turntable_cameras(c, ext, 8, res, res, distance_factor=distance_factor, focal_factor=1.1 * distance_factor / 2.5)[view]
+    o, d = views.generate_ray(res, res, cam[3], cam[2])
+    return np.concatenate([o.numpy(), d.numpy()], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("distance_factor", [2.5, 20.0, 100.0, 1000.0])
+def test_far_camera_keeps_its_hits(hand, distance_factor):
+    """The hit-point condition must not cost a distant camera its legitimate hits: its tolerance grows with the distance between the
+    ray's origin and the triangle (oracle/hit_point.h), as the float32 error of the reconstructed point does.  Against the four
+    inequalities alone (no fifth condition): same hits, same faces, same t -- with the absolute margin of round 3 five of the 698 hits
+    of the 1000-extent camera were dropped (hit points up to 2.2 margins outside their triangle's box)."""
+    f32, v32 = hand.faces.astype(np.int32), hand.vertices.astype(np.float32)
+    rays = far_camera_rays(hand, distance_factor)
+    T, ID = orc.trace_closest(f32, v32, rays)
+    T0, ID0 = orc.trace_closest(f32, v32, rays, mt_only=True)
+    assert (ID >= 0).sum() > 600
+    assert np.array_equal(ID, ID0) and np.array_equal(T, T0)
+    Tb, IDb = orc.trace_closest(f32, v32, rays, bvh=True)
+    assert np.array_equal(ID, IDb) and np.array_equal(T, Tb)
 
 
 def test_stepwise_hit_terms_vs_golden(hand):
