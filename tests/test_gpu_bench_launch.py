@@ -1,0 +1,58 @@
+"""The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py --gpus N --steps K --warmup W`), run as a subprocess: one rank per GPU over RCCL where the box has >= 2 GPUs,
+two ranks sharing the one GPU over gloo otherwise (DRT_DIST_BACKEND=gloo: a functional check of the same code path).  The JSON line of
+rank 0 must say n_gpus = 2 and carry the loss of ALL views, equal to the one-process run's after the same number of steps (SURVEY.md
+section 8e: the ranks' parameters stay identical, the all-reduce only changes the order of a float64 sum)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+ARGS = ["--steps", "2", "--warmup", "1", "--res", "256", "--views", "8", "--no-cpu-baseline", "--no-extras"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _run(cmd, env):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    return _json_line(p.stdout)
+
+
+def test_the_drivers_launch_line_with_two_ranks_equals_one_process():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
+    assert one["n_gpus"] == 1 and one["config"]["views_per_gpu"] == 8
+    env2 = dict(env)
+    rccl = torch.cuda.device_count() >= 2
+    if not rccl:
+        env2["DRT_DIST_BACKEND"] = "gloo"          # two ranks on the one GPU of the box: the all-reduce goes through the host
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + ARGS, env2)
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["warmup"] == 1
+    assert two["metric"] == one["metric"] and two["unit"] == "M camera-rays/s" and two["scaling"] == "strong"
+    assert two["config"]["views_per_gpu"] == 4 and two["config"]["workload"] == one["config"]["workload"]
+    # a share of 4 x 256^2 rays is below the whole-step-graph threshold: captured over RCCL on every rank or on none (never over gloo)
+    assert two["config"]["hip_graph"] in ((True, False) if rccl else (False,))
+    a, b = one["config"]["final_loss"], two["config"]["final_loss"]
+    assert a > 0 and abs(a - b) <= 1e-12 * abs(a), (a, b)
+    assert two["value"] > 0 and two["ms_per_step"] > 0
