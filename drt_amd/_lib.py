@@ -93,6 +93,8 @@ def lib():
                            "(run `python __graft_entry__.py`); there is no CPU fallback")
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("DRT_HIP_LIB") and not hasattr(h, name):
+                continue                        # an OLDER build selected for an A/B run (tools/ab.sh): entry points added since are simply absent
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args

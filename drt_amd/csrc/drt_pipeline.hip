@@ -35,7 +35,7 @@ struct Ray64 {
 };
 struct Pipe {
     RayList r0, r1, r2;
-    unsigned* count;   // [0..2] list sizes of the sub-batch in flight, [4..6] rays handed to k_trace_redo per stage
+    unsigned* count;   // [0..2] list sizes of the sub-batch in flight, [4..6] rays handed to the second pass of k_trace per stage, [16] its retired-workgroup counter
     unsigned* valid;   // number of valid rays of the whole call (shared by all sub-batches)
     int32_t* redo;     // list entries whose traversal overflowed the LDS stack
 };
@@ -1395,11 +1395,9 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
           // a demotion inside this call did list waits for k_gen_late below
       } else if (rz.views) {       // only the R0 slots listed by k_cull (rays that are not grid rays)
           const TraceOut out{p.r0.face, nullptr, nullptr, w.gen_list};
-          k_trace<false, 2><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 3, out, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
-          k_trace_redo<false, 2><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, out);
+          k_trace<false, 2><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 3, out, p.redo, p.count + 4, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
       } else {
-          k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
-          k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r0.ray, p.redo, p.count + 4, TraceOut{p.r0.face, nullptr, nullptr, nullptr});
+          k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
       } }
     if (mega) {     // k_shade1 parks float64 rays in rows of the dense outputs: their zeroing must be through
         if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));
@@ -1422,15 +1420,13 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         return DRT_OK;
     }
     { StageTimer t(s, st, kStageTrace2);
-      k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr);
-      k_trace_redo<false, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r1.ray, p.redo, p.count + 5, TraceOut{p.r1.face, nullptr, nullptr, nullptr}); }
+      k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr); }
     if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));     // k_shade2 is the first kernel that writes rows of the dense outputs
     if (late_fill && pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
     { StageTimer t(s, st, kStageTrace3);
-      k_trace<true, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr);
-      k_trace_redo<true, 0><<<kRedoGrid, kTraceBlock, 0, st>>>(pc.tc, p.r2.ray, p.redo, p.count + 6, TraceOut{p.r2.face, nullptr, nullptr, nullptr}); }
+      k_trace<true, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
     return DRT_OK;
 }
 }  // extern "C++"

@@ -53,8 +53,8 @@ constexpr int kStackFast = DRT_STACK_FAST;         // LDS stack entries per lane
 static_assert(kStackFast >= 3, "FastStack keeps four spare entries (kStackFast + 1 rows) above its usable depth");
 constexpr int kStackTotal = 192;
 constexpr int kStackSlowDev = kStackTotal - kStackFast;   // global overflow entries per thread
-constexpr int kQCount = 16;            // words of a pipeline's counter block
-constexpr int kRedoGrid = 64;          // blocks of k_trace_redo (rays that overflowed the LDS-only stack of k_trace)
+constexpr int kQCount = 24;            // words of a pipeline's counter block ([16]: k_trace's retired-workgroup counter)
+constexpr int kRedoGrid = 64;          // blocks of the one-thread-per-item second-pass kernels (k_path_redo, k_gen_late); sizes the overflow areas
 constexpr int kTraceGridMax = 4096;    // blocks per traversal launch (persistent, grid-stride)
 constexpr int64_t kChunkRays = 1 << 26; // max rays per pipeline pass; bounds the list workspace (96 B per ray of the largest pass)
 
@@ -115,8 +115,8 @@ struct drt_scene {
         unsigned* qcount = nullptr;                          // [kQCount] list sizes + redo counts of the sub-batch in flight, [8..15]: k_path's cursors
         double* ray64 = nullptr;                             // fused one-kernel path: [2][cap,3] float64 refracted rays between bounce #1 and #2
         int64_t ray64_cap = 0;
-        int32_t* redo = nullptr;                             // [cap] rays for k_trace_redo
-        int32_t* slow_stack = nullptr;                       // [kRedoGrid * kTraceBlock * kStackSlowDev] overflow area of this stream's k_trace_redo
+        int32_t* redo = nullptr;                             // [cap] rays for the second pass of k_trace (its last workgroup's epilogue)
+        int32_t* slow_stack = nullptr;                       // [kRedoGrid * kTraceBlock * kStackSlowDev] overflow area of this stream's second passes
         int64_t q_cap = 0, fused_cap = 0;
         // projected primary visibility (drt_raster.h): per-ray keys (all-empty between calls), one bit per 64 rays that
         // says "some key here was written", the fitted image models, triangles too large for one lane

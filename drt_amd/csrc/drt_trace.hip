@@ -88,14 +88,13 @@ static int b1_query(drt_scene* s, const float* d_rays, int64_t n_rays, float* d_
         HIP_TRY(hipMalloc(&s->b1_redo, sizeof(int32_t) * n_rays));
         s->b1_cap = n_rays;
     }
-    if (!s->b1_count) HIP_TRY(hipMalloc(&s->b1_count, sizeof(unsigned) * 2));
+    if (!s->b1_count) HIP_TRY(hipMalloc(&s->b1_count, sizeof(unsigned) * 3));
     { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
-    HIP_TRY(hipMemsetAsync(s->b1_count, 0, sizeof(unsigned) * 2, st));
+    HIP_TRY(hipMemsetAsync(s->b1_count, 0, sizeof(unsigned) * 3, st));
     const TraceCtx tc = trace_ctx(s);
     const TraceOut out{d_ID, d_T, d_hit, s->b1_list};
     k_b1_cull<ANY><<<grid_for(n_rays, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(tc.nodes, tc.n_tris, d_rays, n_rays, d_T, d_ID, d_hit, s->b1_list, s->b1_count);
-    k_trace<ANY, 1><<<s->grid_path, kPathBlock, 0, st>>>(tc, d_rays, s->b1_count, out, s->b1_redo, s->b1_count + 1, s->refill_min, s->inner_min, nullptr);
-    k_trace_redo<ANY, 1><<<kRedoGrid, kTraceBlock, 0, st>>>(tc, d_rays, s->b1_redo, s->b1_count + 1, out);
+    k_trace<ANY, 1><<<s->grid_path, kPathBlock, 0, st>>>(tc, d_rays, s->b1_count, out, s->b1_redo, s->b1_count + 1, s->b1_count + 2, s->refill_min, s->inner_min, nullptr);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -54,11 +54,23 @@ __device__ __forceinline__ const float* trace_ray(const float* __restrict__ rays
     return rays + 6 * (int64_t)(MODE != 0 ? out.idx[slot] : (int32_t)slot);
 }
 
+// A ray handed to the second pass (its LDS-only stack overflowed, or its winner failed the deferred hit-point condition).  The list is
+// read by ANOTHER workgroup of the same launch (the one that retires last, below), possibly on another XCD, whose L2 is not coherent with
+// this one's: the entry is a relaxed agent-scope atomic store (write-through, `sc1`), drained, as in k_refit's box hand-off -- no fences.
+__device__ __forceinline__ void trace_redo_push(int32_t* redo_list, unsigned* redo_count, int32_t slot) {
+    __hip_atomic_store(&redo_list[atomicAdd(redo_count, 1u)], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // acknowledged before this wave can reach the epilogue's barrier (rare path: the wait costs nothing)
+}
+
 // Persistent traversal over a ray list.  Each wave owns a contiguous segment of the list; a lane
 // whose ray finishes takes the segment's next ray (no atomics: the cursor is wave-uniform).
+// The second pass for the rays on `redo_list` (normally none) is the epilogue of the workgroup that retires LAST (`done_count`, zero at
+// launch and put back to zero by that workgroup): one thread per ray with the spilling Stack.  It used to be a launch of its own, an
+// empty kernel that -- queued behind this launch while the neighbour pipeline's persistent grid holds every wave slot of the chip -- took
+// 0.11 ms to get through the dispatcher in every pipeline of every step (profiles/r03_kernel_summary.txt: 112 us per call, 4 us alone).
 template <bool ANY, int MODE>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
-                                                       TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count,
+                                                       TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count, unsigned* done_count,
                                                        int refill_min, int inner_min, unsigned long long* stats) {
     __shared__ int32_t lds[kStackFast + 1 + kGuardRows][kPathBlock];     // 20 x 1 KB x 8 blocks = the CU's 160 KB; the top FOUR rows are FastStack's spare entries
     FastStack st;
@@ -97,7 +109,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         const bool refill = idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull);
         if ((refill || idle == ~0ull) && fin) {
             if (trav_winner_ok(c.tris, s)) trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
-            else redo_list[atomicAdd(redo_count, 1u)] = slot;
+            else trace_redo_push(redo_list, redo_count, slot);
             slot = -1;
         }
         if (refill) {
@@ -126,8 +138,8 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             lane_steps += (unsigned long long)__popcll(mi);
             if (at_inner) {
                 const bool done = trav_inner<ANY>(c.nodes, s, st);
-                if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to k_trace_redo
-                    redo_list[atomicAdd(redo_count, 1u)] = slot;
+                if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to the second pass (epilogue)
+                    trace_redo_push(redo_list, redo_count, slot);
                     slot = -1;
                 } else if (done) {
                     s.cur = kFinished;          // (emitted at the top of the loop)
@@ -152,21 +164,24 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         atomicAdd(stats + 2, leaf_steps);
         atomicMax(stats + 3, wave_steps);
     }
-}
-
-// Second pass for the rays whose traversal overflowed the LDS-only stack of k_trace: one thread per
-// ray, spilling stack.  Normally the list is empty and the kernel returns at once.
-template <bool ANY, int MODE>
-__global__ void __launch_bounds__(kTraceBlock) k_trace_redo(TraceCtx c, const float* __restrict__ rays, const int32_t* __restrict__ redo_list,
-                                                             const unsigned* __restrict__ redo_count, TraceOut out) {
-    __shared__ int32_t lds[kStackFast][kTraceBlock];
-    const unsigned n = *redo_count;
-    if (n == 0) return;
-    Stack st = make_stack(lds, c);
-    for (unsigned k = blockIdx.x * kTraceBlock + threadIdx.x; k < n; k += gridDim.x * kTraceBlock) {
-        const int32_t slot = redo_list[k];
-        const float* e = trace_ray<MODE>(rays, out, (unsigned)slot);
-        const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, st);
-        trace_emit<ANY, MODE>(out, slot, h.t, h.face);
+    // ---- epilogue: the workgroup that retires last runs the second pass.  The barrier's workgroup-scope release waits for this wave's
+    // stores (its redo entries among them) to be acknowledged before thread 0 announces the workgroup; row kStackFast of the stack array
+    // (a spare row of the FastStack, outside the kStackFast rows the spilling Stack uses) carries the verdict to the other waves.
+    __syncthreads();
+    if (threadIdx.x == 0) lds[kStackFast][0] = atomicAdd(done_count, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!lds[kStackFast][0]) return;
+    const unsigned n_redo = __hip_atomic_load(redo_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_redo) {
+        Stack sst;
+        sst.fast = &lds[0][threadIdx.x]; sst.stride = kPathBlock; sst.depth_fast = kStackFast; sst.sp = 0;
+        sst.slow = c.slow_stack + (int64_t)threadIdx.x * kStackSlowDev;      // (the area is sized for kRedoGrid * kTraceBlock >= kPathBlock threads)
+        for (unsigned k = threadIdx.x; k < n_redo; k += kPathBlock) {
+            const int32_t rs = __hip_atomic_load(&redo_list[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float* e = trace_ray<MODE>(rays, out, (unsigned)rs);
+            const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, sst);
+            trace_emit<ANY, MODE>(out, rs, h.t, h.face);
+        }
     }
+    if (threadIdx.x == 0) __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch on this stream
 }
