@@ -98,7 +98,7 @@ struct drt_scene {
     int32_t* slow_stack = nullptr; // [max(grid_trace, 4 n_cu, kRedoGrid) * kTraceBlock * kStackSlowDev] (B1 queries, closest point, edge probes): ensure_slow_stack
     unsigned long long* scratch = nullptr;  // small counters
     int32_t *b1_list = nullptr, *b1_redo = nullptr;   // B1 queries (drt_intersect*): candidate ray numbers, redo list
-    unsigned* b1_count = nullptr;           // [0] candidates, [1] redo entries
+    unsigned* b1_count = nullptr;           // [0] candidates, [1] redo entries, [2] retired workgroups of k_trace (all zero between queries)
     int64_t b1_cap = 0;
     // wavefront-pipeline workspace, sized for one chunk of rays, allocated on first use
     // Pipeline workspaces: one per internal stream.  A call is cut into sub-batches that run on

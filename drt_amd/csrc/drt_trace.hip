@@ -81,6 +81,7 @@ template <bool ANY>
 static int b1_query(drt_scene* s, const float* d_rays, int64_t n_rays, float* d_T, int32_t* d_ID, uint8_t* d_hit, hipStream_t st) {
     if (n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     { int rc = wait_build(s, st); if (rc) return rc; }
+    { int rc = ensure_slow_stack(s, st); if (rc) return rc; }       // (first: it refuses a first use under stream capture with a message)
     if (n_rays > s->b1_cap) {
         (void)hipFree(s->b1_list); (void)hipFree(s->b1_redo);
         s->b1_list = s->b1_redo = nullptr; s->b1_cap = 0;
@@ -88,9 +89,10 @@ static int b1_query(drt_scene* s, const float* d_rays, int64_t n_rays, float* d_
         HIP_TRY(hipMalloc(&s->b1_redo, sizeof(int32_t) * n_rays));
         s->b1_cap = n_rays;
     }
-    if (!s->b1_count) HIP_TRY(hipMalloc(&s->b1_count, sizeof(unsigned) * 3));
-    { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
-    HIP_TRY(hipMemsetAsync(s->b1_count, 0, sizeof(unsigned) * 3, st));
+    if (!s->b1_count) {      // zero once: k_trace<ANY, 1>'s last workgroup puts the three counters back to zero at the end of every query
+        HIP_TRY(hipMalloc(&s->b1_count, sizeof(unsigned) * 4));
+        HIP_TRY(hipMemset(s->b1_count, 0, sizeof(unsigned) * 4));
+    }
     const TraceCtx tc = trace_ctx(s);
     const TraceOut out{d_ID, d_T, d_hit, s->b1_list};
     k_b1_cull<ANY><<<grid_for(n_rays, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(tc.nodes, tc.n_tris, d_rays, n_rays, d_T, d_ID, d_hit, s->b1_list, s->b1_count);

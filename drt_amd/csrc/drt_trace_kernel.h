@@ -183,5 +183,11 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             trace_emit<ANY, MODE>(out, rs, h.t, h.face);
         }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch on this stream
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch on this stream
+        if (MODE == 1) {      // B1: the query's counters go back to zero here (every workgroup has read them), so the next query needs no memset in front
+            __hip_atomic_store(const_cast<unsigned*>(n_ptr), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(redo_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }

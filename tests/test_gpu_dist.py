@@ -212,16 +212,18 @@ def test_a_replayed_update_rebuilds_the_scene_box_from_the_vertices_of_the_repla
     v0 = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda")
     c = v0.mean(0)
     static = v0.clone()
+    rays = torch.cat([c.float() + torch.tensor([0.0, 0.0, 400.0], device="cuda"), torch.tensor([0.0, 0.0, -1.0], device="cuda")]).repeat(64, 1).contiguous()
+    step = lambda: (scene.update_verticex(static), scene.optix_mesh.intersect_any(rays))[1]     # (a consumer of the tree joins the build stream)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(2):
-            scene.update_verticex(static)
+            step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        scene.update_verticex(static)
+        hit = step()
     pads = []
     for scale in (1.0, 3.0, 0.5, 0.1, 0.7):              # grows once, then shrinks well below the first box
         static.copy_(c + (v0 - c) * scale)

@@ -50,8 +50,11 @@ with open(out + '/kernel_summary.txt', 'w') as o:
 PY
 run_pmc () {  # name counters...
   local name=$1; shift
-  # (DRT_PREFILL_NEXT=0: counters are per-kernel properties; without it the last step leaves one more set of output fills than patch lists)
-  DRT_PREFILL_NEXT=0 rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
+  # Counter passes run with the internal streams SERIALISED (one pipeline, fills in front of the projection pass, no ahead-of-time fills):
+  # TCC / FETCH_SIZE / WRITE_SIZE are chip-wide, and with two pipelines + fills side by side a 2.4 MB kernel was charged 422 MB of its
+  # neighbours' traffic (round 3).  Counters are per-kernel properties; launch TIMES come from the default run above.
+  # (DRT_PREFILL_NEXT=0 also keeps the number of output fills equal to the number of patch lists.)
+  DRT_STREAMS=1 DRT_FILL_OVERLAP=0 DRT_PREFILL_NEXT=0 DRT_ASYNC_BUILD=0 rocprofv3 --pmc "$@" --output-format csv -d "$W/$name" -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --random-targets "${BARGS[@]}" > "$O/$name.log" 2>&1
   local f=$(find "$W/$name" -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then python tools/pmc_summary.py "$f" > "$O/$name.txt"; else echo "no counter file" > "$O/$name.txt"; fi
 }
