@@ -818,6 +818,21 @@ __global__ void k_store_count(const unsigned* __restrict__ count, int64_t* __res
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = (int64_t)*count;
 }
 
+// drt_outputs_clean: the rows a render call left non-zero are exactly its list of completed paths; zero them again (51 B per listed row
+// instead of 51 B per ray of the call).
+__global__ void __launch_bounds__(256) k_unwrite_rows(double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
+                                                      const int32_t* __restrict__ rows, const int64_t* __restrict__ n_rows, int64_t n_rays) {
+    const int64_t n = *n_rows;
+    const d3 z{0.0, 0.0, 0.0};
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = rows[k];
+        if (i < 0 || i >= n_rays) continue;
+        store_d3(out_ori, i, z);
+        store_d3(out_dir, i, z);
+        mask[3 * i] = 0; mask[3 * i + 1] = 0; mask[3 * i + 2] = 0;
+    }
+}
+
 
 // Vertex-gradient accumulation through an LDS hash table.  The float64 scatter is bound by the
 // chip's atomic rate (measured 22.6 G global_atomic_add_f64 per second, tools/ubench/atomic_scope.hip,
@@ -1552,6 +1567,28 @@ int drt_prefill_zero(drt_scene_t* s, void* d_buf, int64_t bytes, void* stream) {
       HIP_TRY(hipMemsetAsync(d_buf, 0, (size_t)bytes, bs)); }
     HIP_TRY(hipEventRecord(s->prefill_done, bs));
     s->prefill[s->n_prefill].ptr = d_buf; s->prefill[s->n_prefill].bytes = bytes; ++s->n_prefill;
+    return DRT_OK;
+}
+
+int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint8_t* d_mask, int64_t n_rays,
+                      const int32_t* d_valid_idx, const int64_t* d_n_valid, void* stream) {
+    CHECK_SCENE(s);
+    if (n_rays <= 0 || !d_out_ori || !d_out_dir || !d_mask || !d_valid_idx || !d_n_valid) return fail(DRT_E_INVALID, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return fail(DRT_E_INVALID, "drt_outputs_clean: not while a graph is being captured");
+    if (s->n_prefill) {       // zeroings of OTHER buffers still pending on the build stream: order them in front of this stream, forget the entries
+        HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
+        s->n_prefill = 0;
+    }
+    { StageTimer t(s, st, kStageFill);
+      k_unwrite_rows<<<4 * s->n_cu, 256, 0, st>>>(d_out_ori, d_out_dir, d_mask, d_valid_idx, d_n_valid, n_rays); }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->prefill_done, st));
+    s->prefill[0].ptr = d_out_ori; s->prefill[0].bytes = (int64_t)sizeof(double) * 3 * n_rays;
+    s->prefill[1].ptr = d_out_dir; s->prefill[1].bytes = (int64_t)sizeof(double) * 3 * n_rays;
+    s->prefill[2].ptr = d_mask;    s->prefill[2].bytes = 3 * n_rays;
+    s->n_prefill = 3;
     return DRT_OK;
 }
 

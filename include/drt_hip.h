@@ -163,6 +163,16 @@ int drt_scale_rows3(double* d_x, const int32_t* d_list, const uint32_t* d_n_list
  * releases such a buffer WITHOUT rendering into it (its allocator may hand the memory to work on `stream`); drt_destroy waits by itself. */
 int drt_prefill_zero(drt_scene_t* s, void* d_buf, int64_t bytes, void* stream);
 int drt_prefill_wait(drt_scene_t* s, void* stream);
+/* The outputs of an EARLIER drt_render_forward (same scene or not) offered again as the outputs of the next one of `n_rays` rays: they
+ * are zeros in every row but the rows that call listed in d_valid_idx / d_n_valid (a call's dense outputs are zero wherever its mask is
+ * -- the reference's torch.zeros + index_put, DiffRender.py:421-431 -- and its list of completed paths is exactly the set rows), so
+ * zeroing THOSE rows (51 B per listed row, on `stream`) leaves the three buffers as freshly zeroed ones, and the next
+ * drt_render_forward on this scene with exactly these pointers does not fill them again (the fills are 51 B per RAY: 3.85 GB of the
+ * 72 x 1024^2 step, its one HBM-bound stage).  The caller vouches that nothing else wrote the buffers since that earlier call and that
+ * nobody else still reads them (drt_amd/diffrender.py: storage use counts and version counters); entries are forgotten at the next
+ * drt_render_forward, like drt_prefill_zero's.  Not while a graph is being captured. */
+int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint8_t* d_mask, int64_t n_rays,
+                      const int32_t* d_valid_idx, const int64_t* d_n_valid, void* stream);
 /* ray_loss (reference optim.py:91-108) AND its vertex gradient in one pass over the forward's list of completed paths
  * (drt_render_forward's d_valid_idx / d_n_valid, face ids from the same call): *d_loss += the loss (float64 scalar, zero it first)
  * and d_grad_verts float64 [V,3] += d loss / d vertices with a UNIT seed (the caller scales it by the incoming gradient of the loss:

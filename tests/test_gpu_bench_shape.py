@@ -40,15 +40,23 @@ def test_the_timed_call_equals_72_plain_tree_calls():
     try:
         scene = Render.Scene(mesh, 0)
         assert scene.optix_mesh is not None
-        for it in range(3):                            # establish the verdict, read it back, then the trusted + prefilled call that is timed
+        recycled_ptr = None
+        for it in range(4):                            # establish the verdict, read it back (trusted, fresh outputs), then trusted + RECYCLED outputs: what is timed
             V = V0.clone().requires_grad_(True)
             scene.update_verticex(V)
             oo, od, mk = scene.render_transparent(o_all, d_all)
             loss = Render.ray_loss(oo, od, mk, sp_all, valid_all)
             if it == 1:
                 assert d_all._drt_grid[3][0] is True                       # every image verified in every ray -> DRT_GRID_ALL_VERIFIED from now on
-                if Render.PREFILL_NEXT and len(o_all) >= Render.PREFILL_MIN_RAYS:
+                if Render.RECYCLE_OUTPUTS and len(o_all) >= Render.RECYCLE_MIN_RAYS:
+                    recycled_ptr = scene.optix_mesh._out_pool.entries[-1][3][0].data_ptr()      # kept by the library for the next call of this size
+                    assert recycled_ptr == oo.data_ptr()
+                elif Render.PREFILL_NEXT and len(o_all) >= Render.PREFILL_MIN_RAYS:
                     assert scene.optix_mesh._prefilled is not None         # the next call's out_ori / mask are being zeroed right now
+            if it >= 2 and recycled_ptr is not None:
+                assert oo.data_ptr() == recycled_ptr                       # rendered into the memory of call 1, only its set rows zeroed in between
+            if it < 3:
+                del oo, od, mk, loss                                       # (a step of the optimisation lets go of its outputs before the next one)
         assert (Render._grid_cache(o_all, d_all, len(o_all), RES, RES)[0] & (3 | 32)) == (2 | 32)
         grad, = torch.autograd.grad(loss, V)
         f1_all, f2_all = scene.last_face1, scene.last_face2

@@ -947,7 +947,14 @@ def test_outputs_zeroed_ahead_of_time_equal_outputs_filled_in_the_call(Render, h
     V0 = torch.tensor(hand.vertices, dtype=torch.float64, device="cuda")
     gen = torch.Generator(device="cuda").manual_seed(5)
     moves = [1e-3 * torch.randn(V0.shape, dtype=torch.float64, device="cuda", generator=gen) for _ in range(5)]
+    recycle, Render.RECYCLE_OUTPUTS = Render.RECYCLE_OUTPUTS, False      # (recycled outputs -- tests/test_gpu_recycle.py -- take precedence over buffers zeroed ahead of time)
+    try:
+        _prefill_body(Render, o, d, n, V0, moves)
+    finally:
+        Render.RECYCLE_OUTPUTS = recycle
 
+
+def _prefill_body(Render, o, d, n, V0, moves):
     def run(prefill):
         old = Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS
         Render.PREFILL_NEXT, Render.PREFILL_MIN_RAYS = prefill, 0
