@@ -93,7 +93,7 @@ def _pmc(mode, workload):
 VALU_PER_INNER_STEP, VALU_PER_LEAF_STEP = 103, 72
 
 
-def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None, live=None, wave_steps=None):
+def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None, live=None, wave_steps=None, recycled=False):
     """Per-kernel live timing (hipEvents on the launch streams, drt_profile_*) -> the kernel that takes the most time, BY
     KERNEL NAME (the two closest-hit traversals are one kernel), with the bound that applies to it, and the HBM-streaming
     stage beside it.
@@ -102,7 +102,9 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
       costs +24 %).  achieved = VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of the same
       command, profiles/pmc.json) / the live launch time; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles.
     * `fill + k_cull` (dead values into the dense float64 outputs + the patches that matter) is the HBM stage: algorithmic
-      bytes = 51 B per ray written + (48 read + 36 list + 8 key) per primary hit, DESIGN.md section 4.
+      bytes = 51 B per ray written + (48 read + 36 list + 8 key) per primary hit, DESIGN.md section 4.  `recycled`: the call renders into
+      the outputs of the previous one (diffrender.RECYCLE_OUTPUTS) and the "fill" is 51 B per COMPLETED PATH of that call (the rows it had
+      set), not per ray: the stage is then a latency-bound scatter and no longer a bandwidth figure worth a roofline.
     Stage times of the timed region overlap (two internal streams); `alone` = the same steps with the streams serialised."""
     n = P * n_local_views * args.steps                 # rays through the pipeline in the timed region
     it = {k: v[2] for k, v in prof.items()}
@@ -112,7 +114,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
     fused = args.mode == "fused"
     # bytes per item: list entry = 4 (index) + 24 (float32 ray) + 4 (face); float64 ray = 48; dense outputs = 51 + 8 (face ids)
     alg = {
-        "fill": 0 if fused else 51 * n,                      # dense outputs 24 + 24 + 3 B per ray (face ids only where mask = 1)
+        "fill": 0 if fused else (55 * v if recycled else 51 * n),      # dense outputs 24 + 24 + 3 B per ray (face ids only where mask = 1); recycled outputs: the rows of the previous call's list (4 B read + 51 B written each)
         "cull": (48 + 36 + 8) * h0 + (0 if it.get("fill", 0) or fused else 51 * n),
         "trace1": 28 * c, "trace2": 28 * h, "trace3": 28 * s2,
         "shade1": (8 + 48 + 4) * h0 + 28 * h,
@@ -208,7 +210,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
                 per_step = sum(pmc[q]["hbm_bytes_per_launch"] * pmc[q]["launches"] for q in names)
                 ref_launches = pmc.get("k_patch_list", {}).get("launches")
                 traffic = round(per_step / ref_launches) if ref_launches else None
-        out = {"kernel": "fill + k_cull", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+        out = {"kernel": "k_unwrite_rows + k_cull (outputs recycled: no dense fill)" if recycled else "fill + k_cull", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                "traffic": traffic, "pmc_stale": pmc_prov["stale"], "alg_bytes_per_launch": round(bytes_ / max(1, launches)), "avg_launch_ms": round(ms / max(1, launches), 4)}
         if alone and all(m in alone for m in members):
             ms_a = sum(alone[m]["ms_per_step"] for m in members) * args.steps
@@ -491,7 +493,7 @@ def main():
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD"
                                + ("" if args.distance_factor == 2.5 else f", cameras at {args.distance_factor} extents")
                                + (", no grid verdict cache" if args.no_grid_cache else ""),
-                   "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
+                   "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "outputs_recycled": bool(args.mode == "dropin" and not args.graph and Render.RECYCLE_OUTPUTS and P * len(my_views) >= Render.RECYCLE_MIN_RAYS), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
                    "final_loss": float(ddist.allreduce_sum_(loss.detach().clone().reshape(1).double()).item())},     # (summed over the ranks: the loss of all views)
     }
     prof_live = scene.optix_mesh.profile_read() if live_profile else None
@@ -667,7 +669,8 @@ def main():
     scene.optix_mesh.profile_enable(0)
     if rank == 0:
         wave_steps = {k: {"inner": ws - lf, "leaf": lf, "launches": max(1, prof2[k][1])} for k, (ws, ls, lf, mx) in tstats.items() if ws} if prof2 else None
-        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso, LIVE if prof_live else None, wave_steps)
+        out["roofline"] = roofline(prof, args, P, len(my_views), n_verts, n_faces, elapsed, world, prof_iso, LIVE if prof_live else None, wave_steps,
+                                   recycled=args.mode == "dropin" and not args.graph and Render.RECYCLE_OUTPUTS and P * len(my_views) >= Render.RECYCLE_MIN_RAYS)
         # what the step actually traces: paths that start at a primary hit (every pixel counts in `value`, SURVEY section 8d, but 96 % of
         # the benchmark's pixels see the background)
         h0 = prof["shade1"][2] / max(1, args.steps)
