@@ -176,15 +176,24 @@ template <bool APPLY>
 __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_cand, const uint8_t* __restrict__ ok, const int64_t* __restrict__ E,
                                     int64_t* F, double* V, const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double min_len,
                                     unsigned seed, const double* __restrict__ length, unsigned long long* lock, uint8_t* __restrict__ f_alive,
-                                    uint8_t* __restrict__ v_alive, int32_t* n_done) {
+                                    uint8_t* __restrict__ v_alive, uint8_t* dirty, int32_t* n_done) {
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= n_cand || !ok[c]) return;
     const int64_t e = cand[c], a = E[2 * e], b = E[2 * e + 1];
     const unsigned long long key = collapse_key(length[e], min_len, e, seed);      // (from the lengths of the round's start: V changes under APPLY)
+    // Sub-rounds (several claim / apply pairs on ONE evaluation and ONE set of tables): a collapse that went ahead marks everything it
+    // read or wrote `dirty`; a candidate takes part in a later sub-round only while its two vertices and both rings are clean -- then no
+    // face, position, normal or valence its evaluation relied on has changed (a face around a clean vertex cannot have been touched: the
+    // collapse that touched it would have had that vertex in a ring), so the verdict `ok` still stands.  `dirty` is read in the claim
+    // pass and written in the apply pass only: a candidate that was not eligible has left no claim and cannot find its key in `lock`.
+    if (!APPLY && (dirty[a] | dirty[b])) return;
+    if (APPLY && !(lock[a] == key && lock[b] == key)) return;
     Ring ra, rb;
     collect_ring(a, F, vf_start, vf_face, ra);
     collect_ring(b, F, vf_start, vf_face, rb);
     if (!APPLY) {
+        for (int k = 0; k < ra.n; ++k) if (dirty[ra.v[k]]) return;
+        for (int k = 0; k < rb.n; ++k) if (dirty[rb.v[k]]) return;
         atomicMin(&lock[a], key); atomicMin(&lock[b], key);
         for (int k = 0; k < ra.n; ++k) if (rb.has(ra.v[k])) atomicMin(&lock[ra.v[k]], key);       // the two opposite vertices
         return;
@@ -203,6 +212,9 @@ __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_
     }
     v_alive[b] = 0;
     store_d3(V, a, m);
+    dirty[a] = 1; dirty[b] = 1;
+    for (int k = 0; k < ra.n; ++k) dirty[ra.v[k]] = 1;
+    for (int k = 0; k < rb.n; ++k) dirty[rb.v[k]] = 1;
     atomicAdd(n_done, 1);
 }
 
@@ -263,16 +275,23 @@ __global__ void k_rm_flip_eval(const int64_t* __restrict__ E, int64_t n_edges, c
     ok[e] = 1;
 }
 template <bool APPLY>
-__global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok, const int64_t* __restrict__ quad, int64_t* F, unsigned* lock, int32_t* n_done) {
+__global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok, const int64_t* __restrict__ quad, int64_t* F, unsigned* lock, uint8_t* dirty, int32_t* n_done) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= n_edges || !ok[e]) return;
     const int64_t* o = quad + 6 * e;
     const unsigned key = (unsigned)e;
-    if (!APPLY) { for (int k = 0; k < 4; ++k) atomicMin(&lock[o[k]], key); return; }
+    // (sub-rounds as in k_rm_collapse_claim: a flip that went ahead dirties its four vertices -- their valences and two of their faces
+    // changed; a later sub-round admits only quads that are clean, whose evaluation therefore still stands)
+    if (!APPLY) {
+        for (int k = 0; k < 4; ++k) if (dirty[o[k]]) return;
+        for (int k = 0; k < 4; ++k) atomicMin(&lock[o[k]], key);
+        return;
+    }
     for (int k = 0; k < 4; ++k) if (lock[o[k]] != key) return;
     const int64_t a = o[0], b = o[1], c = o[2], d = o[3], f1 = o[4], f2 = o[5];
     F[3 * f1] = c; F[3 * f1 + 1] = a; F[3 * f1 + 2] = d;
     F[3 * f2] = d; F[3 * f2 + 1] = b; F[3 * f2 + 2] = c;
+    for (int k = 0; k < 4; ++k) dirty[o[k]] = 1;
     atomicAdd(n_done, 1);
 }
 
@@ -375,15 +394,21 @@ int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d
 }
 
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
-                          const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, uint32_t seed, const double* d_length,
-                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, int32_t* d_n_done, void* stream) {
+                          const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, const double* d_length,
+                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream) {
     if (n_cand <= 0) return DRT_OK;
-    if (!d_cand || !d_ok || !d_edges || !d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_length || !d_lock || !d_f_alive || !d_v_alive || !d_n_done)
-        return fail(DRT_E_INVALID, "null pointer argument");
+    if (!d_cand || !d_ok || !d_edges || !d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_length || !d_lock || !d_f_alive || !d_v_alive || !d_dirty ||
+        !d_n_done || n_verts <= 0 || sub_rounds < 1)
+        return fail(DRT_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* lock = reinterpret_cast<unsigned long long*>(d_lock);
-    k_rm_collapse_claim<false><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, seed, d_length, lock, d_f_alive, d_v_alive, d_n_done);
-    k_rm_collapse_claim<true><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, seed, d_length, lock, d_f_alive, d_v_alive, d_n_done);
+    HIP_TRY(hipMemsetAsync(d_dirty, 0, (size_t)n_verts, st));
+    for (int r = 0; r < sub_rounds; ++r) {
+        HIP_TRY(hipMemsetAsync(lock, 0xFF, sizeof(unsigned long long) * (size_t)n_verts, st));          // all ones = no claim
+        const uint32_t sd = seed + 0x632BE5ABu * (uint32_t)r;
+        k_rm_collapse_claim<false><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
+        k_rm_collapse_claim<true><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
+    }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -397,12 +422,17 @@ int drt_rm_flip_eval(const int64_t* d_edges, int64_t n_edges, const int64_t* d_e
     return DRT_OK;
 }
 
-int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, uint32_t* d_lock, int32_t* d_n_done, void* stream) {
+int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, uint32_t* d_lock, uint8_t* d_dirty,
+                      int sub_rounds, int32_t* d_n_done, void* stream) {
     if (n_edges <= 0) return DRT_OK;
-    if (!d_ok || !d_quad || !d_faces || !d_lock || !d_n_done) return fail(DRT_E_INVALID, "null pointer argument");
+    if (!d_ok || !d_quad || !d_faces || !d_lock || !d_dirty || !d_n_done || n_verts <= 0 || sub_rounds < 1) return fail(DRT_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    k_rm_flip_claim<false><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_n_done);
-    k_rm_flip_claim<true><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_n_done);
+    HIP_TRY(hipMemsetAsync(d_dirty, 0, (size_t)n_verts, st));
+    for (int r = 0; r < sub_rounds; ++r) {
+        HIP_TRY(hipMemsetAsync(d_lock, 0xFF, sizeof(uint32_t) * (size_t)n_verts, st));
+        k_rm_flip_claim<false><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_dirty, d_n_done);
+        k_rm_flip_claim<true><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_dirty, d_n_done);
+    }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

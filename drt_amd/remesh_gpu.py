@@ -36,6 +36,9 @@ from .remesh import SPLIT, COLLAPSE, FLIP, SMOOTH, REPROJECT, CHECK_DIST, ALL  #
 
 MAX_Q = 24                 # surface-distance queries per collapse candidate (midpoint + surviving faces); more -> the edge is left alone
 MAX_ROUNDS = 96            # evaluate / claim / apply rounds per step (a round applies an independent set of the candidates: a few per cent)
+SUB_ROUNDS = int(__import__("os").environ.get("DRT_REMESH_SUB_ROUNDS", 3))     # claim / apply pairs per evaluation (one set of edge tables, vertex -> face lists and surface queries
+                           # serves several independent sets: candidates whose neighbourhood an earlier pair of the round touched sit out until the next evaluation)
+TAIL_CUT = int(__import__("os").environ.get("DRT_REMESH_TAIL_CUT", 32))       # a step ends when a round applies less than 1 / TAIL_CUT of what its first round applied
 DEBUG = False
 
 
@@ -50,6 +53,9 @@ class _Work:
         self.V, self.F = V.contiguous(), F.contiguous()
         self.surface, self.max_dist = surface, max_dist
         self.dev = V.device
+        # what a caller can check afterwards: evaluation rounds per step, steps that ran out of rounds with candidates still passing,
+        # moves that still folded a face after the last roll-back round (each is then rolled back by more rounds: see move_vertices)
+        self.stats = {"collapse_rounds": 0, "flip_rounds": 0, "collapse_unfinished": 0, "flip_unfinished": 0, "move_rounds_max": 0, "move_unresolved": 0}
 
     # ---- derived tables
     def edges(self):
@@ -107,10 +113,18 @@ class _Work:
         lib = _lib.lib()
         done = 0
         v_alive = torch.ones(self.V.shape[0], dtype=torch.uint8, device=self.dev)
-        for rnd in range(MAX_ROUNDS):
-            E, _, _ = self.edges()
+        first = 0
+        for rnd in range(MAX_ROUNDS + 1):
+            if rnd == MAX_ROUNDS:
+                self.stats["collapse_unfinished"] += 1            # candidates were still being applied when the rounds ran out
+                break
+            self.stats["collapse_rounds"] += 1
+            # candidates straight from the faces: every edge of a closed oriented mesh is the directed edge (lo -> hi) of exactly one face
+            # corner, so the rows 3 f + k with F[f, k] < F[f, k + 1] ARE the unique edges -- no sorted edge table per round (0.6 ms of a
+            # 1.4 ms round at 80 k faces; the flips, which search the table, still build it)
+            E = self.F[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2).contiguous()
             length = (self.V[E[:, 0]] - self.V[E[:, 1]]).norm(dim=1).contiguous()
-            cand = torch.nonzero(length < min_len).squeeze(1).contiguous()
+            cand = torch.nonzero((length < min_len) & (E[:, 0] < E[:, 1])).squeeze(1).contiguous()
             if len(cand) == 0:
                 break
             vf_start, vf_face = self.csr()
@@ -130,12 +144,14 @@ class _Work:
             ok[far_rows] = 0
             if int(ok.sum()) == 0:
                 break
-            lock = torch.full((self.V.shape[0],), -1, dtype=torch.int64, device=self.dev)        # all ones = no claim (compared as unsigned)
+            nv = self.V.shape[0]
+            lock = torch.empty(nv, dtype=torch.int64, device=self.dev)                           # (workspaces: preset by the call)
+            dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
             f_alive = torch.ones(self.F.shape[0], dtype=torch.uint8, device=self.dev)
             n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
             _check(lib.drt_rm_collapse_apply(cand.data_ptr(), len(cand), ok.data_ptr(), E.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
-                                             vf_start.data_ptr(), vf_face.data_ptr(), float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, length.data_ptr(),
-                                             lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), n_done.data_ptr(), _stream()))
+                                             vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, length.data_ptr(),
+                                             lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), dirty.data_ptr(), SUB_ROUNDS, n_done.data_ptr(), _stream()))
             n = int(n_done.item())
             if DEBUG:
                 print(f"  collapse round: {len(cand)} short edges, {int(ok.sum())} pass, {n} applied")
@@ -143,13 +159,20 @@ class _Work:
                 break
             done += n
             self.F = self.F[f_alive.bool()].contiguous()
+            first = first or n
+            if n < max(4, first // TAIL_CUT):     # the tail of a step: a handful of candidates per round, each round a rebuild of the tables;
+                break                             # what is left is picked up by the next of the call's iterations (or the next pass)
         return done
 
     # ---- 3. flip
     def flip_edges(self, max_len):
         lib = _lib.lib()
-        done = 0
-        for _ in range(MAX_ROUNDS):
+        done = first = 0
+        for rnd in range(MAX_ROUNDS + 1):
+            if rnd == MAX_ROUNDS:
+                self.stats["flip_unfinished"] += 1
+                break
+            self.stats["flip_rounds"] += 1
             E, _, edge_rows = self.edges()
             vf_start, vf_face = self.csr()
             vn = self.vertex_normals(vf_start, vf_face)
@@ -166,15 +189,21 @@ class _Work:
             ok[idx[~near]] = 0
             if int(ok.sum()) == 0:
                 break
-            lock = torch.full((self.V.shape[0],), -1, dtype=torch.int32, device=self.dev)
+            nv = self.V.shape[0]
+            lock = torch.empty(nv, dtype=torch.int32, device=self.dev)
+            dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
             n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
-            _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), lock.data_ptr(), n_done.data_ptr(), _stream()))
+            _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), nv, lock.data_ptr(), dirty.data_ptr(), SUB_ROUNDS,
+                                         n_done.data_ptr(), _stream()))
             n = int(n_done.item())
             if DEBUG:
                 print(f"  flip round: {int(ok.sum())} pass, {n} applied")
             if n == 0:
                 break
             done += n
+            first = first or n
+            if n < max(4, first // TAIL_CUT):
+                break
         return done
 
     # ---- 4./5. relaxation and projection, with roll-back
@@ -188,11 +217,21 @@ class _Work:
         self.V = target.contiguous()
         revert = torch.empty(nv, dtype=torch.uint8, device=self.dev)
         n_bad = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        for _ in range(4):
+        # every round takes the vertices of the faces that fold (or degenerate) back to where they were; that can fold a neighbour, whose
+        # vertices go back in the next round.  The cascade ends -- with every vertex back the mesh is the one it started from -- so the loop
+        # runs until a round finds nothing (four rounds were the rule before, and what was still folded after them stayed folded)
+        prev = -1
+        for rnd in range(1, 65):
             _check(lib.drt_rm_move_check(self.F.data_ptr(), self.V.data_ptr(), old.data_ptr(), vn.data_ptr(), a0.data_ptr(), nf, nv,
                                          revert.data_ptr(), n_bad.data_ptr(), _stream()))
-            if int(n_bad.item()) == 0:
+            n = int(n_bad.item())
+            if n == 0:
                 break
+            if n == prev:        # nothing left to take back: these faces were degenerate before the move already (not this step's doing)
+                self.stats["move_unresolved"] = max(self.stats["move_unresolved"], n)
+                break
+            prev = n
+        self.stats["move_rounds_max"] = max(self.stats["move_rounds_max"], rnd)
 
     def smooth_tangential(self):
         vf_start, vf_face = self.csr()
@@ -244,6 +283,7 @@ def isotropic_remesh_gpu(vertices, faces, target_len, surface=None, iterations=3
                 w.project_to_surface()
             w.compact()
             stats["iterations"] += 1
+    stats.update(w.stats)
     return (w.V, w.F, stats) if return_stats else (w.V, w.F)
 
 

@@ -278,12 +278,15 @@ int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double*
  *   drt_rm_collapse_eval    candidates d_cand int64 [n] (indices into d_edges int64 [E,2]): ok uint8 [n] = every rule but the surface
  *                           distance; d_query float64 [n, max_q, 3] / d_n_query int32 [n]: the points whose distance to the input surface
  *                           the caller still has to check (midpoint, centroids of the faces that survive).
- *   drt_rm_collapse_apply   claim (64-bit atomicMin of (length class, hash(edge, seed), edge index) on d_lock uint64 [V], preset to all ones;
- *                           d_length float64 [E]: edge lengths at the start of the round) what each candidate with ok = 1 writes, and
+ *   drt_rm_collapse_apply   claim (64-bit atomicMin of (length class, hash(edge, seed), edge index) on d_lock uint64 [V] -- workspace, preset
+ *                           here; d_length float64 [E]: edge lengths at the start of the round) what each candidate with ok = 1 writes, and
  *                           apply those that nobody with a higher priority contests: faces rewritten in place, d_f_alive / d_v_alive
- *                           cleared for what dies, *d_n_done += number applied.
+ *                           cleared for what dies, *d_n_done += number applied.  `sub_rounds` claim / apply pairs on the same evaluation
+ *                           and tables: a collapse that went ahead marks what it read or wrote in d_dirty uint8 [V] (workspace, cleared
+ *                           here), and later sub-rounds admit only candidates whose vertices and rings are clean (their verdict stands).
  *   drt_rm_flip_eval/apply  the same for edge flips (d_edge_rows int64 [E,2]: the two directed-edge rows 3f+k of every edge; d_quad int64
- *                           [E,6] = a b c d f1 f2 of a flip that passes; d_query float64 [E,3] the midpoint of the new edge; d_lock uint32 [V]).
+ *                           [E,6] = a b c d f1 f2 of a flip that passes; d_query float64 [E,3] the midpoint of the new edge; d_lock uint32 [V], d_dirty uint8 [V] and
+ *                           sub_rounds as above).
  *   drt_rm_smooth_target    tangential relaxation targets float64 [V,3].
  *   drt_rm_face_agreement   cosine between each face normal and the consensus of its corners, float64 [F] (before a move).
  *   drt_rm_move_check       after vertices moved: every face that degenerated or folded (against d_a0) takes its three vertices back from
@@ -296,11 +299,12 @@ int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d
                          const double* d_vn, const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, double max_len, int max_q,
                          uint8_t* d_ok, int32_t* d_n_query, double* d_query, void* stream);
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
-                          const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, uint32_t seed, const double* d_length,
-                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, int32_t* d_n_done, void* stream);
+                          const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, const double* d_length,
+                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream);
 int drt_rm_flip_eval(const int64_t* d_edges, int64_t n_edges, const int64_t* d_edge_rows, const int64_t* d_faces, const double* d_verts, const double* d_vn,
                      const int64_t* d_vf_start, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream);
-int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, uint32_t* d_lock, int32_t* d_n_done, void* stream);
+int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, uint32_t* d_lock, uint8_t* d_dirty,
+                      int sub_rounds, int32_t* d_n_done, void* stream);
 int drt_rm_smooth_target(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
                          double* d_target, void* stream);
 int drt_rm_face_agreement(const int64_t* d_faces, const double* d_verts, const double* d_vn, int64_t n_faces, double* d_a0, void* stream);

@@ -1,0 +1,29 @@
+"""Where a device remesh call spends its time: per step (split / collapse / flip / smooth / project), rounds, host syncs.
+usage (via gpurun): python tools/ubench/remesh_probe.py [target_len_factor]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from drt_amd import diffrender as Render, mesh_io, remesh_gpu as RG
+
+factor = float(sys.argv[1]) if len(sys.argv) > 1 else 0.9
+mesh = mesh_io.subdivide_midpoint(mesh_io.read_ply("data/horse_vh.ply"))
+scene = Render.Scene(mesh, 0)
+L = scene.mean_len * factor
+V, F = scene.vertices.detach(), scene.faces
+T = {}
+def timed(name, fn):
+    def wrap(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize(); T[name] = T.get(name, 0.0) + time.perf_counter() - t0
+        return r
+    return wrap
+for name in ("split_long_edges", "collapse_short_edges", "flip_edges", "smooth_tangential", "project_to_surface", "compact", "edges", "csr"):
+    setattr(RG._Work, name, timed(name, getattr(RG._Work, name)))
+for rep in range(3):
+    T.clear()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    V2, F2, stats = RG.isotropic_remesh_gpu(V, F, L, surface=scene.optix_mesh, return_stats=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"remesh {len(F)} -> {len(F2)} faces, target {L:.3f}: {1e3 * dt:.1f} ms  {stats}")
+    print("   " + "  ".join(f"{k} {1e3 * v:.1f}" for k, v in sorted(T.items(), key=lambda kv: -kv[1])), "(ms; edges / csr are inside the steps)")
