@@ -324,7 +324,7 @@ def main():
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it; 0: eager; "
-                         "-1 (default): graph when N > 1 AND the rank's share is below 2^24 camera rays -- a chain of small launches whose host enqueue "
+                         "-1 (default): graph when N > 1 AND the rank's share is below 2^25 camera rays -- a chain of small launches whose host enqueue "
                          "and launch gaps a replay removes (9 views: 0.69 vs 0.72 ms; at 36 views a replay is 13 %% slower than eager) -- eager otherwise; "
                          "falls back to eager if the capture fails")
     ap.add_argument("--no-cpu-baseline", action="store_true")

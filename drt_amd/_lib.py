@@ -32,6 +32,7 @@ SIGNATURES = {
     "drt_bvh_check": (_c.c_int, [_P, _P, _c.POINTER(_I64), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32)]),
     "drt_bvh_sorted_faces": (_c.c_int, [_P, _P, _P]),
     "drt_build_params": (_c.c_int, [_P, _c.POINTER(_c.c_float), _P]),
+    "drt_tree_mode": (_c.c_int, [_P, _c.c_int, _c.c_int]),
     "drt_render_forward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "drt_render_backward": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
     "drt_ray_loss": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),

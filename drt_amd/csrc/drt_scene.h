@@ -88,6 +88,11 @@ struct drt_scene {
     bool build_pending = false;    // a build was enqueued on build_stream: consumers of the tree wait for build_done
     bool order_valid = false;      // idx[sorted_buf] holds the Morton order of the last build over the CURRENT faces (k_tri_flat's order)
     int sorted_buf = 0;            // which of keys[] / idx[] the last sort ended in (three radix passes end in 1, four in 0)
+    // DRT_TREE (drt_tree_mode): 0 = the LBVH is rebuilt from the Morton sort on every update (the default: BASELINE's "LBVH rebuilt each
+    // iteration"); 1 = its TOPOLOGY is kept for `rebuild_every` updates, the updates in between only refit the boxes and re-quantise the
+    // wide nodes; 2 = a binned-SAH topology built on the host at every update_mesh, refit-only on every update_vert.
+    int tree_mode = 0, rebuild_every = 1, since_full = 0;
+    bool topology_fixed = false;   // mode 2: the host's topology is installed for the current faces
     uint32_t* bounds_acc = nullptr;  // [6] scene-box accumulators of drt_update_vert_f64's cast kernel (order-preserving uint encodings; put back to +-inf by the build that read them)
     bool async_build = true;       // DRT_ASYNC_BUILD=0: build on the caller's stream
     uint32_t *keys[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};

@@ -149,6 +149,11 @@ class optix_mesh:
         self.wide_depth = wide.value
         return v.value, hgt.value
 
+    def tree_mode(self, mode, rebuild_every=1):
+        """0: full LBVH build per update (default); 1: topology kept for ``rebuild_every`` updates (refit in between); 2: binned-SAH topology
+        from the host at every update_mesh, refit per update_vert (include/drt_hip.h: drt_tree_mode)."""
+        _lib.check(_lib.lib().drt_tree_mode(self._h, int(mode), int(rebuild_every)))
+
     def build_params(self):
         """(lo[3], 1/extent[3], leaf padding) of the scene box the last build derived from the vertices; synchronises."""
         out = (ctypes.c_float * 7)()

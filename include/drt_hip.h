@@ -73,6 +73,13 @@ int drt_intersect_bruteforce(drt_scene_t* s, const float* d_rays, int64_t n_rays
 int drt_bvh_check(drt_scene_t* s, void* stream, int64_t* n_violations, int32_t* height, int32_t* wide_depth);
 /* Diagnostic: copy the Morton-sorted face order (int32 [F]) to d_order. */
 int drt_bvh_sorted_faces(drt_scene_t* s, int32_t* d_order, void* stream);
+/* How updates treat the tree (also DRT_TREE / DRT_REBUILD_EVERY at drt_create).  mode 0 (default): every update is a full LBVH build --
+ * Morton keys, radix sort, Karras hierarchy, refit, 4-wide collapse -- as the reference's OptiX model is rebuilt on every update_vert
+ * (optix_extend.cpp:23-27, 61-67).  mode 1: the LBVH's topology is kept for `rebuild_every` updates; the updates in between refit the
+ * boxes and re-quantise the wide nodes only (3 launches instead of 7).  mode 2: a binned-SAH topology is built on the HOST at every
+ * drt_update_mesh (one device -> host copy of the mesh, milliseconds) and every drt_update_vert* refits it.  Results do not depend on the
+ * mode: boxes only decide which triangles are tested (drt_bvh_check validates any of the trees). */
+int drt_tree_mode(drt_scene_t* s, int mode, int rebuild_every);
 /* Diagnostic: the scene box the last build derived from the vertices -- out7 = lo[3], 1/extent[3], leaf padding (float32; the margin of
  * the hit-point test is half the padding); host-synchronising.  What a replayed capture of an update must reproduce. */
 int drt_build_params(drt_scene_t* s, float* out7, void* stream);

@@ -80,6 +80,9 @@ def parse(path, counter):
         if m:
             cur = (m.group(1), int(m.group(2)))
             continue
+        if line and not line.startswith(" "):
+            cur = None          # another kernel's header (a torch kernel: not kept) -- its counters must not land on the previous name
+            continue            # (round 3: k_tri_flat, 5.8 MB per launch, was listed with 422 MB this way)
         m = re.match(r"\s+%s\s+total=(\S+)" % counter, line)
         if m and cur:
             res[cur[0]] = (float(m.group(1)), cur[1])
