@@ -324,8 +324,8 @@ def main():
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it; 0: eager; "
-                         "-1 (default): graph when N > 1 AND the rank's share is below 2^25 camera rays -- a chain of small launches whose host enqueue "
-                         "and launch gaps a replay removes (9 views: 0.69 vs 0.72 ms; at 36 views a replay is 13 %% slower than eager) -- eager otherwise; "
+                         "-1 (default): graph when N > 1 AND the rank's share is below 2^22 camera rays (shares that do not recycle their outputs: above, the eager "
+                         "step is the faster one -- 9 views: 0.67 vs 0.69 ms, 36 views: 1.16 vs 1.56) -- eager otherwise; "
                          "falls back to eager if the capture fails")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -404,12 +404,13 @@ def main():
         return O.full_batch_step(scene, local_views, init_vertices, parameter, opt, w_ray, fused=args.mode == "fused")
 
     if args.graph < 0:
-        # Measured per share on one GPU (profiles/r03_scaling_proxy.txt): a replay beats the eager step where the step is a chain of small
-        # launches -- 9 views: 0.68 vs 0.72 ms; 18: 0.88 vs 0.92; 36: 1.55 vs 1.40 (a replayed graph overlaps the internal streams worse
-        # than eager launches do, and the ahead-of-time fills of calls of >= 2^25 rays are not part of a capture).  So: shares below 2^25
-        # camera rays only.
+        # Measured per share on one GPU.  Round 3 (profiles/r03_scaling_proxy.txt): a replay beat the eager step where the step is a chain of
+        # small launches (9 views: 0.68 vs 0.72 ms; 18: 0.88 vs 0.92; 36: 1.55 vs 1.40).  Round 4 (profiles/r04_scaling_proxy.txt): the eager
+        # step renders into the previous step's outputs (diffrender.RECYCLE_OUTPUTS, not available inside a capture, whose fills are part of
+        # the graph) and is the faster one at every share that recycles: 36 views 1.16 vs 1.56 ms, 18: 0.81 vs 0.86, 9: 0.67 vs 0.69.  So: a
+        # graph only for shares below RECYCLE_MIN_RAYS (2^22 camera rays: a chain of tiny launches, no recycling either way).
         # (Not over gloo -- the functional two-ranks-on-one-GPU check: its all-reduce goes through the host and cannot be captured.)
-        small = len(my_views) * P < (1 << 25)
+        small = len(my_views) * P < (Render.RECYCLE_MIN_RAYS if Render.RECYCLE_OUTPUTS else (1 << 25))
         args.graph = 1 if world > 1 and small and os.environ.get("DRT_BENCH_GRAPH", "1") != "0" and os.environ.get("DRT_DIST_BACKEND") != "gloo" else 0
     graph = None
     if args.graph:

@@ -2,7 +2,7 @@
 # The measurement batch whose outputs go to profiles/ at the end of a round (run on the GPU box through gpurun).
 # usage: bash tools/final_runs.sh <prefix>      e.g. r02
 set -u
-P=${1:-r03}
+P=${1:-r04}
 O=gpurun_out/final_$P; mkdir -p $O
 {
   for cfg in "--mesh hand --res 512 --views 72" "--mesh mouse --res 1024 --views 72" "--mesh horse --res 1024 --views 72" "--mesh monkey --res 1024 --views 72" "--mesh monkey --res 1024 --views 144"; do
@@ -34,8 +34,21 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager, DRT_MEGA_MAX_LOG2=25 (k_path)', d['ms_per_step'], 'ms/step')"
   done
 } > $O/scaling_proxy.txt 2>&1
+{
+  # drt_tree_mode: full LBVH build per update (default) / its topology kept for 50 updates / binned-SAH topology from the host, refit per update
+  for a in "" "--distance-factor 1.1" "--views 18" "--views 9"; do
+    for e in "DRT_TREE=0" "DRT_TREE=1 DRT_REBUILD_EVERY=50" "DRT_TREE=2"; do
+      echo "bench.py $a :: $e :: $(env $e DRT_BENCH_NOPROF=1 python bench.py $a --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], 'ms/step')")"
+    done
+  done
+  # outputs recycled (default) / zeroed ahead of time (round 3) / filled inside the call
+  for e in "DRT_RECYCLE_OUTPUTS=1" "DRT_RECYCLE_OUTPUTS=0" "DRT_RECYCLE_OUTPUTS=0 DRT_PREFILL_NEXT=0"; do
+    echo "bench.py :: $e :: $(env $e python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], 'ms/step')")"
+  done
+} > $O/modes.txt 2>&1
 python tools/ubench/trace_repeat.py 9 2>&1 | grep -v amdgpu > $O/trace_repeat.txt
-python tools/ubench/reorder_probe.py 2>&1 | grep -v amdgpu > $O/reorder_probe.txt
+python tools/ubench/remesh_probe.py 0.9 2>&1 | grep -v amdgpu > $O/remesh_probe.txt
+python tools/ubench/vh_probe.py 2>&1 | grep -v amdgpu | head -3 > $O/vh_probe.txt
 for r in gpu host; do REMESH=$r python tools/recon_trend.py 2>&1 | grep -v amdgpu > $O/recon_trend_$r.txt; done
 python -m drt_amd.reconstruct --name monkey --views 144 --res 1024 2>&1 | grep -v amdgpu > $O/recon_monkey_144views.txt
 # the launch line of the driver's multi-GPU runs, two ranks on this box's one GPU (gloo instead of RCCL): functional check of bench.py's N > 1 path
@@ -43,6 +56,10 @@ DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --n
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
 bash tools/profile.sh $P > $O/profile.log 2>&1
 PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 DRT_PREFILL_NEXT=0 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
+# the regime real captures live in: the object fills the image (camera at 1.1 extents)
+bash tools/profile.sh ${P}_tight --distance-factor 1.1 > $O/profile_tight.log 2>&1
+PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 DRT_PREFILL_NEXT=0 bash tools/profile.sh ${P}_tight_serial --distance-factor 1.1 > $O/profile_tight_serial.log 2>&1
+bash tools/step_timeline.sh $O/step_timeline_tight.txt --distance-factor 1.1 > /dev/null 2>&1
 # the bench lines LAST, with this build's own counters: bench.py prices k_trace's live launch time against SQ_INSTS_VALU of profiles/pmc.json
 python tools/make_pmc_json.py gpurun_out/$P profiles/pmc.json dropin > /dev/null && cp profiles/pmc.json $O/pmc.json
 # (measured twice: right after the counter passes above the same box runs the step 3 % slower -- 2.40 vs 2.33 ms -- than in a call of its own; let it settle)
