@@ -1489,6 +1489,7 @@ int pipeline_blocks_per_cu() {
 
 extern "C" {
 
+static int flush_clean(drt_scene* s, hipStream_t st);
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
                        int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h,
@@ -1525,8 +1526,19 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         if (matched != s->n_prefill) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
         s->n_prefill = 0;     // one shot (launch_chunk waits for prefill_done in front of the first kernel that writes those outputs)
     }
-    int rc = fork_streams(s, st, pl.streams);
+    // drt_outputs_clean's rows.  A trusted-grid call through the projection pass writes no row of the dense outputs before k_shade2, which
+    // waits for prefill_done: the zeroing then runs on the caller's stream BEHIND the fork, beside the pipelines' first stages.  Any other
+    // call (k_cull writes every row straight away) gets it in front of the fork.
+    bool clean_late = s->clean.rows != nullptr && (grid_mode & 3) == DRT_GRID_TRUST && d_grid_cache != nullptr;
+    for (int j = 0; j < pl.count && clean_late; ++j) {
+        const int64_t b = j * pl.size, n = n_rays - b < pl.size ? n_rays - b : pl.size;
+        clean_late = raster_on(s, n, tile_w, tile_h);
+    }
+    int rc = DRT_OK;
+    if (s->clean.rows && !clean_late) { rc = flush_clean(s, st); if (rc) return rc; }
+    rc = fork_streams(s, st, pl.streams);
     if (rc) return rc;
+    if (s->clean.rows) { rc = flush_clean(s, st); if (rc) return rc; }
     for (int j = 0; j < pl.count; ++j) {
         drt_scene::Sub& w = s->sub[j % pl.streams];
         const int64_t b = j * pl.size;
@@ -1570,6 +1582,17 @@ int drt_prefill_zero(drt_scene_t* s, void* d_buf, int64_t bytes, void* stream) {
     return DRT_OK;
 }
 
+static int flush_clean(drt_scene* s, hipStream_t st) {
+    const drt_scene::Clean c = s->clean;
+    s->clean = drt_scene::Clean{};
+    if (!c.rows) return DRT_OK;
+    { StageTimer t(s, st, kStageFill);
+      k_unwrite_rows<<<4 * s->n_cu, 256, 0, st>>>(c.ori, c.dir, c.mask, c.rows, c.n_rows, c.n); }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->prefill_done, st));
+    return DRT_OK;
+}
+
 int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint8_t* d_mask, int64_t n_rays,
                       const int32_t* d_valid_idx, const int64_t* d_n_valid, void* stream) {
     CHECK_SCENE(s);
@@ -1581,10 +1604,11 @@ int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint
         HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
         s->n_prefill = 0;
     }
-    { StageTimer t(s, st, kStageFill);
-      k_unwrite_rows<<<4 * s->n_cu, 256, 0, st>>>(d_out_ori, d_out_dir, d_mask, d_valid_idx, d_n_valid, n_rays); }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->prefill_done, st));
+    // The zeroing itself is enqueued by the drt_render_forward that takes these outputs, on its caller's stream BEHIND the fork of the
+    // pipelines (that stream is idle until the join, and nothing writes a row of the outputs before k_shade2, which waits for
+    // prefill_done): 30 us that no longer sit between the vertex update and the projection pass.
+    if (s->clean.rows) { int rc = flush_clean(s, st); if (rc) return rc; }          // an earlier request nobody rendered into: honour it now
+    s->clean = drt_scene::Clean{d_out_ori, d_out_dir, d_mask, n_rays, d_valid_idx, d_n_valid};
     s->prefill[0].ptr = d_out_ori; s->prefill[0].bytes = (int64_t)sizeof(double) * 3 * n_rays;
     s->prefill[1].ptr = d_out_dir; s->prefill[1].bytes = (int64_t)sizeof(double) * 3 * n_rays;
     s->prefill[2].ptr = d_mask;    s->prefill[2].bytes = 3 * n_rays;

@@ -143,6 +143,8 @@ struct drt_scene {
     hipEvent_t fork_ev = nullptr;
     // drt_prefill_zero: dense outputs of the NEXT drt_render_forward zeroed ahead of time on the build stream (idle after a forward's
     // join, i.e. during the caller's loss / backward / optimiser tail); a forward whose out_ori / out_dir / mask IS such a buffer skips that fill
+    // drt_outputs_clean: the rows to zero, launched by the next drt_render_forward on the caller's stream BEHIND its fork (idle until the join)
+    struct Clean { double* ori = nullptr; double* dir = nullptr; uint8_t* mask = nullptr; int64_t n = 0; const int32_t* rows = nullptr; const int64_t* n_rows = nullptr; } clean;
     struct Prefill { const void* ptr = nullptr; int64_t bytes = 0; };
     Prefill prefill[3];
     int n_prefill = 0;
