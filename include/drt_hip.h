@@ -173,8 +173,10 @@ int drt_prefill_wait(drt_scene_t* s, void* stream);
 /* The outputs of an EARLIER drt_render_forward (same scene or not) offered again as the outputs of the next one of `n_rays` rays: they
  * are zeros in every row but the rows that call listed in d_valid_idx / d_n_valid (a call's dense outputs are zero wherever its mask is
  * -- the reference's torch.zeros + index_put, DiffRender.py:421-431 -- and its list of completed paths is exactly the set rows), so
- * zeroing THOSE rows (51 B per listed row, on `stream`) leaves the three buffers as freshly zeroed ones, and the next
- * drt_render_forward on this scene with exactly these pointers does not fill them again (the fills are 51 B per RAY: 3.85 GB of the
+ * zeroing THOSE rows (51 B per listed row) leaves the three buffers as freshly zeroed ones, and the next drt_render_forward on this scene
+ * with exactly these pointers does not fill them again.  The zeroing kernel is enqueued BY that drt_render_forward (same `stream`: behind
+ * the fork of its internal pipelines when the call is a trusted-grid one, in front of it otherwise; by the next drt_outputs_clean if no
+ * render call comes in between) (the fills are 51 B per RAY: 3.85 GB of the
  * 72 x 1024^2 step, its one HBM-bound stage).  The caller vouches that nothing else wrote the buffers since that earlier call and that
  * nobody else still reads them (drt_amd/diffrender.py: storage use counts and version counters); entries are forgotten at the next
  * drt_render_forward, like drt_prefill_zero's.  Not while a graph is being captured. */
