@@ -149,7 +149,10 @@ PREFILL_MIN_RAYS = int(os.environ.get("DRT_PREFILL_MIN_RAYS", 1 << 25))         
 # returns are fresh tensor objects (detached aliases: same storage, same version counter) that nothing else references; a caller who
 # keeps its outputs alive simply gets fresh allocations and the fills, as before.  The price: the last outputs (51 B per ray) stay
 # allocated between calls.  Not inside a graph capture (a replay must own its buffers).
-RECYCLE_OUTPUTS = os.environ.get("DRT_RECYCLE_OUTPUTS", "1") != "0"
+# (The use count of a storage is read through torch._C._storage_Use_Count, which torch's own CUDA-graph trees rely on; a torch without it
+# simply does not recycle.  As with any caching allocator, a caller who used the outputs on ANOTHER stream must have ordered that work in front
+# of the stream of its next render call before dropping them.)
+RECYCLE_OUTPUTS = os.environ.get("DRT_RECYCLE_OUTPUTS", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
 RECYCLE_MIN_RAYS = int(os.environ.get("DRT_RECYCLE_MIN_RAYS", 1 << 22))
 
 
