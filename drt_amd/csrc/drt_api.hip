@@ -51,6 +51,7 @@ int drt_create(int device, drt_scene_t** out) {
         e = hipMemcpy(s->bounds_acc, init, sizeof(init), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->seg_counts, sizeof(unsigned) * drt_scene::kMaxSeg);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->build_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->prefill_fork, hipEventDisableTiming);
@@ -115,7 +116,7 @@ void drt_destroy(drt_scene_t* s) {
     if (s->build_stream) (void)hipStreamDestroy(s->build_stream);
     (void)hipFree(s->params);
     (void)hipFree(s->slow_stack);
-    (void)hipFree(s->scratch); (void)hipFree(s->bounds_acc);
+    (void)hipFree(s->scratch); (void)hipFree(s->bounds_acc); (void)hipFree(s->seg_counts);
     (void)hipFree(s->b1_list); (void)hipFree(s->b1_redo); (void)hipFree(s->b1_count);
     for (int j = 0; j < drt_scene::kMaxSub; ++j) {
         drt_scene::Sub& w = s->sub[j];

@@ -818,6 +818,31 @@ __global__ void k_store_count(const unsigned* __restrict__ count, int64_t* __res
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = (int64_t)*count;
 }
 
+// Behind the join of a call cut into sub-batches: segment j of the list of completed paths (written at offset `src` = the index of the
+// sub-batch's first ray) moves down behind the segments before it.  dst <= src always; when the two ranges do not overlap every block
+// copies its share, otherwise (more than half of the rays complete) block 0 copies chunk by chunk in ascending order.  The launch for the
+// last segment also stores the total.
+__global__ void __launch_bounds__(256) k_join_lists(int32_t* list, const unsigned* __restrict__ counts, int j, int64_t src, int last,
+                                                    unsigned* total_u, int64_t* total_i64) {
+    int64_t dst = 0;
+    for (int k = 0; k < j; ++k) dst += counts[k];
+    const int64_t len = counts[j];
+    if (last && blockIdx.x == 0 && threadIdx.x == 0) { *total_u = (unsigned)(dst + len); if (total_i64) *total_i64 = dst + len; }
+    if (dst == src || len == 0) return;
+    if (dst + len <= src) {
+        for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < len; k += (int64_t)gridDim.x * blockDim.x) list[dst + k] = list[src + k];
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    for (int64_t base = 0; base < len; base += blockDim.x) {
+        const int64_t k = base + threadIdx.x;
+        const int32_t v = k < len ? list[src + k] : 0;
+        __syncthreads();
+        if (k < len) list[dst + k] = v;
+        __syncthreads();
+    }
+}
+
 // drt_outputs_clean: the rows a render call left non-zero are exactly its list of completed paths; zero them again (51 B per listed row
 // instead of 51 B per ray of the call).
 __global__ void __launch_bounds__(256) k_unwrite_rows(double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
@@ -1157,10 +1182,14 @@ __global__ void __launch_bounds__(256) k_loss_bwd_listed(PathCtx c, const double
                                                          const double* __restrict__ screen_pixel, const uint8_t* __restrict__ valid,
                                                          const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
                                                          const int32_t* __restrict__ paths, const int64_t* __restrict__ n_paths,
+                                                         const unsigned* __restrict__ first_ptr, const unsigned* __restrict__ n32_ptr,
                                                          double* loss, double* grad_verts) {
     __shared__ int32_t hkeys[kHashSize];
     __shared__ double hsums[3 * kHashSize];
-    const int64_t n = *n_paths;
+    // the listed range: [*first_ptr (0 without one), *n32_ptr or *n_paths)
+    const int64_t first = first_ptr ? (int64_t)*first_ptr : 0;
+    paths += first;
+    const int64_t n = (n32_ptr ? (int64_t)*n32_ptr : *n_paths) - first;
     const HashAdd3 add{hkeys, hsums, grad_verts};
     double acc = 0.0;
     for (int64_t base = blockIdx.x * (int64_t)kBwdBatch; base < n; base += (int64_t)gridDim.x * kBwdBatch) {
@@ -1506,6 +1535,10 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, false); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
+    // the list of completed paths by sub-batch (drt_scene::segs): only when the call is cut into a few sub-batches
+    const bool segmented = d_valid_idx != nullptr && pl.count >= 2 && pl.count <= drt_scene::kMaxSeg;
+    if (segmented) HIP_TRY(hipMemsetAsync(s->seg_counts, 0, sizeof(unsigned) * pl.count, st));
+    s->segs = drt_scene::Segs{};
     grid_mode &= ~kIntMask;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
@@ -1544,22 +1577,30 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         const int64_t b = j * pl.size;
         const int64_t n = n_rays - b < pl.size ? n_rays - b : pl.size;
         const PathCtx pc = sub_ctx(s, w, d_verts, ior_int, ior_ext);
-        const Pipe p = pipe_of(s, w);
+        Pipe p = pipe_of(s, w);
+        int32_t* vlist = d_valid_idx;
+        if (segmented) { p.valid = s->seg_counts + j; vlist = d_valid_idx + b; }      // this sub-batch's own segment and counter
         HIP_TRY(hipMemsetAsync(w.qcount, 0, kQCount * sizeof(unsigned), w.stream));
         bool finished = false;
         rc = launch_chunk<false>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
                                  d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h),
-                                 st, b, d_valid_idx, &finished);
+                                 st, b, vlist, &finished);
         if (rc) return rc;
         if (!finished) {
             StageTimer t(s, w.stream, kStageFinish);
-            k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, d_valid_idx);
+            k_finish<<<8 * s->n_cu, kPathBlock, 0, w.stream>>>(d_out_ori + 3 * b, d_out_dir + 3 * b, d_mask + 3 * b, d_face2 + b, p, b, vlist);
         }
         if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 0, raster_on(s, n, tile_w, tile_h), finished);
     }
     rc = join_streams(s, st, pl.streams);
     if (rc) return rc;
-    if (d_n_valid) k_store_count<<<1, 64, 0, st>>>(s->vcount, d_n_valid);
+    if (segmented) {
+        for (int j = 1; j < pl.count; ++j)
+            k_join_lists<<<2 * s->n_cu, 256, 0, st>>>(d_valid_idx, s->seg_counts, j, (int64_t)j * pl.size, j + 1 == pl.count, s->vcount, d_n_valid);
+        s->segs = drt_scene::Segs{d_valid_idx, pl.count, 0};      // (sub-batch 0 runs on internal stream 0)
+    } else if (d_n_valid) {
+        k_store_count<<<1, 64, 0, st>>>(s->vcount, d_n_valid);
+    }
     if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1714,7 +1755,39 @@ int drt_ray_loss_listed_grad(drt_scene_t* s, const double* d_verts, const double
     hipStream_t st = (hipStream_t)stream;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
     { StageTimer t(s, st, kStageBackward);
-      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, d_loss, d_grad_verts); }
+      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, nullptr, nullptr, d_loss, d_grad_verts); }
+    if (s->prof_on) s->prof_stream = st;
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_ray_loss_listed_grad_split(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                                   double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                                   const double* d_screen_pixel, const uint8_t* d_valid, const int32_t* d_paths, const int64_t* d_n_paths,
+                                   double* d_loss, double* d_grad_verts, void* stream) {
+    CHECK_BUILT(s);
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    // the list of the last render call, cut into sub-batches on different internal streams, outside a capture: otherwise the plain form
+    if (s->segs.list != d_paths || s->segs.n < 2 || cs != hipStreamCaptureStatusNone || n_rays <= 0)
+        return drt_ray_loss_listed_grad(s, d_verts, d_origin, d_dir, n_rays, ior_int, ior_ext, d_face1, d_face2, d_screen_pixel, d_valid, d_paths, d_n_paths,
+                                        d_loss, d_grad_verts, stream);
+    if (n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
+    if (!d_verts || !d_origin || !d_dir || !d_face1 || !d_face2 || !d_screen_pixel || !d_valid || !d_n_paths || !d_loss || !d_grad_verts)
+        return fail(DRT_E_INVALID, "null pointer argument");
+    const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
+    drt_scene::Sub& w = s->sub[s->segs.stream0];
+    // segment 0 (never moved by the join) on the internal stream that produced it: it starts as soon as that pipeline is through, beside
+    // the tail of the other one; the rest of the list on the caller's stream, behind the join; the caller's stream then waits for both.
+    { StageTimer t(s, w.stream, kStageBackward);
+      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, w.stream>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, nullptr, nullptr,
+                                                                  s->seg_counts, d_loss, d_grad_verts); }
+    HIP_TRY(hipEventRecord(w.done, w.stream));
+    { StageTimer t(s, st, kStageBackward);
+      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, s->seg_counts,
+                                                           nullptr, d_loss, d_grad_verts); }
+    HIP_TRY(hipStreamWaitEvent(st, w.done, 0));
     if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;

@@ -145,6 +145,13 @@ struct drt_scene {
     // join, i.e. during the caller's loss / backward / optimiser tail); a forward whose out_ori / out_dir / mask IS such a buffer skips that fill
     // drt_outputs_clean: the rows to zero, launched by the next drt_render_forward on the caller's stream BEHIND its fork (idle until the join)
     struct Clean { double* ori = nullptr; double* dir = nullptr; uint8_t* mask = nullptr; int64_t n = 0; const int32_t* rows = nullptr; const int64_t* n_rows = nullptr; } clean;
+    // The list of completed paths of the last drt_render_forward, by sub-batch: sub-batch j appends into the caller's list at its own
+    // offset (its first ray's index: a sub-batch cannot complete more paths than it has rays) under its own counter seg_counts[j]; behind
+    // the join k_join_lists closes the gaps.  Segment 0 is never moved -- what lets drt_ray_loss_listed_grad_split start on it while the
+    // other pipeline is still tracing.
+    static constexpr int kMaxSeg = 32;
+    unsigned* seg_counts = nullptr;            // device [kMaxSeg]
+    struct Segs { const int32_t* list = nullptr; int n = 0; int stream0 = 0; } segs;
     struct Prefill { const void* ptr = nullptr; int64_t bytes = 0; };
     Prefill prefill[3];
     int n_prefill = 0;

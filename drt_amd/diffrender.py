@@ -181,8 +181,32 @@ class _OutputPool:
             self.entries.pop(0)
 
 
+# SPLIT_LOSS: the loss + gradient pass over the completed paths of the call's FIRST sub-batch starts on the internal stream that produced
+# them, beside the tail of the other pipeline, instead of behind the join (drt_ray_loss_listed_grad_split).  For that its two accumulators
+# must have been zeroed before the render call was enqueued (render_transparent creates them: `_GradLink.pre`), and the targets must have
+# been complete by then -- known when the very same target tensors (object, storage, version) went through ray_loss before.
+SPLIT_LOSS = os.environ.get("DRT_SPLIT_LOSS", "1") != "0"
+SPLIT_LOSS_MIN_RAYS = int(os.environ.get("DRT_SPLIT_LOSS_MIN_RAYS", 1 << 25))          # below, a call is not cut into sub-batches (DRT_MIN_SUB_LOG2 = 24 per sub-batch)
+_seen_targets = {}
+
+
+def _targets_seen_before(sp, valid):
+    """True when these very tensors (same objects, same storage, unchanged version counters) were the targets of an earlier ray_loss:
+    their content was complete long before the render call whose loss is being taken.  Registers them either way."""
+    ok = True
+    for t in (sp, valid):
+        rec = _seen_targets.get(id(t))
+        if not (rec is not None and rec[0]() is t and rec[1] == t._version and rec[2] == t.data_ptr()):
+            ok = False
+            if len(_seen_targets) > 4096:
+                _seen_targets.clear()
+            _seen_targets[id(t)] = (weakref.ref(t), t._version, t.data_ptr())
+    return ok
+
+
 class _GradLink:
     def __init__(self):
+        self.pre = None        # (stash zeros_like(vertices), loss zeros(())) created before the render call was enqueued (SPLIT_LOSS)
         self.pending = []
         self._token = None
         self.paths = None
@@ -256,6 +280,8 @@ class _RenderTransparent(torch.autograd.Function):
             counts = tuple(_use_count(t) for t in bases)          # with nobody but these three names holding them
         face1 = torch.empty(n, dtype=torch.int32, device=o.device)
         face2 = torch.empty(n, dtype=torch.int32, device=o.device)
+        if (SPLIT_LOSS and need_bwd and EAGER_LOSS_GRAD and link is not None and not capturing and n >= SPLIT_LOSS_MIN_RAYS):
+            link.pre = (torch.zeros_like(v), torch.zeros((), dtype=torch.float64, device=o.device))
         want_list = need_bwd or recycle
         valid_idx = torch.empty(n, dtype=torch.int32, device=o.device) if want_list else None
         n_valid = torch.empty(1, dtype=torch.int64, device=o.device) if want_list else None
@@ -350,8 +376,14 @@ class _RayLoss(torch.autograd.Function):
             if eager:
                 # loss + unit-seed vertex gradient in one pass over the completed paths (see EAGER_LOSS_GRAD)
                 scene, v, o, d, face1, face2, ior = link.render
-                ctx.stash = torch.zeros_like(v)
-                _lib.check(_lib.lib().drt_ray_loss_listed_grad(
+                pre, link.pre = link.pre, None
+                early = pre is not None and _targets_seen_before(screen_pixel, valid) and sp.data_ptr() == screen_pixel.data_ptr() and va.data_ptr() == valid.data_ptr()
+                if early:      # accumulators zeroed before the render call: the head of the list can be processed beside the pipelines (SPLIT_LOSS)
+                    ctx.stash, loss = pre
+                else:
+                    ctx.stash = torch.zeros_like(v)
+                fn = _lib.lib().drt_ray_loss_listed_grad_split if early else _lib.lib().drt_ray_loss_listed_grad
+                _lib.check(fn(
                     scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, ior[0], ior[1], face1.data_ptr(), face2.data_ptr(),
                     sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(), link.paths[1].data_ptr(), loss.data_ptr(), ctx.stash.data_ptr(), _stream()))
             elif own:

@@ -191,6 +191,15 @@ int drt_ray_loss_listed_grad(drt_scene_t* s, const double* d_verts, const double
                              double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
                              const double* d_screen_pixel, const uint8_t* d_valid, const int32_t* d_paths, const int64_t* d_n_paths,
                              double* d_loss, double* d_grad_verts, void* stream);
+/* The same, started EARLY on the part of the list that is ready early: a drt_render_forward cut into sub-batches keeps the completed paths
+ * of its first sub-batch as the head of d_valid_idx (never moved by the join); when d_paths is that list, the head is processed on the
+ * internal stream that produced it -- beside the tail of the other pipeline -- and only the rest behind the join on `stream`, which then
+ * waits for both.  PRECONDITIONS (the caller's): d_loss and d_grad_verts were zeroed on `stream` BEFORE that drt_render_forward was
+ * enqueued, and d_screen_pixel / d_valid were complete by then.  Any other list, or a capture: exactly drt_ray_loss_listed_grad. */
+int drt_ray_loss_listed_grad_split(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                                   double ior_int, double ior_ext, const int32_t* d_face1, const int32_t* d_face2,
+                                   const double* d_screen_pixel, const uint8_t* d_valid, const int32_t* d_paths, const int64_t* d_n_paths,
+                                   double* d_loss, double* d_grad_verts, void* stream);
 /* Adjoint of drt_render_forward followed by drt_ray_loss, for the rays drt_ray_loss listed (d_rows / *d_n_rows):
  * grad_verts [V,3] += *d_scale * d ray_loss / d vertices.  Equivalent to drt_scale_rows3 + drt_render_backward with the
  * dense d loss / d out_dir, without that [N,3] tensor (zero in all but the listed rows) ever being written or read:

@@ -153,3 +153,49 @@ def test_gradients_and_loss_through_recycled_outputs(setup):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)
     scale = np.abs(res[0][1]).max()
     assert scale > 1e-3 and np.abs(res[0][1] - res[1][1]).max() <= 1e-11 * scale
+
+
+_SPLIT_SCRIPT = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+from conftest import IOR, data_path
+from drt_amd import diffrender as Render, mesh_io, optim as O, views
+RES, NV = 128, 4
+Render.intIOR = IOR; Render.resx = Render.resy = RES
+mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+c, ext = views.mesh_frame(mesh.vertices)
+cams = views.turntable_cameras(c, ext, 8, RES, RES)
+rays = [views.generate_ray(RES, RES, cams[k][3], cams[k][2], device="cuda") for k in range(NV)]
+o = torch.cat([r[0] for r in rays]).contiguous(); d = torch.cat([r[1] for r in rays]).contiguous()
+rng = np.random.default_rng(5)
+sp = torch.tensor(rng.standard_normal((o.shape[0], 3)) * 40.0 + np.asarray(c) + np.array([0.0, 0.0, 150.0]), device="cuda")
+valid = torch.tensor(rng.random(o.shape[0]) > 0.1, device="cuda")
+scene = Render.Scene(mesh, 0)
+init_vertices, parameter, opt = O.setup_opt(scene, 0.1, O.HyperParams, hook=False, fused=True)
+losses, early = [], 0
+orig = Render._lib.lib().drt_ray_loss_listed_grad_split
+for step in range(6):
+    losses.append(O.full_batch_step(scene, [(sp, valid, o, d)], init_vertices, parameter, opt, 40 * 217.5 / RES / RES, fused=False).item())
+torch.cuda.synchronize()
+segs = int(scene.optix_mesh._h is not None)
+print(json.dumps({"losses": losses, "param": parameter.detach().cpu().numpy().tolist()}))
+"""
+
+
+def test_loss_started_on_the_first_sub_batch_equals_the_loss_behind_the_join(tmp_path):
+    """SPLIT_LOSS / drt_ray_loss_listed_grad_split with a call cut into FOUR sub-batches on two internal streams (DRT_MIN_SUB_LOG2 small):
+    the list of completed paths is written by segment and joined behind the pipelines, the loss + gradient pass over its head runs on an
+    internal stream.  Same losses and parameters as with one undivided list and the loss behind the join."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    script = tmp_path / "split.py"
+    script.write_text(_SPLIT_SCRIPT)
+    out = {}
+    for name, env in (("split", {"DRT_MIN_SUB_LOG2": "14", "DRT_SUB_PER_STREAM": "2", "DRT_SPLIT_LOSS_MIN_RAYS": "0", "DRT_RECYCLE_MIN_RAYS": "0"}),
+                      ("plain", {"DRT_SPLIT_LOSS": "0", "DRT_STREAMS": "1", "DRT_RECYCLE_OUTPUTS": "0"})):
+        p = subprocess.run([sys.executable, str(script)], cwd=ROOT, env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    np.testing.assert_allclose(out["split"]["losses"], out["plain"]["losses"], rtol=1e-12)
+    a, b = np.array(out["split"]["param"]), np.array(out["plain"]["param"])
+    assert np.abs(a).max() > 1e-3 and np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
