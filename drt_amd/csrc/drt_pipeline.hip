@@ -307,24 +307,32 @@ __global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __re
                                                            const Node4Q* __restrict__ nodes, int n_tris, const double* __restrict__ origin, const double* __restrict__ dir,
                                                            const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
                                                            double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                           int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz) {
+                                                           int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz,
+                                                           PathCtx c, bool direct, bool prefilled) {
+    // `direct` (round 4): a pixel of a trusted image with a key does bounce #1 RIGHT HERE -- the float64 ray is being loaded anyway -- and goes
+    // straight to list R1; list R0 then only holds what the untrusted images contribute (cull_patch below), and k_shade1, a pass of its own
+    // over 1.5 M entries before, has next to nothing to do (it is not even launched when every image of the call is a verified one).  The
+    // number of primary hits is still counted (count[17]: the stage statistics and the bench line's `paths` read it).
     __shared__ CullShared sh;
     __shared__ StageFace st;
     stage_init(st.m);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int vt = ((tid & 63) >> 4) * 64 + (tid >> 6) * 16 + (tid & 15);   // position of this thread's pixel in tile order
     const unsigned ppr = (unsigned)tile_w / 64u;
+    const RayList dst = direct ? p.r1 : p.r0;
+    unsigned* const dst_count = direct ? &p.count[1] : &p.count[0];
     auto flush = [&]() {                                    // whole block; st.m.n stable
         const unsigned cnt = st.m.n;
-        if (tid == 0) st.m.base = cnt ? atomicAdd(&p.count[0], cnt) : 0u;
+        if (tid == 0) st.m.base = cnt ? atomicAdd(dst_count, cnt) : 0u;
         __syncthreads();
         const unsigned base = st.m.base;
-        for (unsigned k = tid; k < cnt; k += kPathBlock) { p.r0.idx[base + k] = st.m.idx[k]; p.r0.face[base + k] = st.face[k]; }
-        for (unsigned k = tid; k < 6u * cnt; k += kPathBlock) p.r0.ray[6 * (int64_t)base + k] = st.m.ray[k];
+        for (unsigned k = tid; k < cnt; k += kPathBlock) { dst.idx[base + k] = st.m.idx[k]; if (!direct) dst.face[base + k] = st.face[k]; }
+        for (unsigned k = tid; k < 6u * cnt; k += kPathBlock) dst.ray[6 * (int64_t)base + k] = st.m.ray[k];
         __syncthreads();
         if (tid == 0) st.m.n = 0u;
         __syncthreads();
     };
+    unsigned n_hits = 0;                                    // primary hits this thread saw (direct mode: they are not listed anywhere)
     const unsigned count = *n_patches;
     for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
         const unsigned patch = patches[k];
@@ -345,8 +353,28 @@ __global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __re
             if (key != kRasterEmpty) rz.zbuf[zs] = kRasterEmpty;           // consumed: the buffer is empty again for the next call
         }
         const bool cand = key != kRasterEmpty && (!FUSED || valid[i]);
-        // rank of this thread's hit among the patch's hits, in 16x4-tile order
-        sh.flag[vt] = cand ? 1 : 0;
+        bool push = cand;                                   // contributes a list entry
+        f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f};
+        if (cand) {
+            if (direct) {
+                // bounce #1 (what k_shade1 does with an R0 entry): float64 Moeller-Trumbore + refraction on the face the projection pass found
+                const int32_t f1 = (int32_t)(uint32_t)key;
+                face1[i] = f1;
+                d3 v0, v1, v2;
+                int32_t vid[3];
+                Bounce b;
+                load_tri64(c, f1, v0, v1, v2, vid);
+                bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+                push = !b.tir;
+                o = to_f32(b.new_o); d = to_f32(b.wt);
+                if (!push && !FUSED) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
+                ++n_hits;
+            } else {
+                o = to_f32(load_d3(origin, i)); d = to_f32(load_d3(dir, i));
+            }
+        }
+        // rank of this thread's entry among the patch's entries, in 16x4-tile order
+        sh.flag[vt] = push ? 1 : 0;
         __syncthreads();
         if ((word & bit) && lane == 0) atomicAnd(&rz.zmask[i >> 11], ~bit);  // (after the barrier: every wave has read its bit)
         const bool mine = sh.flag[tid] != 0;
@@ -354,12 +382,11 @@ __global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __re
         if (lane == 0) sh.tmp[wave] = (unsigned)__popcll(bm);
         __syncthreads();
         unsigned before = 0, tot = 0;
-        for (int w = 0; w < kPathWaves; ++w) { const unsigned c = sh.tmp[w]; if (w < wave) before += c; tot += c; }
+        for (int w = 0; w < kPathWaves; ++w) { const unsigned cw = sh.tmp[w]; if (w < wave) before += cw; tot += cw; }
         sh.slot[tid] = mine ? (int)(before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))) : -1;
         __syncthreads();
-        if (cand) {
+        if (push) {
             const unsigned slot = st.m.n + (unsigned)sh.slot[vt];
-            const f3 o = to_f32(load_d3(origin, i)), d = to_f32(load_d3(dir, i));
             st.m.idx[slot] = (int32_t)i;
             float* e = st.m.ray + 6 * slot;
             e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z;
@@ -371,6 +398,11 @@ __global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __re
         if (st.m.n > kStageCap - kPathBlock) flush();
     }
     flush();
+    if (direct) {
+        unsigned h = n_hits;
+        for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+        if (lane == 0 && h) atomicAdd(&p.count[17], h);
+    }
 }
 
 // Which patches k_cull_listed has to visit: one thread per patch.
@@ -1228,14 +1260,14 @@ __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long
     if (raster) atomicAdd(&tot[kStageRaster], n_rays);
     if (raster && !fused) atomicAdd(&tot[kStageFill], n_rays);
     if (mega) {       // one kernel did the back half: its item count is list R1; the size list R2 would have had was counted inside it
-        atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
+        atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0] + qcount[17]);
         atomicAdd(&tot[kStagePath], (unsigned long long)qcount[1]);
         atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
         atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[6]);
         atomicAdd(&tot[fused ? kStageLossBwdFused : kStageFinish], (unsigned long long)qcount[6]);
         return;
     }
-    atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0]);
+    atomicAdd(&tot[kStageTrace1], (unsigned long long)qcount[raster ? 3 : 0]); atomicAdd(&tot[kStageShade1], (unsigned long long)qcount[0] + qcount[17]);
     atomicAdd(&tot[kStageTrace2], (unsigned long long)qcount[1]); atomicAdd(&tot[kStageShade2], (unsigned long long)qcount[1]);
     atomicAdd(&tot[kStageTrace3], (unsigned long long)qcount[2]);
     atomicAdd(&tot[fused ? kStageLossBwdFused : kStageFinish], (unsigned long long)qcount[2]);
@@ -1408,13 +1440,20 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     if (pre_any && !late_fill) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     const bool tree_late = all_verified && rz.views != nullptr;
     if (!tree_late) { int rc = wait_build(s, st); if (rc) return rc; }
+    // bounce #1 inside the cull of the listed patches (k_cull_listed's `direct`); the one-kernel path parks float64 rays in k_shade1: not there
+    // Only for large sub-batches: the listed patches are handled one after the other by each block, a few hits per patch, so the float64
+    // bounce runs at low lane use and with the patch loop's barriers around it -- cheaper than a pass of its own over list R0 once the chip
+    // is saturated (72 views: -1.3 %, the object filling the image: -4.3 %), dearer when the call is a chain of latencies (36 views in two
+    // sub-batches +3.5 %, 9 views +6.5 %).
+    const bool direct = s->cull_direct && rz.views && grid_mode == DRT_GRID_TRUST && !mega && n >= s->cull_direct_min_rays;
     { StageTimer t(s, st, kStageCull);
       const unsigned n_patches = (unsigned)((n + kPathBlock - 1) / kPathBlock);
       if (rz.views && grid_mode == DRT_GRID_TRUST) {
           // (the dense outputs were pre-filled with the dead values above, before the projection pass)
           uint32_t* list = reinterpret_cast<uint32_t*>(p.redo);          // free until the first k_trace of this sub-batch
           k_patch_list<<<(n_patches + kPathBlock - 1) / kPathBlock, kPathBlock, 0, st>>>(n_patches, tile_w, rz, list, p.count + 7);
-          k_cull_listed<FUSED><<<gs, kPathBlock, 0, st>>>(list, p.count + 7, pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
+          k_cull_listed<FUSED><<<gs, kPathBlock, 0, st>>>(list, p.count + 7, pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz,
+                                                          pc, direct, late_fill);
       } else {
           k_cull<FUSED><<<n_patches, kPathBlock, 0, st>>>(pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz);
       } }
@@ -1447,7 +1486,8 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));
         if (pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     }
-    { StageTimer t(s, st, kStageShade1);
+    {   // (with `direct` list R0 only holds what untrusted images contributed -- normally nothing: a launch that returns at once)
+      StageTimer t(s, st, kStageShade1);
       k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill, r64); }
     if (late_fill && !mega && fills_after_shade1) { int rc = issue_late_fills(); if (rc) return rc; }
     if (tree_late) {
