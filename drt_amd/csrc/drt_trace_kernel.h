@@ -21,6 +21,10 @@ constexpr int32_t kGuardPoison = 0x5A5A5A5A;
 #else
 constexpr int kGuardRows = 0;
 #endif
+#ifndef DRT_LEAF_PARK
+#define DRT_LEAF_PARK 1
+#endif
+constexpr int32_t kDrained = INT32_MIN + 2;       // TravState::cur of a ray whose stack is empty and whose PARKED leaf is all that is left (DRT_LEAF_PARK)
 constexpr int32_t kFinished = INT32_MIN + 1;      // TravState::cur of a ray that is done and waits to be emitted (never a node: a leaf reference this large has no slot)
 
 // Where a finished ray's result goes.  Pipeline: out.face[list slot].  B1 (`idx` non-null): the list holds ray numbers;
@@ -121,12 +125,58 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                     trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
                     st.overflow = false;
                     slot = (int32_t)k;
+                    lds[kStackFast][threadIdx.x] = 0;            // (nothing parked: DRT_LEAF_PARK)
                 }
             }
             taken += (unsigned)__popcll(idle);
         }
         const unsigned long long busy = __ballot(slot >= 0);
         if (busy == 0) break;
+#if DRT_LEAF_PARK
+        // "While-while" with PARKED leaves.  A lane that reaches a leaf does not wait for the wave's next triangle step: it parks the leaf
+        // (one per lane, in the spare top row of its stack column; 0 = nothing parked) and goes on with the next node of its stack; only a
+        // lane that reaches a SECOND leaf, or whose stack is empty, waits.  The triangle step then tests everybody's parked leaf -- also those
+        // of lanes that are still descending -- so both kinds of step run with more lanes.  The parked leaf's hit arrives a few visits late
+        // as a pruning bound; what is visited in between would have been popped (and visited once) anyway, only its children are not culled
+        // yet.  (The spare row is written by a node visit only when that visit overflows the stack, and then the ray is abandoned.)
+        for (;;) {
+            const bool at_inner = slot >= 0 && s.cur >= 0;
+            const unsigned long long mi = __ballot(at_inner);
+            if (mi == 0) break;
+            if ((int)__popcll(mi) < inner_min && __ballot(slot >= 0 && s.cur < 0 && s.cur != kFinished) != 0) break;
+            ++wave_steps;
+            lane_steps += (unsigned long long)__popcll(mi);
+            if (at_inner) {
+                const bool done = trav_inner<ANY>(c.nodes, s, st);
+                if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to the second pass (epilogue)
+                    trace_redo_push(redo_list, redo_count, slot);
+                    slot = -1;
+                } else if (done) {
+                    s.cur = lds[kStackFast][threadIdx.x] != 0 ? kDrained : kFinished;
+                } else if (s.cur < 0 && lds[kStackFast][threadIdx.x] == 0) {
+                    lds[kStackFast][threadIdx.x] = s.cur;
+                    if (trav_pop(s, st)) s.cur = kDrained;
+                }
+            }
+        }
+        // triangle step: every parked leaf; then the lanes that wait at a second leaf park that one and move on
+        const int32_t pk = slot >= 0 ? lds[kStackFast][threadIdx.x] : 0;
+        const unsigned long long mh = __ballot(pk != 0);
+        if ((mh | __ballot(slot >= 0 && s.cur < 0 && s.cur != kFinished)) != 0) {
+            ++wave_steps; ++leaf_steps;
+            lane_steps += (unsigned long long)__popcll(mh);
+            if (pk != 0) {
+                lds[kStackFast][threadIdx.x] = 0;
+                if (trav_leaf_test<ANY, true>(c.tris, s, pk)) s.cur = kFinished;      // (any-hit: done)
+                else if (s.cur == kDrained) s.cur = kFinished;
+            }
+            if (slot >= 0 && s.cur < 0 && s.cur != kFinished) {       // a leaf nobody has looked at yet: park it, move on
+                lds[kStackFast][threadIdx.x] = s.cur;
+                if (trav_pop(s, st)) s.cur = kDrained;
+            }
+        }
+    }
+#else
         // inner phase ("while-while"): lanes at inner nodes keep descending; lanes that reached a leaf
         // wait, so that the (longer) triangle code runs once for many lanes instead of on every step
         for (;;) {
@@ -155,6 +205,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             if (at_leaf && trav_leaf<ANY, true>(c.tris, s, st)) s.cur = kFinished;
         }
     }
+#endif
 #if defined(DRT_CHECK)
     for (int g = 0; g < kGuardRows; ++g) DRT_DEV_ASSERT(lds[kStackFast + 1 + g][threadIdx.x] == kGuardPoison, drt::kCheckGuardRow);
 #endif

@@ -280,6 +280,33 @@ DRT_HD bool trav_leaf(const TriRec* __restrict__ tris, TravState& s, STACK& st) 
     return trav_pop(s, st);
 }
 
+// The triangle tests of leaf `ref` alone (no pop): what trav_leaf does before it takes the next node.  For the persistent kernel's
+// PARKED leaves (drt_trace_kernel.h): a lane that reaches a leaf parks it and goes on with the next node of its stack; the wave tests
+// everybody's parked leaves together.  Returns true when an any-hit query is finished by it.
+template <bool ANY, bool DEFER = false>
+DRT_HD bool trav_leaf_test(const TriRec* __restrict__ tris, TravState& s, int32_t leaf) {
+    if (leaf == kEmptyChild) return false;
+    const int32_t ref = ~leaf;
+    const int first = ref >> kLeafBits, count = (ref & (kLeafMax - 1)) + 1;
+    for (int j = 0; j < count; ++j) {
+        const F4* tp = reinterpret_cast<const F4*>(tris + first + j);
+        const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+        float t;
+        const bool hit = DEFER ? tri_hit_mt(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)
+                               : tri_hit(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, p1.w, t);
+        if (hit) {
+            int32_t face;
+            memcpy(&face, &p0.w, 4);
+            if (ANY || t < s.best_t || (t == s.best_t && face < s.best_face)) {
+                s.best_t = t; s.best_face = face;
+                if (DEFER) s.best_slot = first + j;
+                if (ANY) return true;
+            }
+        }
+    }
+    return false;
+}
+
 // The deferred hit-point condition of a finished ray (trav_leaf<ANY, true>): false = traverse it again with the exact form.
 DRT_HD bool trav_winner_ok(const TriRec* __restrict__ tris, const TravState& s) {
     if (s.best_face < 0) return true;
