@@ -109,33 +109,41 @@ def fixture_view(g):
 _frame = {}
 _mesh = {}
 HEADLINE_FIXTURE = "horse50k_r256_v11"      # the reference's own Python on BASELINE.json's ~50k-triangle mesh (make_golden.py horse)
+BIG_FIXTURES = [HEADLINE_FIXTURE, "mouse37k_r256_v29"]     # + BASELINE.json configs[2]'s hull, mouse_vh.ply x4 (make_golden.py mouse)
+
+
+def _fixture_key(g):
+    if "mesh_sha256" not in g.files:
+        return "hand"
+    return str(g["hull"]) if "hull" in g.files else "horse"
 
 
 def fixture_mesh(g):
-    """The mesh a render fixture was made on: hand_vh.ply, or -- fixtures that carry `mesh_sha256` -- horse_vh.ply after one midpoint
-    subdivision (50 248 triangles), rebuilt here exactly as make_golden.py built it and checked against the fixture's hash."""
+    """The mesh a render fixture was made on: hand_vh.ply, or -- fixtures that carry `mesh_sha256` -- <hull>_vh.ply after one midpoint
+    subdivision (horse: 50 248 triangles, mouse: 36 984), rebuilt here exactly as make_golden.py built it and checked against the
+    fixture's hash."""
     from drt_amd import mesh_io
-    key = "horse" if "mesh_sha256" in g.files else "hand"
+    key = _fixture_key(g)
     if key not in _mesh:
         if key == "hand":
             _mesh[key] = mesh_io.read_ply(data_path("hand_vh.ply"))
         else:
             import hashlib
             import tempfile
-            hull = mesh_io.subdivide_midpoint(mesh_io.read_ply(data_path("horse_vh.ply")))
+            hull = mesh_io.subdivide_midpoint(mesh_io.read_ply(data_path(f"{key}_vh.ply")))
             with tempfile.TemporaryDirectory() as tmp:
-                f = os.path.join(tmp, "horse_x4.ply")
+                f = os.path.join(tmp, f"{key}_x4.ply")
                 mesh_io.write_ply(f, hull.vertices, hull.faces)
                 m = mesh_io.read_ply(f)
             sha = hashlib.sha256(np.ascontiguousarray(m.vertices, np.float64).tobytes() + np.ascontiguousarray(m.faces, np.int64).tobytes()).hexdigest()
-            assert sha == str(g["mesh_sha256"]) and len(m.faces) == int(g["n_faces"]) == 50248
+            assert sha == str(g["mesh_sha256"]) and len(m.faces) == int(g["n_faces"]) > 30000
             _mesh[key] = m
     return _mesh[key]
 
 
 def fixture_frame(g):
     from drt_amd import views
-    key = "horse" if "mesh_sha256" in g.files else "hand"
+    key = _fixture_key(g)
     if key not in _frame:
         _frame[key] = views.mesh_frame(fixture_mesh(g).vertices)
     return _frame[key]

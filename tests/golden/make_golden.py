@@ -416,6 +416,26 @@ def degenerate_fixture(DR, optim, mesh, center, extent):
           "NaN grad_sm rows", int(np.isnan(rec["grad_sm"]).any(axis=1).sum()), "sil", len(sil), "vh", vh.item(), "valid", len(vi), loss_str)
 
 
+def big_mesh_fixture(DR, optim, name, view_id, tag):
+    """A BASELINE-size hull (`name`_vh.ply after one midpoint subdivision) through the reference's own Python, one view at 256x256."""
+    import hashlib
+    import tempfile
+    hull = mesh_io.subdivide_midpoint(mesh_io.read_ply(os.path.join(REPO, "data", f"{name}_vh.ply")))
+    center, extent = views.mesh_frame(hull.vertices)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, f"{name}_x4.ply")
+        mesh_io.write_ply(path, hull.vertices, hull.faces)
+        mesh = mesh_io.read_ply(path)            # (float32 on disk: what Scene(path) sees)
+        scene = DR.Scene(path)
+        render_fixture(DR, optim, scene, mesh, center, extent, 256, view_id, tag)
+    f = os.path.join(OUT, tag + ".npz")
+    rec = dict(np.load(f))
+    rec.update(n_faces=len(mesh.faces), n_vertices=len(mesh.vertices), hull=name,
+               mesh_sha256=hashlib.sha256(np.ascontiguousarray(mesh.vertices, np.float64).tobytes() + np.ascontiguousarray(mesh.faces, np.int64).tobytes()).hexdigest())
+    np.savez_compressed(f, **rec)
+    print(tag, "fixture:", rec["n_faces"], "faces,", os.path.getsize(f), "bytes")
+
+
 def horse_fixture(DR, optim):
     """The HEADLINE mesh (BASELINE.json's ~50k-triangle workload: horse_vh.ply after one midpoint subdivision = 50 248 triangles,
     25 126 vertices), one view at 256x256, through the reference's own Python: per-bounce ids and terms, outputs, ray_loss and its
@@ -451,6 +471,8 @@ def main():
         return degenerate_fixture(DR, optim, mesh, center, extent)
     if only == {"horse"}:
         return horse_fixture(DR, optim)
+    if only == {"mouse"}:       # BASELINE.json configs[2]: mouse_vh.ply subdivided to 36 984 triangles
+        return big_mesh_fixture(DR, optim, "mouse", 29, "mouse37k_r256_v29")
     scene = DR.Scene(path)
     np.savez_compressed(os.path.join(OUT, "hand_topology.npz"), Edges=scene.Edges.numpy(), E2F=scene.E2F.numpy(),
                         mean_len=scene.mean_len, n_vertices=len(mesh.vertices), n_faces=len(mesh.faces))
@@ -461,6 +483,7 @@ def main():
     smooth_fixture(DR, optim, scene, mesh, center, extent)
     degenerate_fixture(DR, optim, mesh, center, extent)
     horse_fixture(DR, optim)
+    big_mesh_fixture(DR, optim, "mouse", 29, "mouse37k_r256_v29")
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import HEADLINE_FIXTURE, IOR, data_path, fixture_mesh, fixture_view, golden
+from conftest import BIG_FIXTURES, HEADLINE_FIXTURE, IOR, data_path, fixture_mesh, fixture_view, golden
 from drt_amd import mesh_io, views
 from oracle import diffrender_oracle as orc
 
@@ -153,7 +153,7 @@ def test_full_size_traversal_equals_gpu_bruteforce(horse50k, res):
         assert torch.equal(T[idx], Tb)
 
 
-@pytest.mark.parametrize("name", [f"hand_r{r}_v{v}" for r in (64, 128) for v in (5, 23, 41)] + [HEADLINE_FIXTURE])
+@pytest.mark.parametrize("name", [f"hand_r{r}_v{v}" for r in (64, 128) for v in (5, 23, 41)] + BIG_FIXTURES)
 def test_render_transparent_vs_golden(Render, name):
     """Against the reference's own Python (tests/golden/make_golden.py): hand_vh at 64^2 / 128^2, and the HEADLINE mesh -- horse_vh x4,
     50 248 triangles, one view at 256^2 (DiffRender.py:420-432, optim.py:91-108 on BASELINE.json's workload)."""
@@ -273,7 +273,7 @@ def test_properties_at_full_size(Render, horse50k):
 
 
 # ----------------------------------------------------------------------------- silhouette / smoothness branches
-@pytest.mark.parametrize("name", [f"hand_r{r}_v{v}" for r in (64, 128) for v in (5, 23, 41)] + [HEADLINE_FIXTURE])
+@pytest.mark.parametrize("name", [f"hand_r{r}_v{v}" for r in (64, 128) for v in (5, 23, 41)] + BIG_FIXTURES)
 def test_silhouette_branch_vs_golden(Render, name):
     g = golden(name)
     hand = fixture_mesh(g)
@@ -281,7 +281,7 @@ def test_silhouette_branch_vs_golden(Render, name):
     Render.resx = Render.resy = res
     o, d, _, _ = fixture_view(g)
     scene = Render.Scene(hand, 0)
-    if name != HEADLINE_FIXTURE:
+    if name not in BIG_FIXTURES:
         topo = golden("hand_topology")
         assert np.array_equal(scene.Edges.cpu().numpy(), topo["Edges"]) and np.array_equal(scene.E2F.cpu().numpy(), topo["E2F"])
         assert scene.mean_len == pytest.approx(float(topo["mean_len"]), rel=1e-14)

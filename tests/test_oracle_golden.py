@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import HEADLINE_FIXTURE, IOR, data_path, fixture_mesh, fixture_view, golden
+from conftest import BIG_FIXTURES, HEADLINE_FIXTURE, IOR, data_path, fixture_mesh, fixture_view, golden
 from drt_amd import mesh_io, views
 from oracle import diffrender_oracle as orc
 
@@ -46,7 +46,7 @@ def test_unit_tables():
     close(u, g["mt_u"]); close(v, g["mt_v"]); close(t, g["mt_t"]); close(n, g["mt_n"])
 
 
-@pytest.mark.parametrize("name", FIXTURES + [HEADLINE_FIXTURE])
+@pytest.mark.parametrize("name", FIXTURES + BIG_FIXTURES)
 def test_render_path(name):
     g = golden(name)
     hand = fixture_mesh(g)            # (the headline fixture: horse_vh x4, 50 248 triangles)
@@ -91,11 +91,11 @@ def test_render_path(name):
     close(g_lin, g["grad_lin"], rtol=1e-9, atol=1e-11 * np.abs(g["grad_lin"]).max())
 
 
-@pytest.mark.parametrize("name", FIXTURES + [HEADLINE_FIXTURE])
+@pytest.mark.parametrize("name", FIXTURES + BIG_FIXTURES)
 def test_silhouette_branch(name):
     g = golden(name)
     hand = fixture_mesh(g)
-    if name == HEADLINE_FIXTURE:      # (edge tables: mesh_io's, pinned to the reference's on the hand hull by test_topology_tables)
+    if name in BIG_FIXTURES:      # (edge tables: mesh_io's, pinned to the reference's on the hand hull by test_topology_tables)
         e, e2f, _ = mesh_io.edge_tables(hand)
         topo = {"Edges": e, "E2F": e2f}
     else:
