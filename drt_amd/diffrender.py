@@ -237,7 +237,8 @@ class _RenderTransparent(torch.autograd.Function):
         om = scene.optix_mesh            # owns the buffers zeroed ahead of time: its drt_destroy waits for the zeroing before they are released
         capturing = torch.cuda.is_current_stream_capturing()
         need_bwd = ctx.needs_input_grad[0]
-        recycle = RECYCLE_OUTPUTS and (grid[0] & 3) == 2 and n >= RECYCLE_MIN_RAYS and not capturing
+        recycle = RECYCLE_OUTPUTS and n >= RECYCLE_MIN_RAYS and not capturing      # (any grid mode: a call that verifies every ray -- no cache, or the
+                                                                                  #  establishing one -- then at least does not write the dead rows again)
         pre = getattr(om, "_prefilled", None)
         if capturing:
             # a graph replays THESE launches on THESE buffers: the fills must be part of it, and nothing outside the capture may be waited
