@@ -114,7 +114,8 @@ int drt_build_params(drt_scene_t* s, float* out7, void* stream);
 #define DRT_GRID_TRUST 2
 #define DRT_GRID_CACHE_BYTES 104
 /* OR-ed into grid_mode: d_face1 / d_face2 are only guaranteed for the rays with mask = 1 (what drt_render_backward* read);
- * in DRT_GRID_TRUST mode the -1 entries of all other rays are then not written (8 bytes per ray less to fill). */
+ * in DRT_GRID_TRUST mode -- and in any mode when the three dense outputs were offered through drt_outputs_clean -- the -1 entries of
+ * all other rays are then not written (8 bytes per ray less to fill). */
 #define DRT_GRID_SPARSE_FACES 16
 /* OR-ed into DRT_GRID_TRUST: the caller has read the cache back after the establishing call and EVERY image in it is recorded
  * as a pinhole grid in all of its rays (int32 `ok` and `all` at byte offsets 96 and 100 of each DRT_GRID_CACHE_BYTES record
