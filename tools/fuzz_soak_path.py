@@ -5,6 +5,8 @@ import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_fuzz as fz
+from drt_amd import diffrender
+diffrender.DENSE_FACE_IDS = True      # (what tests/conftest.py's autouse fixture sets under pytest)
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0; t0 = time.time()
 for seed in range(first, first + count):

@@ -8,6 +8,7 @@ import test_gpu_raster as tr
 from conftest import IOR
 from drt_amd import diffrender
 diffrender.intIOR = IOR
+diffrender.DENSE_FACE_IDS = True      # (what tests/conftest.py's autouse fixture sets under pytest: the tests compare last_face1 for EVERY ray)
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0; t0 = time.time()
 for seed in range(first, first + count):
