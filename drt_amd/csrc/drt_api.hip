@@ -60,6 +60,7 @@ int drt_create(int device, drt_scene_t** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->build_done, hipEventDisableTiming);
     if (const char* ev = getenv("DRT_ASYNC_BUILD")) s->async_build = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_CULL_DIRECT")) s->cull_direct = atoi(ev) != 0;
+    if (const char* ev = getenv("DRT_CULL_PARK")) s->cull_park = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_CULL_DIRECT_MIN_LOG2")) { const int v = atoi(ev); if (v >= 0 && v <= 40) s->cull_direct_min_rays = (int64_t)1 << v; }
     if (const char* ev = getenv("DRT_TREE")) { const int v = atoi(ev); if (v >= 0 && v <= 2) s->tree_mode = v; }
     if (const char* ev = getenv("DRT_REBUILD_EVERY")) { const int v = atoi(ev); if (v >= 1) s->rebuild_every = v; }

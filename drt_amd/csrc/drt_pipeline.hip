@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __re
                                                            const uint8_t* __restrict__ valid, int64_t n, double* __restrict__ out_ori,
                                                            double* __restrict__ out_dir, uint8_t* __restrict__ mask,
                                                            int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p, int tile_w, RasterIn rz,
-                                                           PathCtx c, bool direct, bool prefilled) {
+                                                           PathCtx c, bool direct, bool prefilled, Ray64 park) {
     // `direct` (round 4): a pixel of a trusted image with a key does bounce #1 RIGHT HERE -- the float64 ray is being loaded anyway -- and goes
     // straight to list R1; list R0 then only holds what the untrusted images contribute (cull_patch below), and k_shade1, a pass of its own
     // over 1.5 M entries before, has next to nothing to do (it is not even launched when every image of the call is a verified one).  The
@@ -368,6 +368,9 @@ __global__ void __launch_bounds__(kPathBlock) k_cull_listed(const uint32_t* __re
                 bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
                 push = !b.tir;
                 o = to_f32(b.new_o); d = to_f32(b.wt);
+                // (the float64 refracted ray parked in the ray's rows of the dense outputs -- already zeroed, rewritten by k_shade2 whatever
+                // becomes of the path -- so that k_shade2 does bounce #2 only: what k_shade1 does for the one-kernel path)
+                if (push && park.o) { store_d3(park.o, i, b.new_o); store_d3(park.d, i, b.wt); }
                 if (!push && !FUSED) { if (prefilled) face2[i] = -1; else write_dead(i, out_ori, out_dir, mask, face2); }
                 ++n_hits;
             } else {
@@ -513,7 +516,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_gen_late(PathCtx c, const doubl
 template <bool FUSED>
 __global__ void __launch_bounds__(kPathBlock) k_shade2(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                         double* __restrict__ out_ori, double* __restrict__ out_dir, uint8_t* __restrict__ mask,
-                                                        const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p) {
+                                                        const int32_t* __restrict__ face1, int32_t* __restrict__ face2, Pipe p,
+                                                        bool parked /* rows i of out_ori / out_dir hold the float64 refracted ray of R1's entries (k_cull_listed direct) */) {
     __shared__ StageMem stage;
     stage_init(stage);
     const unsigned n1 = p.count[1];
@@ -531,9 +535,14 @@ __global__ void __launch_bounds__(kPathBlock) k_shade2(PathCtx c, const double* 
                 d3 v0, v1, v2;
                 int32_t vid[3];
                 Bounce b;
-                load_tri64(c, face1[i], v0, v1, v2, vid);
-                bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
-                const d3 o2 = b.new_o, d2 = b.wt;
+                d3 o2, d2;
+                if (parked) {
+                    o2 = load_d3(out_ori, i); d2 = load_d3(out_dir, i);
+                } else {
+                    load_tri64(c, face1[i], v0, v1, v2, vid);
+                    bounce_forward(load_d3(origin, i), load_d3(dir, i), v0, v1, v2, c.ior_ext, c.ior_int, b);
+                    o2 = b.new_o; d2 = b.wt;
+                }
                 load_tri64(c, f2, v0, v1, v2, vid);
                 bounce_forward(o2, d2, v0, v1, v2, c.ior_ext, c.ior_int, b);
                 ok = !b.tir;
@@ -1447,6 +1456,11 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     // is saturated (72 views: -1.3 %, the object filling the image: -4.3 %), dearer when the call is a chain of latencies (36 views in two
     // sub-batches +3.5 %, 9 views +6.5 %).
     const bool direct = s->cull_direct && rz.views && grid_mode == DRT_GRID_TRUST && !mega && n >= s->cull_direct_min_rays;
+    // ... and parks the float64 refracted rays in the rows of the dense outputs when those are zeroed already (recycled / zeroed ahead of
+    // time: no fill of this call can run over them) and the zeroing is through (prefill_done)
+    const bool park = direct && !FUSED && pre_ori && pre_dir && pre_mask && s->cull_park;
+    const Ray64 r64p = park ? Ray64{out_ori, out_dir} : r64;      // (k_shade1 and k_gen_late, which serve the untrusted images, park likewise)
+    if (park) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     { StageTimer t(s, st, kStageCull);
       const unsigned n_patches = (unsigned)((n + kPathBlock - 1) / kPathBlock);
       if (rz.views && grid_mode == DRT_GRID_TRUST) {
@@ -1454,7 +1468,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
           uint32_t* list = reinterpret_cast<uint32_t*>(p.redo);          // free until the first k_trace of this sub-batch
           k_patch_list<<<(n_patches + kPathBlock - 1) / kPathBlock, kPathBlock, 0, st>>>(n_patches, tile_w, rz, list, p.count + 7);
           k_cull_listed<FUSED><<<gs, kPathBlock, 0, st>>>(list, p.count + 7, pc.tc.nodes, pc.tc.n_tris, o, d, valid, n, out_ori, out_dir, mask, face1, face2, p, tile_w, rz,
-                                                          pc, direct, late_fill);
+                                                          pc, direct, late_fill, park ? Ray64{out_ori, out_dir} : Ray64{nullptr, nullptr});
       } else {
           // (every ray is read and decided here; with all three outputs already zero -- recycled -- and face ids only promised where mask = 1,
           // the dead ones, nine in ten, need not be written again: 56 B read per ray instead of 56 read + 59 written)
@@ -1492,12 +1506,12 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     }
     {   // (with `direct` list R0 only holds what untrusted images contributed -- normally nothing: a launch that returns at once)
       StageTimer t(s, st, kStageShade1);
-      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill, r64); }
+      k_shade1<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, late_fill, r64p); }
     if (late_fill && !mega && fills_after_shade1) { int rc = issue_late_fills(); if (rc) return rc; }
     if (tree_late) {
         int rc = wait_build(s, st); if (rc) return rc;
         StageTimer t(s, st, kStageTrace1);
-        k_gen_late<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, w.gen_list, late_fill, r64);
+        k_gen_late<FUSED><<<kRedoGrid, kTraceBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, w.gen_list, late_fill, r64p);
     }
     if (mega) {
         StageTimer t(s, st, kStagePath);
@@ -1512,7 +1526,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));     // k_shade2 is the first kernel that writes rows of the dense outputs
     if (late_fill && pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     { StageTimer t(s, st, kStageShade2);
-      k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p); }
+      k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, park); }
     { StageTimer t(s, st, kStageTrace3);
       k_trace<true, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
     return DRT_OK;

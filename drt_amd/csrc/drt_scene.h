@@ -92,6 +92,7 @@ struct drt_scene {
     // iteration"); 1 = its TOPOLOGY is kept for `rebuild_every` updates, the updates in between only refit the boxes and re-quantise the
     // wide nodes; 2 = a binned-SAH topology built on the host at every update_mesh, refit-only on every update_vert.
     bool cull_direct = true;       // DRT_CULL_DIRECT=0: bounce #1 as a pass of its own (k_shade1) over list R0, as before round 4
+    bool cull_park = true;         // DRT_CULL_PARK=0: k_shade2 recomputes bounce #1 instead of reading the parked refracted ray
     int64_t cull_direct_min_rays = (int64_t)1 << 25;   // sub-batches below this keep the separate pass (DRT_CULL_DIRECT_MIN_LOG2)
     int tree_mode = 0, rebuild_every = 1, since_full = 0;
     bool topology_fixed = false;   // mode 2: the host's topology is installed for the current faces
