@@ -1458,7 +1458,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     const bool direct = s->cull_direct && rz.views && grid_mode == DRT_GRID_TRUST && !mega && n >= s->cull_direct_min_rays;
     // ... and parks the float64 refracted rays in the rows of the dense outputs when those are zeroed already (recycled / zeroed ahead of
     // time: no fill of this call can run over them) and the zeroing is through (prefill_done)
-    const bool park = direct && !FUSED && pre_ori && pre_dir && pre_mask && s->cull_park;
+    const bool park = !FUSED && !mega && rz.views && grid_mode == DRT_GRID_TRUST && pre_ori && pre_dir && pre_mask && s->cull_park;      // (with or without `direct`: k_shade1 parks too)
     const Ray64 r64p = park ? Ray64{out_ori, out_dir} : r64;      // (k_shade1 and k_gen_late, which serve the untrusted images, park likewise)
     if (park) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     { StageTimer t(s, st, kStageCull);
