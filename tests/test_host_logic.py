@@ -83,3 +83,58 @@ def test_fused_terms_and_weights_host_arithmetic():
     assert w == (40 * 217.5 / 960 / 960, 2e-3 * 217.5 / 960, 0.08 * 2.5 / 10)
     assert O.interp_R(10, 1, 0, 20) == pytest.approx(10) and O.interp_R(10, 1, 19, 20) == pytest.approx(1)
     assert O.interp_L(0.0, 1.9, 10, 20) == pytest.approx(1.0)
+
+
+def test_output_pool_hands_buffers_out_only_when_nobody_else_holds_them():
+    """diffrender._OutputPool (RECYCLE_OUTPUTS) on CPU tensors: an entry is taken only when the storages' use counts are back to the pool's
+    own, the version counters have not moved, and size / device / stream match; at most two entries are kept."""
+    import torch
+    from drt_amd import diffrender as R
+    if not hasattr(torch._C, "_storage_Use_Count"):
+        import pytest
+        pytest.skip("this torch has no storage use count")
+
+    def fresh(n):
+        bases = (torch.zeros(n, 3, dtype=torch.float64), torch.zeros(n, 3, dtype=torch.float64), torch.zeros(n, 3, dtype=torch.uint8))
+        return bases, tuple(R._use_count(t) for t in bases)
+
+    pool = R._OutputPool()
+    bases, counts = fresh(8)
+    lst, cnt = torch.arange(3, dtype=torch.int32), torch.tensor([3])
+    pool.put(8, torch.device("cpu"), 7, bases, counts, lst, cnt)
+    out = [b.detach() for b in bases]                      # what the caller holds: aliases with the same version counter
+    assert out[0]._version == 0 and out[0].data_ptr() == bases[0].data_ptr()
+    assert pool.take(8, torch.device("cpu"), 7) is None    # the caller still holds them
+    view = out[1][2:4]
+    del out
+    assert pool.take(8, torch.device("cpu"), 7) is None    # a view of one of them survives
+    del view
+    assert pool.take(9, torch.device("cpu"), 7) is None and pool.take(8, torch.device("cpu"), 8) is None     # another size / stream
+    ent = pool.take(8, torch.device("cpu"), 7)
+    assert ent is not None and ent[3][0] is bases[0] and ent[5] is lst and len(pool.entries) == 0
+    # a caller that wrote into its outputs before dropping them: the shared version counter shows it
+    pool.put(8, torch.device("cpu"), 7, bases, counts, lst, cnt)
+    alias = bases[1].detach()
+    alias.add_(1.0)
+    del alias
+    assert bases[1]._version == 1 and pool.take(8, torch.device("cpu"), 7) is None
+    # eviction: two entries at most
+    for k in range(3):
+        b, c = fresh(4 + k)
+        pool.put(4 + k, torch.device("cpu"), 7, b, c, lst, cnt)
+    assert len(pool.entries) == R._OutputPool.MAX == 2 and [e[0] for e in pool.entries] == [5, 6]
+
+
+def test_targets_are_known_complete_only_from_their_second_use_on():
+    """diffrender._targets_seen_before (SPLIT_LOSS): the early start of the loss pass is taken only for target tensors that went through
+    ray_loss before as the same objects, storage and version."""
+    import torch
+    from drt_amd import diffrender as R
+    sp, valid = torch.zeros(5, 3, dtype=torch.float64), torch.ones(5, dtype=torch.bool)
+    assert not R._targets_seen_before(sp, valid)
+    assert R._targets_seen_before(sp, valid)
+    sp.add_(1.0)                                           # written since: not known to be complete any more ...
+    assert not R._targets_seen_before(sp, valid)
+    assert R._targets_seen_before(sp, valid)               # ... until it has been seen again in that state
+    other = torch.zeros(5, 3, dtype=torch.float64)
+    assert not R._targets_seen_before(other, valid)
