@@ -7,8 +7,8 @@ void scene_free_mesh(drt_scene* s) {
     (void)hipFree(s->faces); (void)hipFree(s->verts); (void)hipFree(s->nodes); (void)hipFree(s->tris);
     (void)hipFree(s->keys[0]); (void)hipFree(s->keys[1]); (void)hipFree(s->idx[0]); (void)hipFree(s->idx[1]);
     (void)hipFree(s->hist); (void)hipFree(s->parent_inner); (void)hipFree(s->parent_leaf); (void)hipFree(s->flags);
-    (void)hipFree(s->wide); (void)hipFree(s->range_lo); (void)hipFree(s->range_hi); (void)hipFree(s->tris_flat);
-    s->wide = nullptr; s->range_lo = s->range_hi = nullptr; s->tris_flat = nullptr;
+    (void)hipFree(s->wide); (void)hipFree(s->range_lo); (void)hipFree(s->range_hi); (void)hipFree(s->tris_flat); (void)hipFree(s->slot_of_face);
+    s->slot_of_face = nullptr; s->wide = nullptr; s->range_lo = s->range_hi = nullptr; s->tris_flat = nullptr;
     s->faces = nullptr; s->verts = nullptr; s->nodes = nullptr; s->tris = nullptr;
     s->keys[0] = s->keys[1] = s->idx[0] = s->idx[1] = nullptr;
     s->hist = nullptr; s->parent_inner = s->parent_leaf = nullptr; s->flags = nullptr;
@@ -262,10 +262,11 @@ __device__ __forceinline__ unsigned long long pack2(float a, float b) {
 __global__ void k_refit(const uint32_t* __restrict__ sorted_idx, const int32_t* __restrict__ faces,
                         const float* __restrict__ verts, int n, BuildParams* bp, TriRec* __restrict__ tris,
                         Node* nodes, const int32_t* __restrict__ parent_inner,
-                        const int32_t* __restrict__ parent_leaf, uint32_t* flags) {
+                        const int32_t* __restrict__ parent_leaf, uint32_t* flags, int32_t* __restrict__ slot_of_face) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int32_t face = (int32_t)sorted_idx[k];
+    slot_of_face[face] = k;         // where a temporal hit seed (drt_trace_kernel.h TraceSeed) finds this face's record
     const f3 a = ld_vert(verts, faces[3 * face]), b = ld_vert(verts, faces[3 * face + 1]), c = ld_vert(verts, faces[3 * face + 2]);
     tris[k] = make_tri(a, b, c, face, hit_margin(bp->pad));
     Box box = box_of_tri(a, b, c, bp->pad);
@@ -393,6 +394,7 @@ int ensure_capacity(drt_scene* s, int64_t n_faces, int64_t n_verts) {
     HIP_TRY(hipMalloc(&s->range_hi, sizeof(int32_t) * F));
     HIP_TRY(hipMalloc(&s->tris, sizeof(TriRec) * F));
     HIP_TRY(hipMalloc(&s->tris_flat, sizeof(TriRec) * F));
+    HIP_TRY(hipMalloc(&s->slot_of_face, sizeof(int32_t) * F));
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&s->keys[k], sizeof(uint32_t) * F));
         HIP_TRY(hipMalloc(&s->idx[k], sizeof(uint32_t) * F));
@@ -435,7 +437,7 @@ static int rebuild_impl(drt_scene* s, hipStream_t st, const uint32_t* acc) {
     const int inner = n > 1 ? n - 1 : 1;
     k_hierarchy<<<(inner + 255) / 256, 256, 0, st>>>(s->keys[cur], n, s->nodes, s->parent_inner, s->parent_leaf, s->flags, s->range_lo, s->range_hi, const_cast<uint32_t*>(acc));
     k_refit<<<(n + 255) / 256, 256, 0, st>>>(s->idx[cur], s->faces, s->verts, n, s->params, s->tris, s->nodes,
-                                             s->parent_inner, s->parent_leaf, s->flags);
+                                             s->parent_inner, s->parent_leaf, s->flags, s->slot_of_face);
     k_collapse4<<<(inner + 255) / 256, 256, 0, st>>>(s->nodes, s->parent_inner, s->range_lo, s->range_hi, n, s->wide);
     HIP_TRY(hipGetLastError());
     s->order_valid = true;           // idx[cur] = the face ids in Morton order, kept until the next build starts
@@ -468,7 +470,7 @@ static int refit_impl(drt_scene* s, hipStream_t st, const uint32_t* acc) {
     const int inner = n > 1 ? n - 1 : 1;
     k_refit_prep<<<(inner + 255) / 256, 256, 0, st>>>(s->flags, n, s->params, const_cast<uint32_t*>(acc));
     k_refit<<<(n + 255) / 256, 256, 0, st>>>(s->idx[s->sorted_buf], s->faces, s->verts, n, s->params, s->tris, s->nodes,
-                                             s->parent_inner, s->parent_leaf, s->flags);
+                                             s->parent_inner, s->parent_leaf, s->flags, s->slot_of_face);
     k_collapse4<<<(inner + 255) / 256, 256, 0, st>>>(s->nodes, s->parent_inner, s->range_lo, s->range_hi, n, s->wide);
     HIP_TRY(hipGetLastError());
     return DRT_OK;

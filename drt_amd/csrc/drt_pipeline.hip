@@ -1381,7 +1381,8 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
                         int64_t n, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2, int tile_w, int tile_h,
                         int grid_mode, ViewModel* grid_cache /* models of the images of THIS sub-batch */,
                         hipStream_t aux /* the caller's stream: idle between the fork and the join of a call */, int64_t chunk_base, int32_t* valid_idx,
-                        bool* n_finished /* out: the sub-batch ran as ONE kernel (k_path), which also did k_finish's work */) {
+                        bool* n_finished /* out: the sub-batch ran as ONE kernel (k_path), which also did k_finish's work */,
+                        int32_t* seed2 = nullptr /* temporal hit seeds of THIS sub-batch's camera rays (drt_render_seed), or null */) {
     if (n_finished) *n_finished = false;
     const bool sparse_faces = (grid_mode & DRT_GRID_SPARSE_FACES) != 0;
     const bool pre_ori = (grid_mode & kIntPreOri) != 0, pre_dir = (grid_mode & kIntPreDir) != 0, pre_mask = (grid_mode & kIntPreMask) != 0;   // zeroed ahead of time (drt_prefill_zero)
@@ -1522,7 +1523,12 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
         return DRT_OK;
     }
     { StageTimer t(s, st, kStageTrace2);
-      k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr); }
+      unsigned long long* stats = s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr;
+      if (seed2 && s->hit_seed)       // the refracted rays start from last call's exit triangle of their pixel (TraceSeed)
+          k_trace<false, 0, true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats,
+                                                                        TraceSeed{p.r1.idx, seed2, s->slot_of_face});
+      else
+          k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats); }
     if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));     // k_shade2 is the first kernel that writes rows of the dense outputs
     if (late_fill && pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     { StageTimer t(s, st, kStageShade2);
@@ -1574,7 +1580,21 @@ int pipeline_blocks_per_cu() {
     return per_cu;
 }
 
+// The seeds registered for the next render call (drt_render_seed): one shot, and only for a call of exactly that many rays.
+static int32_t* take_seed(drt_scene* s, int64_t n_rays) {
+    int32_t* p = s->seed.face2 && s->seed.n == n_rays ? s->seed.face2 : nullptr;
+    s->seed = drt_scene::Seed{};
+    return p;
+}
+
 extern "C" {
+
+int drt_render_seed(drt_scene_t* s, int32_t* d_seed_face2, int64_t n_rays) {
+    CHECK_SCENE(s);
+    if (n_rays < 0 || (d_seed_face2 == nullptr && n_rays != 0)) return fail(DRT_E_INVALID, "bad seed buffer");
+    s->seed = drt_scene::Seed{d_seed_face2, n_rays};
+    return DRT_OK;
+}
 
 static int flush_clean(drt_scene* s, hipStream_t st);
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
@@ -1590,6 +1610,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     }
     if (!d_verts || !d_origin || !d_dir || !d_out_ori || !d_out_dir || !d_mask || !d_face1 || !d_face2) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_valid_idx == nullptr) != (d_n_valid == nullptr)) return fail(DRT_E_INVALID, "d_valid_idx and d_n_valid go together");
+    int32_t* const seed2 = take_seed(s, n_rays);
     const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, false); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(s->vcount, 0, sizeof(unsigned), st));
@@ -1642,7 +1663,7 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
         bool finished = false;
         rc = launch_chunk<false>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, nullptr, n, d_out_ori + 3 * b, d_out_dir + 3 * b,
                                  d_mask + 3 * b, d_face1 + b, d_face2 + b, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h),
-                                 st, b, vlist, &finished);
+                                 st, b, vlist, &finished, seed2 ? seed2 + b : nullptr);
         if (rc) return rc;
         if (!finished) {
             StageTimer t(s, w.stream, kStageFinish);
@@ -1867,6 +1888,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
     if (n_rays == 0) return DRT_OK;
     if (!d_verts || !d_origin || !d_dir || !d_screen_pixel || !d_valid || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
+    int32_t* const seed2 = take_seed(s, n_rays);
     const Plan pl = plan_call(s, n_rays, tile_w, tile_h);
     for (int k = 0; k < pl.streams; ++k) { int rc = ensure_queues(s->sub[k], pl.size, true, s->mega_max_rays > 0 && pl.size <= s->mega_max_rays); if (rc) return rc; }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1887,7 +1909,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
         HIP_TRY(hipMemsetAsync(w.qcount, 0, kQCount * sizeof(unsigned), w.stream));
         bool finished = false;
         rc = launch_chunk<true>(s, w, w.stream, pc, p, d_origin + 3 * b, d_dir + 3 * b, d_valid + b, n, nullptr, nullptr, nullptr, w.tmp_face1, w.tmp_face2, tile_w, tile_h, grid_mode, sub_cache(d_grid_cache, b, tile_w, tile_h),
-                                st, b, nullptr, &finished);
+                                st, b, nullptr, &finished, seed2 ? seed2 + b : nullptr);
         if (rc) return rc;
         { StageTimer t(s, w.stream, kStageLossBwdFused);
           k_loss_bwd_fused<<<DRT_BWD_BPC * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,

@@ -83,6 +83,10 @@ struct drt_scene {
     int32_t *range_lo = nullptr, *range_hi = nullptr;   // sorted-slot range of each binary node
     TriRec* tris = nullptr;        // [F] Morton order
     TriRec* tris_flat = nullptr;   // [F] face order (projected primary visibility: needs no tree)
+    int32_t* slot_of_face = nullptr;   // [F] face id -> slot of its record in `tris` (written by k_refit of every build / refit)
+    // drt_render_seed: per camera ray, the face id the refracted ray of that pixel hit in an earlier call (TraceSeed); one shot, consumed by
+    // the next drt_render_forward / drt_render_ray_loss_fused of exactly `n` rays
+    struct Seed { int32_t* face2 = nullptr; int64_t n = 0; } seed;
     hipStream_t build_stream = nullptr;   // the LBVH build runs here, beside the caller's next fills / projection pass
     hipEvent_t build_fork = nullptr, build_done = nullptr;
     bool build_pending = false;    // a build was enqueued on build_stream: consumers of the tree wait for build_done
@@ -188,6 +192,7 @@ struct drt_scene {
     bool fill_after_shade1 = true; // the late fills start behind k_shade1 (beside the VALU-bound second traversal only) instead of behind the cull stage: the
                                    // latency-bound first shading then has the memory system to itself (0.19 -> 0.09 ms per launch, step -1 %); DRT_FILL_AFTER_SHADE1=0
     bool fill_overlap = true;      // DRT_FILL_OVERLAP=0: the dense-output memsets of a DRT_GRID_TRUST call stay in front of the projection pass
+    bool hit_seed = true;          // DRT_HIT_SEED=0: drt_render_seed's seeds are ignored (A/B measurement)
     bool use_raster = true;        // DRT_RASTER=0: every primary ray takes the BVH path (A/B measurement)
     bool built = false;
 };

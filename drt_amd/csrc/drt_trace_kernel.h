@@ -53,6 +53,22 @@ __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// Temporal hit seeds (pipeline, traversal of the refracted rays; reference DiffRender.py:542 -- the second Dintersect of trace2).  The
+// caller is an optimisation loop: between two steps the vertices move by at most lr x clamp (reference optim.py:155-171), so the
+// triangle a pixel's refracted ray left the object through last step is almost always the one it leaves through now.  `store` holds, per
+// camera ray of the call, the face id the previous call on these rays found (-1: none; anything else out of range is ignored); a lane that
+// takes a new ray tests THAT triangle first -- its record of the current build, through `slot_of_face` -- and starts its traversal with
+// best_t / best_face / best_slot of that hit instead of +inf: every box behind it is culled from the first visit on.  The result is the
+// same bit for bit whatever the seed is: the seed is one of the tree's own triangles, tested by the same expression on the same record as
+// its leaf would test it, so the minimum over (t, face) of the candidates is the minimum the unseeded traversal finds; boxes are entered on
+// ties (drt_traverse.h), and a winner that fails the deferred hit-point condition goes to the exact second pass as before.  A stale or
+// wrong seed only weakens the bound.  The ray's result is written back for the next call.
+struct TraceSeed {
+    const int32_t* list_idx;        // list slot -> camera-ray index within the sub-batch (RayList::idx)
+    int32_t* store;                 // [rays of the sub-batch] face id per camera ray, read at refill, written at emit
+    const int32_t* slot_of_face;    // [n_tris] face id -> slot of its record in TraceCtx::tris (k_refit)
+};
+
 template <int MODE>
 __device__ __forceinline__ const float* trace_ray(const float* __restrict__ rays, const TraceOut& out, unsigned slot) {
     return rays + 6 * (int64_t)(MODE != 0 ? out.idx[slot] : (int32_t)slot);
@@ -72,10 +88,11 @@ __device__ __forceinline__ void trace_redo_push(int32_t* redo_list, unsigned* re
 // launch and put back to zero by that workgroup): one thread per ray with the spilling Stack.  It used to be a launch of its own, an
 // empty kernel that -- queued behind this launch while the neighbour pipeline's persistent grid holds every wave slot of the chip -- took
 // 0.11 ms to get through the dispatcher in every pipeline of every step (profiles/r03_kernel_summary.txt: 112 us per call, 4 us alone).
-template <bool ANY, int MODE>
+template <bool ANY, int MODE, bool SEED = false>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
                                                        TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count, unsigned* done_count,
-                                                       int refill_min, int inner_min, unsigned long long* stats) {
+                                                       int refill_min, int inner_min, unsigned long long* stats, TraceSeed sd = TraceSeed{nullptr, nullptr, nullptr}) {
+    static_assert(!SEED || (!ANY && MODE == 0), "seeds: closest hit over a pipeline list");
     __shared__ int32_t lds[kStackFast + 1 + kGuardRows][kPathBlock];     // 20 x 1 KB x 8 blocks = the CU's 160 KB; the top FOUR rows are FastStack's spare entries
     FastStack st;
     st.base = (drt::FastPtr)&lds[0][threadIdx.x]; st.stride = kPathBlock; st.depth = kStackFast - 3; st.reset(); st.overflow = false;
@@ -112,8 +129,12 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         const unsigned long long idle = __ballot(slot < 0 || fin);
         const bool refill = idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull);
         if ((refill || idle == ~0ull) && fin) {
-            if (trav_winner_ok(c.tris, s)) trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
-            else trace_redo_push(redo_list, redo_count, slot);
+            if (trav_winner_ok(c.tris, s)) {
+                trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
+                if (SEED && s.best_face >= 0) sd.store[sd.list_idx[slot]] = s.best_face;
+            } else {
+                trace_redo_push(redo_list, redo_count, slot);
+            }
             slot = -1;
         }
         if (refill) {
@@ -126,6 +147,10 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                     st.overflow = false;
                     slot = (int32_t)k;
                     lds[kStackFast][threadIdx.x] = 0;            // (nothing parked: DRT_LEAF_PARK)
+                    if (SEED) {
+                        const int32_t f = sd.store[sd.list_idx[k]];
+                        if ((uint32_t)f < (uint32_t)c.n_tris) trav_seed(c.tris, s, sd.slot_of_face[f]);
+                    }
                 }
             }
             taken += (unsigned)__popcll(idle);
@@ -232,6 +257,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             const float* e = trace_ray<MODE>(rays, out, (unsigned)rs);
             const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, sst);
             trace_emit<ANY, MODE>(out, rs, h.t, h.face);
+            if (SEED && h.face >= 0) sd.store[sd.list_idx[rs]] = h.face;
         }
     }
     if (threadIdx.x == 0) {

@@ -81,8 +81,38 @@ GRID_CACHE = True      # remember, per (origin, ray_dir) tensor pair, that its i
 _GRID_BYTES = 104      # DRT_GRID_CACHE_BYTES of include/drt_hip.h
 
 
+# Temporal hit seeds (include/drt_hip.h drt_render_seed): a ray tensor that comes back (TRUST mode of the grid cache below) carries an
+# int32 [N] buffer with the face each pixel's refracted ray left the object through in the previous call on it; the traversal of the
+# refracted rays starts from that triangle's distance.  Bit-identical results with any buffer content; 4 B per ray next to the 96 B of the
+# ray itself.  Created outside graph captures only (a captured fill would reset the seeds at every replay).
+HIT_SEED = os.environ.get("DRT_HIT_SEED", "1") != "0"
+
+
+def _hit_seed(ray_dir, n):
+    if not HIT_SEED:
+        return None
+    seed = getattr(ray_dir, "_drt_seed2", None)
+    if seed is not None and seed.shape[0] == n and seed.device == ray_dir.device:
+        return seed
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    seed = torch.full((n,), -1, dtype=torch.int32, device=ray_dir.device)
+    try:
+        ray_dir._drt_seed2 = seed
+    except Exception:
+        return None
+    return seed
+
+
+def _arm_seed(handle, grid, n):
+    """Registers the seeds of this call's ray tensor (third entry of _grid_cache's result) with the library: consumed by the next render call."""
+    seed = grid[2] if len(grid) > 2 else None
+    if seed is not None:
+        _lib.check(_lib.lib().drt_render_seed(handle, seed.data_ptr(), n))
+
+
 def _grid_cache(origin, ray_dir, n, w, h):
-    """(grid_mode, cache tensor or None) for a render call on these ray tensors.
+    """(grid_mode, cache tensor or None, hit seeds or None) for a render call on these ray tensors.
 
     The views of a capture are constants of the optimisation: the same tensor objects come back every iteration.  The
     first call on a pair ESTABLISHES, on the device, which of its images are pinhole ray grids in every single ray
@@ -101,7 +131,7 @@ def _grid_cache(origin, ray_dir, n, w, h):
             # All images verified in all rays -> DRT_GRID_ALL_VERIFIED: the launches that serve other rays are not issued.
             flags = rec[2].view(-1, _GRID_BYTES)[:, 96:104].contiguous().view(torch.int32)
             rec[3][0] = bool((flags != 0).all().item())
-        return 2 | (32 if rec[3][0] else 0), rec[2]
+        return 2 | (32 if rec[3][0] else 0), rec[2], _hit_seed(ray_dir, n)
     cache = torch.zeros((n // (w * h)) * _GRID_BYTES, dtype=torch.uint8, device=ray_dir.device)
     try:
         ray_dir._drt_grid = (key, weakref.ref(origin), cache, [None])
@@ -288,6 +318,7 @@ class _RenderTransparent(torch.autograd.Function):
         valid_idx = torch.empty(n, dtype=torch.int32, device=o.device) if want_list else None
         n_valid = torch.empty(1, dtype=torch.int64, device=o.device) if want_list else None
         with torch.cuda.device(o.device):
+            _arm_seed(scene.optix_mesh._h, grid, n)
             _lib.check(_lib.lib().drt_render_forward(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
                 out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
@@ -445,6 +476,7 @@ class _RenderRayLossFused(torch.autograd.Function):
         loss = torch.zeros((), dtype=torch.float64, device=o.device)
         grad_v = torch.zeros_like(v)
         with torch.cuda.device(o.device):
+            _arm_seed(scene.optix_mesh._h, grid, o.shape[0])
             _lib.check(_lib.lib().drt_render_ray_loss_fused(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), o.shape[0],
                 float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, *_tile_hint(o.shape[0]), grid[0], _lib.ptr(grid[1]), _stream()))

@@ -244,6 +244,7 @@ class FusedIteration:
                 o, d, sp = R._f64c(origin, "origin"), R._f64c(ray_dir, "ray_dir"), R._f64c(target, "screen_pixel")
                 va = R._flag_bytes(valid, "valid", n)
                 grid = R._grid_cache(origin, ray_dir, n, *R._tile_hint(n)) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
+                R._arm_seed(h, grid, n)
                 check(lib.drt_render_ray_loss_fused(h, vertices.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
                                                     float(R.intIOR), float(R.extIOR), self.losses[0:].data_ptr(), self.grads[0].data_ptr(), None,
                                                     *R._tile_hint(n), grid[0], ptr(grid[1]), _stream()))

@@ -183,6 +183,16 @@ int drt_prefill_wait(drt_scene_t* s, void* stream);
  * drt_render_forward, like drt_prefill_zero's.  Not while a graph is being captured. */
 int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint8_t* d_mask, int64_t n_rays,
                       const int32_t* d_valid_idx, const int64_t* d_n_valid, void* stream);
+/* Temporal hit seeds for the NEXT drt_render_forward / drt_render_ray_loss_fused on this scene of exactly `n_rays` rays (one shot; a call
+ * of another size ignores and forgets them).  d_seed_face2: int32 [n_rays], caller-owned, one entry per camera ray: the face id the
+ * REFRACTED ray of that pixel hit (traversal #2 of reference DiffRender.py:542) in an earlier call on the same rays, -1 for none -- any
+ * other value outside [0, F) is ignored, so a buffer that outlived a topology change is harmless.  The call tests that triangle first and
+ * starts the traversal with its distance as the bound, then writes the face it found back into the buffer (entries of rays without a
+ * second hit keep their value).  Results are identical bit for bit with any buffer content (drt_amd/csrc/drt_trace_kernel.h TraceSeed):
+ * the optimisation loop moves vertices by at most lr x clamp per step (reference optim.py:155-171), so last step's face is nearly always
+ * this step's -- what the seed buys is node visits.  The reference has no counterpart (OptiX Prime keeps no state between queries).
+ * The buffer must stay valid until the call it is consumed by has finished on its stream.  DRT_HIT_SEED=0 disables. */
+int drt_render_seed(drt_scene_t* s, int32_t* d_seed_face2, int64_t n_rays);
 /* ray_loss (reference optim.py:91-108) AND its vertex gradient in one pass over the forward's list of completed paths
  * (drt_render_forward's d_valid_idx / d_n_valid, face ids from the same call): *d_loss += the loss (float64 scalar, zero it first)
  * and d_grad_verts float64 [V,3] += d loss / d vertices with a UNIT seed (the caller scales it by the incoming gradient of the loss:
