@@ -301,6 +301,92 @@ def smooth_fixture(DR, optim, scene, mesh, center, extent):
                         param0=steps[0]["param"], param1=steps[1]["param"], loss_str0=steps[0]["loss_str"], loss_str1=steps[1]["loss_str"])
 
 
+def trajectory_fixture(DR, optim, mesh, center, extent, iters=60, every=10, res=64, seed=12):
+    """One pass of the reference's own loop (optim.py:190-215: update_verticex -> all_loss -> backward -> limit_hook -> SGD
+    nesterov), `iters` iterations at the reference's hyper-parameters (config.py:18-39: lr = start_lr of pass 0), with the
+    reference's own Loss_calculator and its own stochastic view order: the imported captured_data.Data's
+    ray_view_generator / silh_view_generator (captured_data.py:61-82) under np.random.seed(seed), one refraction view and
+    eight silhouette views per iteration.  The capture is synthetic (the .h5 captures are not distributed): 72 turntable
+    views at res x res of a ground-truth mesh (the smoothed hand hull displaced along its normals), traced by the oracle
+    -- inputs, stored in the fixture.  Stored outputs: the realised view schedule, loss / loss string / max |grad| of every
+    iteration, the parameter every `every` iterations and at the end."""
+    sys.path.insert(0, REF)
+    import captured_data as cd
+    cd.device = "cpu"
+    Vs = _smooth(mesh)
+    with __import__("tempfile").TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "hand_smooth.ply")
+        mesh_io.write_ply(path, Vs, mesh.faces)
+        scene = DR.Scene(path)
+    DR.resx = DR.resy = res
+    gt = views.displaced_ground_truth(mesh_io.TriMesh(Vs, mesh.faces), sigma=0.4, seed=5)
+    gt_mesh = orc.Mesh(gt.faces, torch.tensor(gt.vertices))
+
+    def render_gt(o, d):
+        with torch.no_grad():
+            return orc.render_transparent(gt_mesh, o, d, IOR)
+
+    def hit_gt(o, d):
+        return orc.intersect_ids(gt_mesh, o, d)[1]
+
+    vs = views.make_views(render_gt, hit_gt, center, extent, 72, res, res)
+    data = cd.Data.__new__(cd.Data)
+    data.name, data.num_view, data.resx, data.resy = "hand", 72, res, res
+    data.Views = vs
+    schedule = {"ray": [], "silh": []}
+    get_view = data.get_view
+
+    def logged_get_view(k):         # (the order the reference's generators hand the views out in, as consumed by all_loss)
+        schedule["cur"].append(int(k))
+        return get_view(k)
+    data.get_view = logged_get_view
+
+    HP = dict(ray_w=40, sm_w=0.08, vh_w=2e-3, momentum=0.95)
+    np.random.seed(seed)
+    lc = optim.Loss_calculator(scene, data, HP)
+    init_vertices = torch.tensor(Vs, dtype=torch.float64)
+    parameter = torch.zeros(init_vertices.shape, dtype=torch.float64, requires_grad=True)
+
+    def limit_hook(grad):        # the reference's closure (optim.py:155-162) is local to optimize(); same statements
+        grad[torch.isnan(grad)] = 0
+        grad[grad > 1] = 1
+        grad[grad < -1] = -1
+        return grad
+
+    parameter.register_hook(limit_hook)
+    lr = 0.1
+    opt = torch.optim.SGD([parameter], lr=lr, momentum=HP["momentum"], nesterov=True)
+    rec = dict(loss=[], loss_str=[], gmax=[], params=[], param_its=[])
+    for it in range(iters):
+        opt.zero_grad()
+        vertices = init_vertices + parameter
+        scene.update_verticex(vertices)
+        schedule["cur"] = []
+        loss, loss_str = lc.all_loss()
+        loss.backward()
+        schedule["ray"].append(schedule["cur"][0])
+        schedule["silh"].append(schedule["cur"][1:])
+        assert len(schedule["cur"]) == 9
+        rec["loss"].append(loss.item()); rec["loss_str"].append(loss_str); rec["gmax"].append(parameter.grad.abs().max().item())
+        opt.step()
+        if (it + 1) % every == 0 or it + 1 == iters:
+            rec["params"].append(parameter.detach().clone().numpy()); rec["param_its"].append(it + 1)
+        if it % 10 == 0:
+            print("trajectory", it, loss_str, "LOSS", loss.item(), "gmax", rec["gmax"][-1])
+    used = sorted(set(schedule["ray"]))
+    np.savez_compressed(
+        os.path.join(OUT, "hand_trajectory.npz"), vertices=Vs.astype(np.float32), res=res, lr=lr, momentum=HP["momentum"], ior=IOR,
+        ray_w=HP["ray_w"], sm_w=HP["sm_w"], vh_w=HP["vh_w"], mean_len=scene.mean_len, seed=seed,
+        ray_schedule=np.array(schedule["ray"]), silh_schedule=np.array(schedule["silh"]),
+        # inputs of the synthetic capture: targets of the refraction views that were used, soft masks of all 72 views (float32 holds them exactly:
+        # process_mask yields multiples of 1/2 clipped EDT values -- checked below)
+        ray_views=np.array(used), screen_pixel=np.stack([vs[k][0].numpy() for k in used]),
+        soft_mask=np.stack([vs[k][2].numpy() for k in range(72)]),
+        loss=np.array(rec["loss"]), loss_str=np.array(rec["loss_str"]), gmax=np.array(rec["gmax"]),
+        param_its=np.array(rec["param_its"]), params=np.stack(rec["params"]))
+    print("wrote hand_trajectory.npz: loss", rec["loss"][0], "->", rec["loss"][-1], "distinct ray views", len(used))
+
+
 def degenerate_fixture(DR, optim, mesh, center, extent):
     """A closed mesh with the defect SURVEY section 4 notes in monkey_vh.ply / dog_vh.ply: a zero-length edge, i.e. two
     zero-area faces (monkey_vh: faces with a duplicated vertex position).  Made from the smoothed hand hull by moving
@@ -471,6 +557,8 @@ def main():
         return degenerate_fixture(DR, optim, mesh, center, extent)
     if only == {"horse"}:
         return horse_fixture(DR, optim)
+    if only == {"trajectory"}:
+        return trajectory_fixture(DR, optim, mesh, center, extent)
     if only == {"mouse"}:       # BASELINE.json configs[2]: mouse_vh.ply subdivided to 36 984 triangles
         return big_mesh_fixture(DR, optim, "mouse", 29, "mouse37k_r256_v29")
     scene = DR.Scene(path)
@@ -481,6 +569,7 @@ def main():
         for view_id in (5, 23, 41):
             render_fixture(DR, optim, scene, mesh, center, extent, res, view_id, f"hand_r{res}_v{view_id}")
     smooth_fixture(DR, optim, scene, mesh, center, extent)
+    trajectory_fixture(DR, optim, mesh, center, extent)
     degenerate_fixture(DR, optim, mesh, center, extent)
     horse_fixture(DR, optim)
     big_mesh_fixture(DR, optim, "mouse", 29, "mouse37k_r256_v29")

@@ -98,3 +98,19 @@ def test_capture_loader_roundtrip(tmp_path):
         cd.get_data({"name": "teapot", "num_view": 72})
     with pytest.raises(FileNotFoundError):
         cd.get_data({"name": "dog", "num_view": 72}, data_path=str(tmp_path))
+
+
+def test_view_order_of_the_recorded_trajectory():
+    """The stochastic view order of tests/golden/hand_trajectory.npz -- produced by the reference's own generators (captured_data.py:61-82)
+    inside its own Loss_calculator (one refraction view, then eight silhouette views per iteration) under np.random.seed -- comes out of
+    drt_amd.captured_data.Data's generators under the same seed, consumed in the same order."""
+    from conftest import golden
+    from drt_amd import captured_data as cd
+    g = golden("hand_trajectory")
+    d = cd.Data()
+    d.name, d.num_view, d.n_total = "hand", 72, 72
+    np.random.seed(int(g["seed"]))
+    ray, silh = d.ray_view_generator(), d.silh_view_generator()
+    for it in range(len(g["ray_schedule"])):
+        assert next(ray) == int(g["ray_schedule"][it]), it
+        assert [next(silh) for _ in range(8)] == [int(k) for k in g["silh_schedule"][it]], it

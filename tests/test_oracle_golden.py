@@ -348,3 +348,41 @@ def test_degenerate_faces_follow_the_reference(hand):
     close(grad, g["step_grad"], rtol=1e-8, atol=1e-12)
     param, _ = orc.sgd_nesterov_step(torch.zeros_like(Vs), grad, None, float(g["lr"]), float(g["momentum"]))
     close(param, g["step_param"], rtol=1e-8, atol=1e-13)
+
+
+def test_long_trajectory_first_iterations(hand):
+    """The first 20 iterations of the recorded pass of the reference's loop (tests/golden/hand_trajectory.npz: optim.py:190-215 with the
+    reference's own Loss_calculator, 1 stochastic refraction view + 8 silhouette views + smoothness per iteration, limit_hook, nesterov)
+    replayed by the oracle: losses of every iteration and the parameter checkpoints at 10 and 20.  (The HIP path replays all 60 on the
+    GPU, tests/test_gpu_trajectory.py; the oracle is the checker there and is itself pinned here.)"""
+    import trajectory_case as tc
+    g = tc.load()
+    topo = golden("hand_topology")
+    data = tc.RecordedCapture(g, hand.vertices, "cpu")
+    res = data.resx
+    Vs = torch.tensor(g["vertices"].astype(np.float64))
+    Edges, E2F = torch.tensor(topo["Edges"]), torch.tensor(topo["E2F"])
+    ray_view, silh_view = data.ray_view_generator(), data.silh_view_generator()
+    param, buf = torch.zeros_like(Vs), None
+    checkpoints = {int(it): p for it, p in zip(g["param_its"], g["params"])}
+    for it in range(20):
+        p = param.clone().requires_grad_(True)
+        V = Vs + p
+        mesh = orc.Mesh(hand.faces, V)
+        sp, valid, _, o, d, _ = data.get_view(next(ray_view))
+        oo, od, mk = orc.render_transparent(mesh, o, d, float(g["ior"]))
+        ray = orc.ray_loss(oo, od, mk, sp, valid)
+        vh = 0
+        for _ in range(8):
+            _, _, soft, o_k, _, cam = data.get_view(next(silh_view))
+            vh = vh + orc.vh_loss_view(mesh, Edges, E2F, cam, o_k[0], soft, res, res)
+        sm = orc.sm_loss(V, E2F)
+        loss = orc.total_loss(ray, vh, sm, res, float(g["mean_len"]))
+        assert loss.item() == pytest.approx(float(g["loss"][it]), rel=1e-9), it
+        assert f"ray={ray:g} vh={vh:g} sm={sm:g}" == str(g["loss_str"][it]), it
+        grad, = torch.autograd.grad(loss, p)
+        grad = orc.limit_grad(grad)
+        assert grad.abs().max().item() == pytest.approx(float(g["gmax"][it]), rel=1e-7)
+        param, buf = orc.sgd_nesterov_step(param, grad, buf, float(g["lr"]), float(g["momentum"]))
+        if it + 1 in checkpoints:
+            close(param, checkpoints[it + 1], rtol=1e-7, atol=1e-10)
