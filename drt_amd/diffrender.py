@@ -851,4 +851,7 @@ class _VhLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         (grad_v,) = ctx.saved_tensors
-        return (grad_v * g_loss, None, None, None) + (None,) * ctx.n_in
+        # The reference's silhouette samples are a float32 tensor (`output`, torch's default dtype, DiffRender.py:251): autograd casts the
+        # incoming d loss / d output to float32 before primary_edge_sample.backward multiplies it in (DiffRender.py:263-267).  The drop-in
+        # pair does the same by construction; here the scalar is rounded the same way (tests/test_gpu_trajectory.py).
+        return (grad_v * g_loss.to(torch.float32).to(torch.float64), None, None, None) + (None,) * ctx.n_in
