@@ -40,6 +40,7 @@ SIGNATURES = {
     "drt_prefill_zero": (_c.c_int, [_P, _P, _I64, _P]),
     "drt_prefill_wait": (_c.c_int, [_P, _P]),
     "drt_outputs_clean": (_c.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P]),
+    "drt_outputs_cancel": (_c.c_int, [_P]),
     "drt_render_seed": (_c.c_int, [_P, _P, _I64]),
     "drt_ray_loss_listed_grad": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "drt_ray_loss_listed_grad_split": (_c.c_int, [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -861,9 +861,11 @@ __global__ void k_store_count(const unsigned* __restrict__ count, int64_t* __res
 }
 
 // Behind the join of a call cut into sub-batches: segment j of the list of completed paths (written at offset `src` = the index of the
-// sub-batch's first ray) moves down behind the segments before it.  dst <= src always; when the two ranges do not overlap every block
-// copies its share, otherwise (more than half of the rays complete) block 0 copies chunk by chunk in ascending order.  The launch for the
-// last segment also stores the total.
+// sub-batch's first ray) moves down behind the segments before it.  dst <= src always.  The list is a SET (within a segment its order is
+// that of the atomics that filled it), so when the two ranges overlap (more than half of the rays of the sub-batches in front complete)
+// only the segment's last src - dst entries move, into the hole [dst, src) in front of it: source [dst + len, src + len) and
+// destination are disjoint then (dst + len > src), and every block copies its share -- round 4 walked the whole segment with ONE block
+// in ascending chunks, tens of milliseconds for an object that fills the frame.  The launch for the last segment also stores the total.
 __global__ void __launch_bounds__(256) k_join_lists(int32_t* list, const unsigned* __restrict__ counts, int j, int64_t src, int last,
                                                     unsigned* total_u, int64_t* total_i64) {
     int64_t dst = 0;
@@ -871,18 +873,9 @@ __global__ void __launch_bounds__(256) k_join_lists(int32_t* list, const unsigne
     const int64_t len = counts[j];
     if (last && blockIdx.x == 0 && threadIdx.x == 0) { *total_u = (unsigned)(dst + len); if (total_i64) *total_i64 = dst + len; }
     if (dst == src || len == 0) return;
-    if (dst + len <= src) {
-        for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < len; k += (int64_t)gridDim.x * blockDim.x) list[dst + k] = list[src + k];
-        return;
-    }
-    if (blockIdx.x != 0) return;
-    for (int64_t base = 0; base < len; base += blockDim.x) {
-        const int64_t k = base + threadIdx.x;
-        const int32_t v = k < len ? list[src + k] : 0;
-        __syncthreads();
-        if (k < len) list[dst + k] = v;
-        __syncthreads();
-    }
+    const bool overlap = dst + len > src;
+    const int64_t n_move = overlap ? src - dst : len, from = overlap ? dst + len : src;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_move; k += (int64_t)gridDim.x * blockDim.x) list[dst + k] = list[from + k];
 }
 
 // drt_outputs_clean: the rows a render call left non-zero are exactly its list of completed paths; zero them again (51 B per listed row
@@ -1597,10 +1590,30 @@ int drt_render_seed(drt_scene_t* s, int32_t* d_seed_face2, int64_t n_rays) {
 }
 
 static int flush_clean(drt_scene* s, hipStream_t st);
+static int render_forward_impl(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                               double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
+                               int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h,
+                               int grid_mode, void* d_grid_cache, void* stream);
 int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
                        int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h,
                        int grid_mode, void* d_grid_cache, void* stream) {
+    const int rc = render_forward_impl(s, d_verts, d_origin, d_dir, n_rays, ior_int, ior_ext, d_out_ori, d_out_dir, d_mask, d_face1, d_face2, d_valid_idx,
+                                       d_n_valid, tile_w, tile_h, grid_mode, d_grid_cache, stream);
+    if (rc != DRT_OK && s) {
+        // a call that failed must not leave raw pointers of its caller registered: the caller is about to release those buffers, and the
+        // next call would zero "rows" of, or skip the fills of, memory that belongs to somebody else by then
+        s->clean = drt_scene::Clean{};
+        s->n_prefill = 0;
+        s->seed = drt_scene::Seed{};
+        s->segs = drt_scene::Segs{};
+    }
+    return rc;
+}
+static int render_forward_impl(drt_scene_t* s, const double* d_verts, const double* d_origin, const double* d_dir, int64_t n_rays,
+                               double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
+                               int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h,
+                               int grid_mode, void* d_grid_cache, void* stream) {
     CHECK_BUILT(s);
     if (n_rays < 0 || n_rays > INT32_MAX) return fail(DRT_E_INVALID, "ray count out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -1676,7 +1689,9 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
     if (segmented) {
         for (int j = 1; j < pl.count; ++j)
             k_join_lists<<<2 * s->n_cu, 256, 0, st>>>(d_valid_idx, s->seg_counts, j, (int64_t)j * pl.size, j + 1 == pl.count, s->vcount, d_n_valid);
-        s->segs = drt_scene::Segs{d_valid_idx, pl.count, 0};      // (sub-batch 0 runs on internal stream 0)
+        // (not while a graph is being captured: a later EAGER drt_ray_loss_listed_grad_split on the same list would start on internal stream 0
+        // with no ordering against the replayed graph that fills the list)
+        if (cap == hipStreamCaptureStatusNone) s->segs = drt_scene::Segs{d_valid_idx, pl.count, 0};      // (sub-batch 0 runs on internal stream 0)
     } else if (d_n_valid) {
         k_store_count<<<1, 64, 0, st>>>(s->vcount, d_n_valid);
     }
@@ -1733,6 +1748,12 @@ int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint
     s->prefill[1].ptr = d_out_dir; s->prefill[1].bytes = (int64_t)sizeof(double) * 3 * n_rays;
     s->prefill[2].ptr = d_mask;    s->prefill[2].bytes = 3 * n_rays;
     s->n_prefill = 3;
+    return DRT_OK;
+}
+
+int drt_outputs_cancel(drt_scene_t* s) {
+    CHECK_SCENE(s);
+    if (s->clean.rows) { s->clean = drt_scene::Clean{}; s->n_prefill = 0; }
     return DRT_OK;
 }
 

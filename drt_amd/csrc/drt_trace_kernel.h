@@ -143,14 +143,20 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                 const unsigned k = ((part_lo + (j >> 6) * n_waves + wave) << 6) | (j & 63u);
                 if (j < my_rays && k < n) {
                     const float* e = trace_ray<MODE>(rays, out, k);
-                    trav_init(s, st, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]});
+                    const f3 ro{e[0], e[1], e[2]}, rd{e[3], e[4], e[5]};
+                    // (the seed's triangle test comes BEFORE trav_init: the reciprocal direction and its products are not alive yet, and the
+                    // kernel stays within its 64 registers without a spill)
+                    float seed_t = INFINITY;
+                    int32_t seed_face = -1, seed_slot = -1;
+                    if (SEED) {
+                        const int32_t f = sd.store[sd.list_idx[k]];
+                        if ((uint32_t)f < (uint32_t)c.n_tris) trav_seed(c.tris, ro, rd, sd.slot_of_face[f], seed_t, seed_face, seed_slot);
+                    }
+                    trav_init(s, st, ro, rd);
+                    if (SEED) { s.best_t = seed_t; s.best_face = seed_face; s.best_slot = seed_slot; }
                     st.overflow = false;
                     slot = (int32_t)k;
                     lds[kStackFast][threadIdx.x] = 0;            // (nothing parked: DRT_LEAF_PARK)
-                    if (SEED) {
-                        const int32_t f = sd.store[sd.list_idx[k]];
-                        if ((uint32_t)f < (uint32_t)c.n_tris) trav_seed(c.tris, s, sd.slot_of_face[f]);
-                    }
                 }
             }
             taken += (unsigned)__popcll(idle);
@@ -256,8 +262,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             const int32_t rs = __hip_atomic_load(&redo_list[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float* e = trace_ray<MODE>(rays, out, (unsigned)rs);
             const Hit h = traverse<ANY>(c.nodes, c.tris, c.n_tris, f3{e[0], e[1], e[2]}, f3{e[3], e[4], e[5]}, sst);
-            trace_emit<ANY, MODE>(out, rs, h.t, h.face);
-            if (SEED && h.face >= 0) sd.store[sd.list_idx[rs]] = h.face;
+            trace_emit<ANY, MODE>(out, rs, h.t, h.face);       // (a ray of the second pass keeps its old seed: rare, and any seed is a valid one)
         }
     }
     if (threadIdx.x == 0) {

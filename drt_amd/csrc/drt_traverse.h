@@ -308,14 +308,14 @@ DRT_HD bool trav_leaf_test(const TriRec* __restrict__ tris, TravState& s, int32_
 }
 
 // A seed: the record in slot `ts` tested as a leaf would test it under DEFER (drt_trace_kernel.h TraceSeed) before the first visit.
-DRT_HD void trav_seed(const TriRec* __restrict__ tris, TravState& s, int32_t ts) {
+DRT_HD void trav_seed(const TriRec* __restrict__ tris, f3 o, f3 d, int32_t ts, float& best_t, int32_t& best_face, int32_t& best_slot) {
     const F4* tp = reinterpret_cast<const F4*>(tris + ts);
     const F4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
     float t;
-    if (tri_hit_mt(s.o, s.d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
+    if (tri_hit_mt(o, d, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z}, t)) {
         int32_t face;
         memcpy(&face, &p0.w, 4);
-        s.best_t = t; s.best_face = face; s.best_slot = ts;
+        best_t = t; best_face = face; best_slot = ts;
     }
 }
 

@@ -177,8 +177,10 @@ PREFILL_MIN_RAYS = int(os.environ.get("DRT_PREFILL_MIN_RAYS", 1 << 25))         
 # show), same stream -- the NEXT call of that size zeroes the listed rows (drt_outputs_clean: 51 B per completed path instead of 51 B
 # per ray) and renders into the same memory: no fill of the dense outputs at all (72 x 1024^2: 2.38 -> 1.8 ms per step).  What a call
 # returns are fresh tensor objects (detached aliases: same storage, same version counter) that nothing else references; a caller who
-# keeps its outputs alive simply gets fresh allocations and the fills, as before.  The price: the last outputs (51 B per ray) stay
-# allocated between calls.  Not inside a graph capture (a replay must own its buffers).
+# keeps its outputs alive simply gets fresh allocations and the fills, as before.  The price in memory: the usual loop rebinds
+# `out = render()` only after the call has returned, so the previous outputs are still held when the pool is asked and the pool ping-pongs
+# between TWO entries: two output sets plus their two row lists (2 x 55 B per ray) stay resident per scene (`Scene.release_outputs()`
+# drops them).  Not inside a graph capture (a replay must own its buffers).
 # (The use count of a storage is read through torch._C._storage_Use_Count, which torch's own CUDA-graph trees rely on; a torch without it
 # simply does not recycle.  As with any caching allocator, a caller who used the outputs on ANOTHER stream must have ordered that work in front
 # of the stream of its next render call before dropping them.)
@@ -219,11 +221,15 @@ SPLIT_LOSS = os.environ.get("DRT_SPLIT_LOSS", "1") != "0"
 SPLIT_LOSS_MIN_RAYS = int(os.environ.get("DRT_SPLIT_LOSS_MIN_RAYS", 1 << 25))          # below, a call is not cut into sub-batches (DRT_MIN_SUB_LOG2 = 24 per sub-batch); zeroing the accumulators
                                                                                  # in front of the render call anyway (two launches off the tail, two more in front of the fork) measured +1 % at 9 and 18 views
 _seen_targets = {}
+_render_seq = [0]          # render_transparent calls enqueued so far (any scene): a clock for "was complete before THAT call"
 
 
-def _targets_seen_before(sp, valid):
-    """True when these very tensors (same objects, same storage, unchanged version counters) were the targets of an earlier ray_loss:
-    their content was complete long before the render call whose loss is being taken.  Registers them either way."""
+def _targets_seen_before(sp, valid, render_seq):
+    """True when these very tensors (same objects, same storage, unchanged version counters) were the targets of a ray_loss that was
+    issued BEFORE the render call number ``render_seq`` was enqueued: their content was then complete before that call's fork, which is all
+    the internal stream is ordered behind.  (Seen in an earlier ray_loss is not enough: render A, render B, build the targets on the
+    stream, ray_loss(A, tgt), ray_loss(B, tgt) -- the second loss would find them registered although they were produced behind B's fork.)
+    Registers them either way, with the current clock."""
     ok = True
     for t in (sp, valid):
         rec = _seen_targets.get(id(t))
@@ -231,13 +237,16 @@ def _targets_seen_before(sp, valid):
             ok = False
             if len(_seen_targets) > 4096:
                 _seen_targets.clear()
-            _seen_targets[id(t)] = (weakref.ref(t), t._version, t.data_ptr())
+            _seen_targets[id(t)] = (weakref.ref(t), t._version, t.data_ptr(), _render_seq[0])
+        elif rec[3] >= render_seq:
+            ok = False
     return ok
 
 
 class _GradLink:
     def __init__(self):
         self.pre = None        # (stash zeros_like(vertices), loss zeros(())) created before the render call was enqueued (SPLIT_LOSS)
+        self.seq = 0           # _render_seq of the render call this link belongs to
         self.pending = []
         self._token = None
         self.paths = None
@@ -285,11 +294,10 @@ class _RenderTransparent(torch.autograd.Function):
                 pool = om._out_pool = _OutputPool()
             ent = pool.take(n, o.device, getattr(stream_id, "value", stream_id))
             if ent is not None:
-                # the outputs of an earlier call that nobody holds any more: zero the rows that call set, render into the same memory
+                # the outputs of an earlier call that nobody holds any more: the rows that call set are zeroed (drt_outputs_clean, registered
+                # below, right in front of the render call and behind every allocation of this one) and the call renders into the same memory
                 bases, counts = ent[3], ent[4]
-                with torch.cuda.device(o.device):
-                    _lib.check(_lib.lib().drt_outputs_clean(om._h, bases[0].data_ptr(), bases[1].data_ptr(), bases[2].data_ptr(), n,
-                                                            ent[5].data_ptr(), ent[6].data_ptr(), stream_id))
+        took = ent if recycle and bases is not None else None
         if bases is not None:
             if pre is not None:
                 with torch.cuda.device(o.device):
@@ -307,6 +315,7 @@ class _RenderTransparent(torch.autograd.Function):
             mask = torch.empty((n, 3), dtype=torch.uint8, device=o.device)
             out_dir = torch.empty((n, 3), dtype=torch.float64, device=o.device)
         pre = None
+        bases_in = bases
         if recycle and bases is None:
             bases = (out_ori, out_dir, mask)
             counts = tuple(_use_count(t) for t in bases)          # with nobody but these three names holding them
@@ -314,16 +323,32 @@ class _RenderTransparent(torch.autograd.Function):
         face2 = torch.empty(n, dtype=torch.int32, device=o.device)
         if (SPLIT_LOSS and need_bwd and EAGER_LOSS_GRAD and link is not None and not capturing and n >= SPLIT_LOSS_MIN_RAYS):
             link.pre = (torch.zeros_like(v), torch.zeros((), dtype=torch.float64, device=o.device))
+        _render_seq[0] += 1
+        if link is not None:
+            link.seq = _render_seq[0]
         want_list = need_bwd or recycle
         valid_idx = torch.empty(n, dtype=torch.int32, device=o.device) if want_list else None
         n_valid = torch.empty(1, dtype=torch.int64, device=o.device) if want_list else None
         with torch.cuda.device(o.device):
-            _arm_seed(scene.optix_mesh._h, grid, n)
-            _lib.check(_lib.lib().drt_render_forward(
-                scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
-                out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
-                _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0] | (0 if DENSE_FACE_IDS else 16), _lib.ptr(grid[1]), stream_id))
-            if PREFILL_NEXT and not recycle and (grid[0] & 3) == 2 and n >= PREFILL_MIN_RAYS and not capturing and getattr(om, "_prefilled", None) is None:
+            # The library is handed raw pointers of buffers only this frame keeps alive (`took`: the pooled outputs and their row list):
+            # nothing that can raise sits between the registration and the call that consumes it, and a call that fails withdraws them
+            # itself (drt_render_forward) -- a request left behind would have the next call zero "rows" of freed memory.
+            try:
+                if took is not None:
+                    _lib.check(_lib.lib().drt_outputs_clean(om._h, bases_in[0].data_ptr(), bases_in[1].data_ptr(), bases_in[2].data_ptr(), n,
+                                                            took[5].data_ptr(), took[6].data_ptr(), stream_id))
+                _arm_seed(scene.optix_mesh._h, grid, n)
+                _lib.check(_lib.lib().drt_render_forward(
+                    scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, float(ior_int), float(ior_ext),
+                    out_ori.data_ptr(), out_dir.data_ptr(), mask.data_ptr(), face1.data_ptr(), face2.data_ptr(),
+                    _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0] | (0 if DENSE_FACE_IDS else 16), _lib.ptr(grid[1]), stream_id))
+            except BaseException:
+                _lib.lib().drt_outputs_cancel(om._h)
+                raise
+            # (with recycling on: only for a caller who evidently KEEPS its outputs -- the pool had nothing to offer for this call and for the one
+            # before it; the steady state of a loop that drops them never gets here)
+            missed, om._recycle_missed = getattr(om, "_recycle_missed", 0), (0 if took is not None or not recycle else getattr(om, "_recycle_missed", 0) + 1)
+            if PREFILL_NEXT and (not recycle or (took is None and missed >= 2)) and (grid[0] & 3) == 2 and n >= PREFILL_MIN_RAYS and not capturing and getattr(om, "_prefilled", None) is None:
                 # outputs of the next call of this size: allocated now, zeroed on the library's idle stream behind this forward pass
                 h = scene.optix_mesh._h
                 nxt_ori = torch.empty((n, 3), dtype=torch.float64, device=o.device)
@@ -410,7 +435,7 @@ class _RayLoss(torch.autograd.Function):
                 # loss + unit-seed vertex gradient in one pass over the completed paths (see EAGER_LOSS_GRAD)
                 scene, v, o, d, face1, face2, ior = link.render
                 pre, link.pre = link.pre, None
-                early = pre is not None and _targets_seen_before(screen_pixel, valid) and sp.data_ptr() == screen_pixel.data_ptr() and va.data_ptr() == valid.data_ptr()
+                early = pre is not None and _targets_seen_before(screen_pixel, valid, link.seq) and sp.data_ptr() == screen_pixel.data_ptr() and va.data_ptr() == valid.data_ptr()
                 if early:      # accumulators zeroed before the render call: the head of the list can be processed beside the pipelines (SPLIT_LOSS)
                     ctx.stash, loss = pre
                 else:
@@ -617,6 +642,19 @@ class Scene(StepwiseMixin):
     def render_mask(self, origin, ray_dir):
         optix_ray = torch.cat([origin.detach().to(torch.float32), ray_dir.detach().to(torch.float32)], dim=1)
         return self.optix_mesh.intersect_any(optix_ray).to(Float)
+
+    def release_outputs(self):
+        """Drops the dense outputs this scene keeps for re-use (RECYCLE_OUTPUTS: up to two sets of 55 B per ray) and the buffers zeroed
+        ahead of time (PREFILL_NEXT); the next render call allocates and fills fresh ones."""
+        om = self.optix_mesh
+        with torch.cuda.device(self._dev):
+            _lib.check(_lib.lib().drt_outputs_cancel(om._h))
+            if getattr(om, "_prefilled", None) is not None:
+                _lib.check(_lib.lib().drt_prefill_wait(om._h, _stream()))
+        om._prefilled = None
+        pool = getattr(om, "_out_pool", None)
+        if pool is not None:
+            pool.entries.clear()
 
     # ------------------------------------------------------------------ refraction path
     def render_transparent(self, origin: torch.Tensor, ray_dir: torch.Tensor):

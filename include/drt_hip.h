@@ -183,6 +183,10 @@ int drt_prefill_wait(drt_scene_t* s, void* stream);
  * drt_render_forward, like drt_prefill_zero's.  Not while a graph is being captured. */
 int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint8_t* d_mask, int64_t n_rays,
                       const int32_t* d_valid_idx, const int64_t* d_n_valid, void* stream);
+/* Withdraws a drt_outputs_clean request that no drt_render_forward has taken yet (the caller could not make the render call after all:
+ * an allocation failed in between): the library forgets the five pointers without touching the memory.  No-op without a pending request.
+ * A drt_render_forward that returns an error withdraws the request (and every other pointer registered for it) by itself. */
+int drt_outputs_cancel(drt_scene_t* s);
 /* Temporal hit seeds for the NEXT drt_render_forward / drt_render_ray_loss_fused on this scene of exactly `n_rays` rays (one shot; a call
  * of another size ignores and forgets them).  d_seed_face2: int32 [n_rays], caller-owned, one entry per camera ray: the face id the
  * REFRACTED ray of that pixel hit (traversal #2 of reference DiffRender.py:542) in an earlier call on the same rays, -1 for none -- any

@@ -125,16 +125,32 @@ def test_output_pool_hands_buffers_out_only_when_nobody_else_holds_them():
     assert len(pool.entries) == R._OutputPool.MAX == 2 and [e[0] for e in pool.entries] == [5, 6]
 
 
-def test_targets_are_known_complete_only_from_their_second_use_on():
+def test_targets_are_known_complete_only_when_seen_before_the_render_call():
     """diffrender._targets_seen_before (SPLIT_LOSS): the early start of the loss pass is taken only for target tensors that went through
-    ray_loss before as the same objects, storage and version."""
+    ray_loss as the same objects, storage and version BEFORE the render call whose loss is taken was enqueued (the internal stream is
+    ordered behind that call's fork only)."""
     import torch
     from drt_amd import diffrender as R
     sp, valid = torch.zeros(5, 3, dtype=torch.float64), torch.ones(5, dtype=torch.bool)
-    assert not R._targets_seen_before(sp, valid)
-    assert R._targets_seen_before(sp, valid)
+
+    def render():                                           # what _RenderTransparent.forward does to the clock
+        R._render_seq[0] += 1
+        return R._render_seq[0]
+
+    a = render()
+    assert not R._targets_seen_before(sp, valid, a)        # first use: registered now
+    b = render()
+    assert R._targets_seen_before(sp, valid, b)            # the usual loop: seen in the previous iteration's loss
     sp.add_(1.0)                                           # written since: not known to be complete any more ...
-    assert not R._targets_seen_before(sp, valid)
-    assert R._targets_seen_before(sp, valid)               # ... until it has been seen again in that state
+    c = render()
+    assert not R._targets_seen_before(sp, valid, c)
+    d = render()
+    assert R._targets_seen_before(sp, valid, d)            # ... until it has been seen again in that state, before the call
     other = torch.zeros(5, 3, dtype=torch.float64)
-    assert not R._targets_seen_before(other, valid)
+    assert not R._targets_seen_before(other, valid, render())
+    # render A, render B, targets built on the stream, ray_loss(A, tgt), ray_loss(B, tgt): registered by A's loss -- but behind B's fork
+    tgt, v2 = torch.zeros(5, 3, dtype=torch.float64), torch.ones(5, dtype=torch.bool)
+    seq_a, seq_b = render(), render()
+    assert not R._targets_seen_before(tgt, v2, seq_a)
+    assert not R._targets_seen_before(tgt, v2, seq_b)
+    assert R._targets_seen_before(tgt, v2, render())
