@@ -36,8 +36,17 @@ __global__ void __launch_bounds__(64) k_fit_views(const double* __restrict__ ori
 // the price of 64 ray loads per image.  An image that fails is re-fitted from its corner rays on the spot and loses `all` -- in the
 // working copy AND in the cache -- so that every one of its rays is verified individually (k_cull_listed's general path), in this
 // call and in every later one, exactly as in a call without a cache.
+// The CANARY (`salt` != 0): besides the fixed lattice every lane re-verifies one more ray of the image at a pseudo-random pixel that changes
+// from call to call (a hash of the call's salt, the image and the lane): 64 rays per image and call that a partial overwrite behind the
+// version counter's back (a block of rows written through a raw pointer, `t.data[...] = ...`) cannot avoid for long -- a fraction f of
+// modified rays survives a call with probability (1 - f)^64 per image.  Same consequence as a lattice mismatch.
+__device__ __forceinline__ uint32_t canary_hash(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (c + 0x165667B1u) * 0xC2B2AE35u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h;
+}
 __global__ void __launch_bounds__(64) k_check_views(const double* __restrict__ origin, const double* __restrict__ dir, int w, int h,
-                                                    ViewModel* __restrict__ cache, ViewModel* __restrict__ views) {
+                                                    ViewModel* __restrict__ cache, ViewModel* __restrict__ views, unsigned salt) {
     __shared__ ViewModel vm;
     const int64_t base = (int64_t)blockIdx.x * w * h;
     if (threadIdx.x == 0) vm = cache[blockIdx.x];
@@ -47,6 +56,12 @@ __global__ void __launch_bounds__(64) k_check_views(const double* __restrict__ o
     const int x = (int)(((int64_t)(w - 1) * sx) / 7), y = (int)(((int64_t)(h - 1) * sy) / 7);
     const int64_t i = base + (int64_t)y * w + x;
     bool good = trusted && view_verify(vm, load_d3(origin, i), load_d3(dir, i), (double)x, (double)y);
+    if (good && salt) {
+        const uint32_t hx = canary_hash(salt, blockIdx.x, threadIdx.x), hy = canary_hash(salt ^ 0xA5A5A5A5u, threadIdx.x, blockIdx.x);
+        const int cx = (int)(((uint64_t)hx * (uint64_t)w) >> 32), cy = (int)(((uint64_t)hy * (uint64_t)h) >> 32);
+        const int64_t ci = base + (int64_t)cy * w + cx;
+        good = view_verify(vm, load_d3(origin, ci), load_d3(dir, ci), (double)cx, (double)cy);
+    }
     if (__ballot(good) == ~0ull) {                     // wave-uniform: the usual case
         if (threadIdx.x == 0) views[blockIdx.x] = vm;
         return;
@@ -236,7 +251,8 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
                   ViewModel* trusted) {
     const int n = (int)s->n_faces;
     HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
-    if (trusted) k_check_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, trusted, w.vmodel);   // models of an earlier call, lattice re-checked
+    if (trusted) k_check_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, trusted, w.vmodel,           // models of an earlier call: lattice re-checked,
+                                                        s->grid_canary ? (++s->canary_salt ? s->canary_salt : ++s->canary_salt) : 0u);   // + 64 rays at this call's random pixels
     else k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
     if (n > 0) {
         for (int pass = 0; pass < 2; ++pass) {

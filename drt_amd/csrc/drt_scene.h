@@ -192,6 +192,8 @@ struct drt_scene {
     bool fill_after_shade1 = true; // the late fills start behind k_shade1 (beside the VALU-bound second traversal only) instead of behind the cull stage: the
                                    // latency-bound first shading then has the memory system to itself (0.19 -> 0.09 ms per launch, step -1 %); DRT_FILL_AFTER_SHADE1=0
     bool fill_overlap = true;      // DRT_FILL_OVERLAP=0: the dense-output memsets of a DRT_GRID_TRUST call stay in front of the projection pass
+    bool grid_canary = true;       // DRT_GRID_CANARY=0: a trusted image is re-checked on its fixed 8x8 lattice only (k_check_views)
+    unsigned canary_salt = 0;      // changes with every trusted projection pass
     bool hit_seed = true;          // DRT_HIT_SEED=0: drt_render_seed's seeds are ignored (A/B measurement)
     bool use_raster = true;        // DRT_RASTER=0: every primary ray takes the BVH path (A/B measurement)
     bool built = false;

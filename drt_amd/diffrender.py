@@ -19,8 +19,10 @@ PyTorch only owns the tensors and the autograd plumbing.  Gradients reach
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
+import warnings
 import weakref
 
 import numpy as np
@@ -29,6 +31,32 @@ import torch
 from . import _lib, mesh_io
 from .optix_mesh import optix_mesh, _stream
 from .stepwise import Intersection, StepwiseMixin  # noqa: F401  (Dintersect / refract_ray / trace2 / project_vert)
+
+# What the caches below did since import (or since cache_report(reset=True)): cache_report().  They are transparent by design -- a call that
+# cannot use one simply takes the slower path -- so this is where a caller sees WHICH path its calls took, and why.
+_stats = collections.Counter()
+_warned = set()
+
+
+def _warn_once(key, msg):
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn("drt_amd.diffrender: " + msg, RuntimeWarning, stacklevel=3)
+
+
+def cache_report(reset=False):
+    """Counters of the transparent caches of this module: grid verdict cache (`grid_trust` calls that relied on a verdict, `grid_establish`
+    calls that read and verified every ray, `grid_off` calls without whole-image hints / with GRID_CACHE off, `grid_unattachable` ray tensors
+    that take no attributes), output recycling (`recycle_take` calls that rendered into pooled buffers; `recycle_miss_held` the pool had an
+    entry of that size but the caller still holds, or wrote, its outputs; `recycle_miss_empty` nothing pooled yet; `recycle_off_capture` inside
+    a graph capture; `recycle_off_small` below RECYCLE_MIN_RAYS), hit seeds (`seed_armed`), and the switches in force."""
+    out = dict(_stats)
+    out["switches"] = {"GRID_CACHE": GRID_CACHE, "RECYCLE_OUTPUTS": RECYCLE_OUTPUTS, "storage_use_count_available": hasattr(torch._C, "_storage_Use_Count"),
+                       "RECYCLE_MIN_RAYS": RECYCLE_MIN_RAYS, "PREFILL_NEXT": PREFILL_NEXT, "HIT_SEED": HIT_SEED, "GRID_CANARY": GRID_CANARY}
+    if reset:
+        _stats.clear()
+    return out
+
 
 debug = False
 resy = 960
@@ -86,6 +114,7 @@ _GRID_BYTES = 104      # DRT_GRID_CACHE_BYTES of include/drt_hip.h
 # refracted rays starts from that triangle's distance.  Bit-identical results with any buffer content; 4 B per ray next to the 96 B of the
 # ray itself.  Created outside graph captures only (a captured fill would reset the seeds at every replay).
 HIT_SEED = os.environ.get("DRT_HIT_SEED", "1") != "0"
+GRID_CANARY = os.environ.get("DRT_GRID_CANARY", "1") != "0"      # (read by the library itself at scene creation; here for cache_report)
 
 
 def _hit_seed(ray_dir, n):
@@ -108,6 +137,7 @@ def _arm_seed(handle, grid, n):
     """Registers the seeds of this call's ray tensor (third entry of _grid_cache's result) with the library: consumed by the next render call."""
     seed = grid[2] if len(grid) > 2 else None
     if seed is not None:
+        _stats["seed_armed"] += 1
         _lib.check(_lib.lib().drt_render_seed(handle, seed.data_ptr(), n))
 
 
@@ -119,9 +149,14 @@ def _grid_cache(origin, ray_dir, n, w, h):
     (drt_raster.h); the record -- a small device buffer -- is kept on the ``ray_dir`` tensor object together with the
     identity of ``origin`` and both tensors' in-place version counters, and later calls TRUST it as long as those
     match: the library then does not re-read the rays of pixels nothing projects onto.  Any in-place write to either
-    tensor bumps its version and the next call re-establishes.  (``t.data = ...`` and writes through raw pointers are not
-    seen by the version counter: do not do that to tensors you render from, or set GRID_CACHE = False.)"""
+    tensor bumps its version and the next call re-establishes.  ``t.data = ...`` and writes through raw pointers (a DLPack / NumPy
+    export of the tensor's memory, a kernel of the caller's own) are not seen by the version counter; what catches them is on the device:
+    every trusted call re-verifies, per image, the 8 x 8 lattice of rays its model was fitted on AND 64 more rays at pixels that change from
+    call to call (k_check_views' canary), and an image that fails is verified ray by ray from then on.  A partial overwrite of a fraction f
+    of an image's rays therefore survives a call with probability (1 - f)^64; a caller who writes single rays behind autograd's back must
+    set GRID_CACHE = False (or bump the version: ``t.add_(0)``)."""
     if not GRID_CACHE or w <= 0 or h <= 0 or n == 0:
+        _stats["grid_off"] += 1
         return 0, None
     rec = getattr(ray_dir, "_drt_grid", None)
     key = (n, w, h, origin._version, ray_dir._version, origin.data_ptr(), ray_dir.data_ptr())
@@ -131,12 +166,16 @@ def _grid_cache(origin, ray_dir, n, w, h):
             # All images verified in all rays -> DRT_GRID_ALL_VERIFIED: the launches that serve other rays are not issued.
             flags = rec[2].view(-1, _GRID_BYTES)[:, 96:104].contiguous().view(torch.int32)
             rec[3][0] = bool((flags != 0).all().item())
+        _stats["grid_trust"] += 1
         return 2 | (32 if rec[3][0] else 0), rec[2], _hit_seed(ray_dir, n)
     cache = torch.zeros((n // (w * h)) * _GRID_BYTES, dtype=torch.uint8, device=ray_dir.device)
     try:
         ray_dir._drt_grid = (key, weakref.ref(origin), cache, [None])
     except Exception:           # a tensor that takes no attributes: no cache
+        _stats["grid_unattachable"] += 1
+        _warn_once("grid_unattachable", "the ray_dir tensor takes no attributes: no grid verdict cache for it (every call verifies every ray)")
         return 0, None
+    _stats["grid_establish"] += 1
     return 1, cache
 
 
@@ -185,6 +224,9 @@ PREFILL_MIN_RAYS = int(os.environ.get("DRT_PREFILL_MIN_RAYS", 1 << 25))         
 # simply does not recycle.  As with any caching allocator, a caller who used the outputs on ANOTHER stream must have ordered that work in front
 # of the stream of its next render call before dropping them.)
 RECYCLE_OUTPUTS = os.environ.get("DRT_RECYCLE_OUTPUTS", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
+if os.environ.get("DRT_RECYCLE_OUTPUTS", "1") != "0" and not RECYCLE_OUTPUTS:
+    warnings.warn("drt_amd.diffrender: this torch has no torch._C._storage_Use_Count -- render_transparent cannot tell when its previous outputs "
+                  "were released and fills fresh ones every call (about a quarter slower at 72 x 1024^2); see cache_report()", RuntimeWarning)
 RECYCLE_MIN_RAYS = int(os.environ.get("DRT_RECYCLE_MIN_RAYS", 1 << 22))
 
 
@@ -288,11 +330,14 @@ class _RenderTransparent(torch.autograd.Function):
             om._prefilled = None
         stream_id = _stream()
         bases = counts = None
+        if not recycle and RECYCLE_OUTPUTS:
+            _stats["recycle_off_capture" if capturing else "recycle_off_small"] += 1
         if recycle:
             pool = getattr(om, "_out_pool", None)
             if pool is None:
                 pool = om._out_pool = _OutputPool()
             ent = pool.take(n, o.device, getattr(stream_id, "value", stream_id))
+            _stats["recycle_take" if ent is not None else ("recycle_miss_held" if any(e[0] == n for e in pool.entries) else "recycle_miss_empty")] += 1
             if ent is not None:
                 # the outputs of an earlier call that nobody holds any more: the rows that call set are zeroed (drt_outputs_clean, registered
                 # below, right in front of the render call and behind every allocation of this one) and the call renders into the same memory

@@ -478,3 +478,51 @@ def test_random_intrinsics_and_poses(Render, seed):
         if not bool(torch.isfinite(d).all()):
             continue
         _check(Render, scene, o, d, w, h)
+
+
+def test_partial_overwrite_behind_the_version_counter_is_caught_by_the_canary(Render):
+    """A block of rows of a trusted image rewritten through `.data` (no version bump) and placed so that it misses the fixed 8 x 8 lattice:
+    the lattice check alone trusts the image for ever (checked below with the canary compiled out of the call: DRT_GRID_CANARY=0 scene);
+    the per-call canary of k_check_views -- 64 more rays per image at pixels that change from call to call -- sees it within a call or
+    two, and from then on the image is verified ray by ray: the answer is that of the NEW rays."""
+    import os
+    from drt_amd import diffrender
+    mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
+    res = 256
+    P = res * res
+    lattice_rows = {int(((res - 1) * k) // 7) for k in range(8)}
+    y0, y1 = 100, 140                                        # 40 rows of image 1: 16 % of its rays, none of them on the lattice
+    assert not any(y0 <= r < y1 for r in lattice_rows)
+
+    def run(canary):
+        old = os.environ.get("DRT_GRID_CANARY")
+        os.environ["DRT_GRID_CANARY"] = "1" if canary else "0"
+        try:
+            scene = Render.Scene(mesh, 0)                   # (the switch is read when the library creates the scene)
+        finally:
+            if old is None:
+                os.environ.pop("DRT_GRID_CANARY", None)
+            else:
+                os.environ["DRT_GRID_CANARY"] = old
+        o, d, cams = _trusted_pair(Render, scene, mesh, res, (4, 22, 47))
+        _, d_b = views.generate_ray(res, res, cams[30][3], cams[30][2], device="cuda")
+        ver = d._version
+        d.data[P + y0 * res:P + y1 * res].copy_(d_b[y0 * res:y1 * res])       # another camera's directions in those rows
+        assert d._version == ver and (diffrender._grid_cache(o, d, len(o), res, res)[0] & 3) == 2
+        Render.resx = Render.resy = res
+        outs = []
+        with torch.no_grad():
+            for _ in range(3):
+                outs.append([t.clone() for t in scene.render_transparent(o, d)])
+            Render.resx = Render.resy = 7                   # the same rays without any whole-image assumption: the tree for every ray
+            ref = [t.clone() for t in scene.render_transparent(o.clone(), d.clone())]
+        Render.resx = Render.resy = res
+        return outs, ref
+
+    outs, ref = run(True)
+    # (1 - 0.16)^64 = 1.4e-5 per call: the first trusting call catches it
+    for k, got in enumerate(outs):
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), k
+    outs0, ref0 = run(False)
+    assert all(torch.equal(a, b) for a, b in zip(ref0, ref))
+    assert not all(torch.equal(a, b) for a, b in zip(outs0[-1], ref0)), "the lattice alone was expected to miss this overwrite (the test no longer tests the canary)"
