@@ -323,7 +323,17 @@ def regime_roofline(scene, step_fn, kk, n_rays_per_step, verify_every_ray):
     step_fn()
     pr2 = om.profile_read()
     ts = om.trace_stats()
+    # ... and `kk` steps with the two internal pipelines serialised on one stream: every kernel with the GPU to itself
+    prefill, Render.PREFILL_NEXT = Render.PREFILL_NEXT, False
+    om.profile_enable(3)
+    step_fn()
+    om.profile_read()
+    for _ in range(kk):
+        step_fn()
+    pa = om.profile_read()
+    Render.PREFILL_NEXT = prefill
     om.profile_enable(0)
+    alone = {k: ms / kk for k, (ms, l, it) in pa.items() if l}
     stages = {k: {"ms_per_step": round(ms / kk, 4), "avg_launch_ms": round(ms / l, 4), "launches_per_step": round(l / kk, 2), "items_per_launch": it // l}
               for k, (ms, l, it) in pr.items() if l}
     rows = {}
@@ -338,15 +348,22 @@ def regime_roofline(scene, step_fn, kk, n_rays_per_step, verify_every_ray):
                                     "valu_instr_per_launch_est": int(est), "node_visits_per_ray": round(ls / max(1, pr2["trace2"][2]), 2),
                                     "lane_utilisation": round(ls / (64.0 * ws), 3),
                                     "frac_source": f"wave-steps counted live x ({VALU_PER_INNER_STEP} VALU per inner visit, {VALU_PER_LEAF_STEP} per leaf visit)"}
+        if alone.get("trace2"):
+            ta = alone["trace2"] / max(1.0, stages["trace2"]["launches_per_step"]) * 1e-3
+            rows["k_trace<closest>"]["alone"] = {"avg_launch_ms": round(ta * 1e3, 4), "achieved": round(est / ta / 1e9, 1), "frac": round(est / ta / VALU_PEAK, 4)}
     if verify_every_ray and "cull" in stages:
         h0 = pr["shade1"][2] / kk
         b = 56.0 * n_rays_per_step + 36.0 * h0
         t = stages["cull"]["ms_per_step"] * 1e-3
         rows["k_cull"] = {"kernel": "k_cull (every ray loaded and verified)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "ms_per_step": stages["cull"]["ms_per_step"],
                           "achieved": round(b / t / 1e9, 1), "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_step": int(b)}
+        if alone.get("cull"):
+            rows["k_cull"]["alone"] = {"ms_per_step": round(alone["cull"], 4), "achieved": round(b / (alone["cull"] * 1e-3) / 1e9, 1),
+                                       "frac": round(b / (alone["cull"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     dom = max(rows, key=lambda k: rows[k]["ms_per_step"]) if rows else None
     return {"roofline": dict(rows[dom], others={k: v for k, v in rows.items() if k != dom}) if dom else None,
-            "stages_ms_per_step": {k: v["ms_per_step"] for k, v in stages.items()}}
+            "stages_ms_per_step": {k: v["ms_per_step"] for k, v in stages.items()},
+            "stages_alone_ms_per_step": {k: round(v, 4) for k, v in alone.items()}}
 
 
 def main():

@@ -6,11 +6,12 @@ mkdir -p gpurun_out/ab
 for r in 1 2; do
   for v in 0 1; do
     env $var=$v timeout 600 python bench.py --no-cpu-baseline "$@" > gpurun_out/ab/${var}_${v}_$r.json 2> gpurun_out/ab/${var}_${v}_$r.err
-    echo "== $var=$v round $r"; python tools/benchsum.py gpurun_out/ab/${var}_${v}_$r.json | grep -E "Mrays|trace|raster"
+    echo "== $var=$v round $r"; python tools/benchsum.py gpurun_out/ab/${var}_${v}_$r.json | grep -E "Mrays|trace|raster|cull"
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab/${var}_${v}_$r.json").read().strip().splitlines()[-1])
-print("   tight:", (d.get("tight_framing") or {}).get("ms_per_step"), " establish:", (d.get("establish_mode") or {}).get("ms_per_step"), " fused:", (d.get("fused_mode") or {}).get("ms_per_step"))
+e=d.get("establish_mode") or {}
+print("   repeats:", d.get("repeats",{}).get("ms_per_step"), " tight:", (d.get("tight_framing") or {}).get("ms_per_step"), " establish:", e.get("ms_per_step"), (e.get("stages_ms_per_step") or {}).get("cull"), " fused:", (d.get("fused_mode") or {}).get("ms_per_step"))
 PY
   done
 done
