@@ -571,6 +571,39 @@ def main():
                    "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "outputs_recycled": bool(args.mode == "dropin" and not args.graph and Render.RECYCLE_OUTPUTS and P * len(my_views) >= Render.RECYCLE_MIN_RAYS), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
                    "final_loss": float(ddist.allreduce_sum_(loss.detach().clone().reshape(1).double()).item())},     # (summed over the ranks: the loss of all views)
     }
+    # N > 1: what the line says about the exchange itself, so that the first run on a multi-GPU node explains itself -- the process group as
+    # torch.distributed sees it, and the step's one all-reduce (grad[V,3] float64) timed alone on every rank, after the timed region
+    if world > 1 or os.environ.get("DRT_DIST_FORCE", "") not in ("", "0"):
+        import torch.distributed as tdist
+        g_probe = torch.zeros_like(parameter)
+        for _ in range(3):
+            ddist.allreduce_sum_(g_probe)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ddist.barrier(); torch.cuda.synchronize()
+        n_ar = 20
+        ev[0].record()
+        for _ in range(n_ar):
+            ddist.allreduce_sum_(g_probe)
+        ev[1].record()
+        torch.cuda.synchronize()
+        mine = torch.tensor([ev[0].elapsed_time(ev[1]) / n_ar, float(len(my_views)), float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        if tdist.is_initialized() and world > 1:
+            tdist.all_gather(per_rank, mine)
+        else:
+            per_rank = [mine]
+        try:
+            nccl_ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            nccl_ver = None
+        out["multi_gpu"] = {
+            "backend": tdist.get_backend() if tdist.is_initialized() else None, "world_size_seen_by_torch_distributed": tdist.get_world_size() if tdist.is_initialized() else 1,
+            "rccl_version": nccl_ver, "visible_devices": torch.cuda.device_count(), "partition": "view k -> rank k mod world; no data-path collective but ONE all-reduce(sum) of grad[V,3] float64 per step",
+            "allreduce_bytes": int(parameter.numel() * 8),
+            "allreduce_ms_per_rank": [round(float(t[0]), 4) for t in per_rank], "views_per_rank": [int(t[1]) for t in per_rank], "device_of_rank": [int(t[2]) for t in per_rank],
+            "allreduce_share_of_step": round(max(float(t[0]) for t in per_rank) / (1e3 * elapsed / args.steps), 4),
+            "note": "the all-reduce figure is the collective alone (20 back-to-back calls after the timed region); inside the step it is one launch in the chain",
+        }
     prof_live = scene.optix_mesh.profile_read() if live_profile else None
     scene.optix_mesh.profile_select(None)
     # the two modes at ONE parameter state (no optimiser step in between): same loss to rounding, or one of them is wrong

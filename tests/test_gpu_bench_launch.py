@@ -56,3 +56,10 @@ def test_the_drivers_launch_line_with_two_ranks_equals_one_process():
     a, b = one["config"]["final_loss"], two["config"]["final_loss"]
     assert a > 0 and abs(a - b) <= 1e-12 * abs(a), (a, b)
     assert two["value"] > 0 and two["ms_per_step"] > 0
+    # the line explains its own exchange: process group as torch.distributed sees it, the all-reduce alone on every rank
+    mg = two["multi_gpu"]
+    assert mg["world_size_seen_by_torch_distributed"] == 2 and mg["backend"] == ("nccl" if rccl else "gloo")
+    assert mg["views_per_rank"] == [4, 4] and len(mg["allreduce_ms_per_rank"]) == 2 and all(t > 0 for t in mg["allreduce_ms_per_rank"])
+    assert "multi_gpu" not in one
+    rp = two["repeats"]
+    assert rp["n"] >= 1 and rp["min"] <= rp["median"] <= rp["max"] and two["ms_per_step"] == rp["median"]
