@@ -384,9 +384,9 @@ def main():
                     help="views concatenated into one render_transparent call (0 = all local views; 1 = the reference's per-view loop)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: capture the whole step (rebuild, pipelines, autograd, all-reduce, SGD) in a HIP graph and replay it; 0: eager; "
-                         "-1 (default): graph when N > 1 AND the rank's share is below 2^22 camera rays (shares that do not recycle their outputs: above, the eager "
-                         "step is the faster one -- 9 views: 0.67 vs 0.69 ms, 36 views: 1.16 vs 1.56) -- eager otherwise; "
-                         "falls back to eager if the capture fails")
+                         "-1 (default): graph when N > 1 AND the rank's share is below 24 views x 1024^2 camera rays (a chain of small launches: "
+                         "9 views 0.655 vs 0.691 ms eager, 18 views 0.792 vs 0.819; above, the eager step is the faster one: 36 views 1.177 vs 1.204) "
+                         "-- eager otherwise; falls back to eager if the capture fails")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps between two barrier + synchronize pairs) is run this many times back to back; "
                          "`value` / `ms_per_step` are those of the MEDIAN repeat, all of them are listed under `repeats`")
@@ -467,13 +467,13 @@ def main():
         return O.full_batch_step(scene, local_views, init_vertices, parameter, opt, w_ray, fused=args.mode == "fused")
 
     if args.graph < 0:
-        # Measured per share on one GPU.  Round 3 (profiles/r03_scaling_proxy.txt): a replay beat the eager step where the step is a chain of
-        # small launches (9 views: 0.68 vs 0.72 ms; 18: 0.88 vs 0.92; 36: 1.55 vs 1.40).  Round 4 (profiles/r04_scaling_proxy.txt): the eager
-        # step renders into the previous step's outputs (diffrender.RECYCLE_OUTPUTS, not available inside a capture, whose fills are part of
-        # the graph) and is the faster one at every share that recycles: 36 views 1.16 vs 1.56 ms, 18: 0.81 vs 0.86, 9: 0.67 vs 0.69.  So: a
-        # graph only for shares below RECYCLE_MIN_RAYS (2^22 camera rays: a chain of tiny launches, no recycling either way).
+        # Measured per share on one GPU (profiles/r05_scaling_proxy.txt; r03 / r04 for the history).  Since round 5 a capture takes a pooled
+        # output set for good (diffrender `graph_set`: replay = recycle, no dense fill inside the graph), so eager and replayed steps do the
+        # same GPU work and differ by the host's enqueue and the gaps between ~60 dependent launches: the replay wins where the step is a chain
+        # of small launches (9 views: 0.655 vs 0.691 ms; 18: 0.792 vs 0.819) and loses where the two pipelines' overlap matters more than the
+        # launch gaps (36 views: 1.204 vs 1.177; 72: 1.83 vs 1.79).  So: a graph for shares below 24 views x 1024^2 rays.
         # (Not over gloo -- the functional two-ranks-on-one-GPU check: its all-reduce goes through the host and cannot be captured.)
-        small = len(my_views) * P < (Render.RECYCLE_MIN_RAYS if Render.RECYCLE_OUTPUTS else (1 << 25))
+        small = len(my_views) * P < (3 << 23)
         args.graph = 1 if world > 1 and small and os.environ.get("DRT_BENCH_GRAPH", "1") != "0" and os.environ.get("DRT_DIST_BACKEND") != "gloo" else 0
     graph = None
     if args.graph:
@@ -568,7 +568,7 @@ def main():
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD"
                                + ("" if args.distance_factor == 2.5 else f", cameras at {args.distance_factor} extents")
                                + (", no grid verdict cache" if args.no_grid_cache else ""),
-                   "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "outputs_recycled": bool(args.mode == "dropin" and not args.graph and Render.RECYCLE_OUTPUTS and P * len(my_views) >= Render.RECYCLE_MIN_RAYS), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
+                   "targets": "random" if args.random_targets else target_src, "mode": args.mode, "hip_graph": bool(args.graph), "outputs_recycled": bool(args.mode == "dropin" and Render.RECYCLE_OUTPUTS and P * len(my_views) >= Render.RECYCLE_MIN_RAYS and (not args.graph or Render.cache_report().get("recycle_graph_set", 0) > 0)), "views_per_gpu": len(my_views), "views_per_call": min(bv, len(my_views)), "ior": IOR, "valid_pixel_fraction": round(valid_frac, 4), "untimed_steps": max(args.warmup, 3), "allocator_in_timed_region": alloc_stats,
                    "final_loss": float(ddist.allreduce_sum_(loss.detach().clone().reshape(1).double()).item())},     # (summed over the ranks: the loss of all views)
     }
     # N > 1: what the line says about the exchange itself, so that the first run on a multi-GPU node explains itself -- the process group as

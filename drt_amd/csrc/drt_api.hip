@@ -56,6 +56,7 @@ int drt_create(int device, drt_scene_t** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->build_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->prefill_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->prefill_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->prefill_done_cap, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->build_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->build_done, hipEventDisableTiming);
     if (const char* ev = getenv("DRT_ASYNC_BUILD")) s->async_build = atoi(ev) != 0;
@@ -138,6 +139,7 @@ void drt_destroy(drt_scene_t* s) {
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
     if (s->prefill_fork) (void)hipEventDestroy(s->prefill_fork);
     if (s->prefill_done) (void)hipEventDestroy(s->prefill_done);
+    if (s->prefill_done_cap) (void)hipEventDestroy(s->prefill_done_cap);
     for (auto& e : s->prof_ev) (void)hipEventDestroy(e);
     (void)hipFree(s->prof_counts);
     delete s;

@@ -1598,8 +1598,14 @@ int drt_render_forward(drt_scene_t* s, const double* d_verts, const double* d_or
                        double ior_int, double ior_ext, double* d_out_ori, double* d_out_dir, uint8_t* d_mask,
                        int32_t* d_face1, int32_t* d_face2, int32_t* d_valid_idx, int64_t* d_n_valid, int tile_w, int tile_h,
                        int grid_mode, void* d_grid_cache, void* stream) {
+    // A call that is being CAPTURED into a graph and was offered its outputs through drt_outputs_clean uses an event of its own for "the rows
+    // are zero again": an event recorded inside a capture must not be waited for by eager work afterwards (and vice versa).
+    hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+    const bool swap_ev = s && s->clean.rows && s->clean.captured && hipStreamIsCapturing((hipStream_t)stream, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
+    if (swap_ev) std::swap(s->prefill_done, s->prefill_done_cap);
     const int rc = render_forward_impl(s, d_verts, d_origin, d_dir, n_rays, ior_int, ior_ext, d_out_ori, d_out_dir, d_mask, d_face1, d_face2, d_valid_idx,
                                        d_n_valid, tile_w, tile_h, grid_mode, d_grid_cache, stream);
+    if (swap_ev) std::swap(s->prefill_done, s->prefill_done_cap);
     if (rc != DRT_OK && s) {
         // a call that failed must not leave raw pointers of its caller registered: the caller is about to release those buffers, and the
         // next call would zero "rows" of, or skip the fills of, memory that belongs to somebody else by then
@@ -1636,7 +1642,7 @@ static int render_forward_impl(drt_scene_t* s, const double* d_verts, const doub
     (void)hipStreamIsCapturing(st, &cap);
     // (while a graph is being captured the buffers zeroed ahead of time stay registered: the capturing call brings its own outputs, and
     // nothing outside the capture may be waited for inside it)
-    if (s->n_prefill && cap == hipStreamCaptureStatusNone) {       // buffers zeroed ahead of time (drt_prefill_zero): which of this call's outputs are they?
+    if (s->n_prefill && (cap == hipStreamCaptureStatusNone || (s->clean.rows && s->clean.captured))) {       // buffers zeroed ahead of time (drt_prefill_zero) / offered again (drt_outputs_clean): which of this call's outputs are they?
         int matched = 0;
         for (int k = 0; k < s->n_prefill; ++k) {
             const drt_scene::Prefill& f = s->prefill[k];
@@ -1648,7 +1654,7 @@ static int render_forward_impl(drt_scene_t* s, const double* d_verts, const doub
         }
         // an entry that is none of this call's outputs is dropped here: whoever writes that buffer next no longer knows about its
         // zeroing, so the zeroing is ordered in front of everything this stream does from now on
-        if (matched != s->n_prefill) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
+        if (matched != s->n_prefill && cap == hipStreamCaptureStatusNone) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
         s->n_prefill = 0;     // one shot (launch_chunk waits for prefill_done in front of the first kernel that writes those outputs)
     }
     // drt_outputs_clean's rows.  A trusted-grid call through the projection pass writes no row of the dense outputs before k_shade2, which
@@ -1734,7 +1740,11 @@ int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint
     if (n_rays <= 0 || !d_out_ori || !d_out_dir || !d_mask || !d_valid_idx || !d_n_valid) return fail(DRT_E_INVALID, "bad arguments");
     hipStream_t st = (hipStream_t)stream;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return fail(DRT_E_INVALID, "drt_outputs_clean: not while a graph is being captured");
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    // While a graph is being captured the request is recorded like any other and the captured drt_render_forward zeroes the listed rows
+    // inside the graph.  That is only the caller's intent when the row list IS the list the captured call writes (same d_valid_idx /
+    // d_n_valid): every replay then zeroes the rows its predecessor set -- replay = recycle (drt_amd/diffrender.py pins such a set).
+    if (capturing && (s->n_prefill || s->clean.rows)) return fail(DRT_E_INVALID, "drt_outputs_clean: zeroings requested outside the capture are still pending");
     if (s->n_prefill) {       // zeroings of OTHER buffers still pending on the build stream: order them in front of this stream, forget the entries
         HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
         s->n_prefill = 0;
@@ -1743,7 +1753,7 @@ int drt_outputs_clean(drt_scene_t* s, double* d_out_ori, double* d_out_dir, uint
     // pipelines (that stream is idle until the join, and nothing writes a row of the outputs before k_shade2, which waits for
     // prefill_done): 30 us that no longer sit between the vertex update and the projection pass.
     if (s->clean.rows) { int rc = flush_clean(s, st); if (rc) return rc; }          // an earlier request nobody rendered into: honour it now
-    s->clean = drt_scene::Clean{d_out_ori, d_out_dir, d_mask, n_rays, d_valid_idx, d_n_valid};
+    s->clean = drt_scene::Clean{d_out_ori, d_out_dir, d_mask, n_rays, d_valid_idx, d_n_valid, capturing};
     s->prefill[0].ptr = d_out_ori; s->prefill[0].bytes = (int64_t)sizeof(double) * 3 * n_rays;
     s->prefill[1].ptr = d_out_dir; s->prefill[1].bytes = (int64_t)sizeof(double) * 3 * n_rays;
     s->prefill[2].ptr = d_mask;    s->prefill[2].bytes = 3 * n_rays;

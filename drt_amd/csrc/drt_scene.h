@@ -151,7 +151,8 @@ struct drt_scene {
     // drt_prefill_zero: dense outputs of the NEXT drt_render_forward zeroed ahead of time on the build stream (idle after a forward's
     // join, i.e. during the caller's loss / backward / optimiser tail); a forward whose out_ori / out_dir / mask IS such a buffer skips that fill
     // drt_outputs_clean: the rows to zero, launched by the next drt_render_forward on the caller's stream BEHIND its fork (idle until the join)
-    struct Clean { double* ori = nullptr; double* dir = nullptr; uint8_t* mask = nullptr; int64_t n = 0; const int32_t* rows = nullptr; const int64_t* n_rows = nullptr; } clean;
+    struct Clean { double* ori = nullptr; double* dir = nullptr; uint8_t* mask = nullptr; int64_t n = 0; const int32_t* rows = nullptr; const int64_t* n_rows = nullptr;
+                   bool captured = false; /* requested while a graph was being captured: consumed by the render call of the same capture */ } clean;
     // The list of completed paths of the last drt_render_forward, by sub-batch: sub-batch j appends into the caller's list at its own
     // offset (its first ray's index: a sub-batch cannot complete more paths than it has rays) under its own counter seg_counts[j]; behind
     // the join k_join_lists closes the gaps.  Segment 0 is never moved -- what lets drt_ray_loss_listed_grad_split start on it while the
@@ -162,7 +163,7 @@ struct drt_scene {
     struct Prefill { const void* ptr = nullptr; int64_t bytes = 0; };
     Prefill prefill[3];
     int n_prefill = 0;
-    hipEvent_t prefill_fork = nullptr, prefill_done = nullptr;
+    hipEvent_t prefill_fork = nullptr, prefill_done = nullptr, prefill_done_cap = nullptr;   // (_cap: stands in for prefill_done inside a captured render call)
     unsigned* vcount = nullptr;    // [0] valid rays of the whole call, [1] silhouette items of drt_vh_loss_fused
     uint32_t* vh_list = nullptr;   // (view, edge) items of drt_vh_loss_fused: its own buffer, so that the call may run on
     int64_t vh_cap = 0;            //   another stream than a pipeline call (which owns the Sub workspaces)

@@ -219,7 +219,7 @@ PREFILL_MIN_RAYS = int(os.environ.get("DRT_PREFILL_MIN_RAYS", 1 << 25))         
 # keeps its outputs alive simply gets fresh allocations and the fills, as before.  The price in memory: the usual loop rebinds
 # `out = render()` only after the call has returned, so the previous outputs are still held when the pool is asked and the pool ping-pongs
 # between TWO entries: two output sets plus their two row lists (2 x 55 B per ray) stay resident per scene (`Scene.release_outputs()`
-# drops them).  Not inside a graph capture (a replay must own its buffers).
+# drops them).  Inside a graph capture a pooled set becomes the graph's own (replay = recycle: `graph_set` in _RenderTransparent.forward).
 # (The use count of a storage is read through torch._C._storage_Use_Count, which torch's own CUDA-graph trees rely on; a torch without it
 # simply does not recycle.  As with any caching allocator, a caller who used the outputs on ANOTHER stream must have ordered that work in front
 # of the stream of its next render call before dropping them.)
@@ -245,7 +245,7 @@ class _OutputPool:
     def take(self, n, device, stream):
         """An entry of this size whose buffers nobody else references or has written; removed from the pool."""
         for k, e in enumerate(self.entries):
-            if e[0] == n and e[1] == device and e[2] == stream and all(_use_count(t) == c and t._version == 0 for t, c in zip(e[3], e[4])):
+            if e[0] == n and e[1] == device and (stream is None or e[2] == stream) and all(_use_count(t) == c and t._version == 0 for t, c in zip(e[3], e[4])):
                 return self.entries.pop(k)
         return None
 
@@ -319,8 +319,14 @@ class _RenderTransparent(torch.autograd.Function):
         om = scene.optix_mesh            # owns the buffers zeroed ahead of time: its drt_destroy waits for the zeroing before they are released
         capturing = torch.cuda.is_current_stream_capturing()
         need_bwd = ctx.needs_input_grad[0]
-        recycle = RECYCLE_OUTPUTS and n >= RECYCLE_MIN_RAYS and not capturing      # (any grid mode: a call that verifies every ray -- no cache, or the
+        recycle = RECYCLE_OUTPUTS and n >= RECYCLE_MIN_RAYS                        # (any grid mode: a call that verifies every ray -- no cache, or the
                                                                                   #  establishing one -- then at least does not write the dead rows again)
+        # Inside a graph capture: REPLAY = RECYCLE.  A set the eager warm-up calls left in the pool is taken out of it for good and becomes the
+        # graph's static outputs; the captured call zeroes the rows of the set's row list and then writes ITS list into those very buffers, so
+        # every replay undoes exactly what its predecessor set (the set's state at capture time is that of the eager call that filled it
+        # last: consistent with its list, which is what the first replay undoes).  No pooled set -- no warm-up call of this size since the
+        # last capture -- and the capture brings fresh outputs and their fills, as before.
+        graph_set = None
         pre = getattr(om, "_prefilled", None)
         if capturing:
             # a graph replays THESE launches on THESE buffers: the fills must be part of it, and nothing outside the capture may be waited
@@ -331,13 +337,25 @@ class _RenderTransparent(torch.autograd.Function):
         stream_id = _stream()
         bases = counts = None
         if not recycle and RECYCLE_OUTPUTS:
-            _stats["recycle_off_capture" if capturing else "recycle_off_small"] += 1
+            _stats["recycle_off_small"] += 1
         if recycle:
             pool = getattr(om, "_out_pool", None)
             if pool is None:
                 pool = om._out_pool = _OutputPool()
-            ent = pool.take(n, o.device, getattr(stream_id, "value", stream_id))
-            _stats["recycle_take" if ent is not None else ("recycle_miss_held" if any(e[0] == n for e in pool.entries) else "recycle_miss_empty")] += 1
+            # (a capture runs on a stream of its own: any pooled set of this size will do -- the capture is ordered behind the warm-up)
+            ent = pool.take(n, o.device, None if capturing else getattr(stream_id, "value", stream_id))
+            if capturing:
+                _stats["recycle_graph_set" if ent is not None else "recycle_off_capture"] += 1
+                if ent is None:
+                    recycle = False
+                else:
+                    graph_set = ent
+                    sets = getattr(om, "_graph_sets", None)
+                    if sets is None:
+                        sets = om._graph_sets = []
+                    sets.append(ent)                     # alive as long as the scene: the graph's replays read and write these buffers
+            else:
+                _stats["recycle_take" if ent is not None else ("recycle_miss_held" if any(e[0] == n for e in pool.entries) else "recycle_miss_empty")] += 1
             if ent is not None:
                 # the outputs of an earlier call that nobody holds any more: the rows that call set are zeroed (drt_outputs_clean, registered
                 # below, right in front of the render call and behind every allocation of this one) and the call renders into the same memory
@@ -372,8 +390,11 @@ class _RenderTransparent(torch.autograd.Function):
         if link is not None:
             link.seq = _render_seq[0]
         want_list = need_bwd or recycle
-        valid_idx = torch.empty(n, dtype=torch.int32, device=o.device) if want_list else None
-        n_valid = torch.empty(1, dtype=torch.int64, device=o.device) if want_list else None
+        if graph_set is not None:
+            valid_idx, n_valid = graph_set[5], graph_set[6]           # this call's list goes where its predecessor's was: see above
+        else:
+            valid_idx = torch.empty(n, dtype=torch.int32, device=o.device) if want_list else None
+            n_valid = torch.empty(1, dtype=torch.int64, device=o.device) if want_list else None
         with torch.cuda.device(o.device):
             # The library is handed raw pointers of buffers only this frame keeps alive (`took`: the pooled outputs and their row list):
             # nothing that can raise sits between the registration and the call that consumes it, and a call that fails withdraws them
@@ -403,8 +424,9 @@ class _RenderTransparent(torch.autograd.Function):
                 om._prefilled = (n, o.device, nxt_ori, nxt_mask)
         if recycle:
             # the pool keeps the base tensors; the caller gets aliases of its own (same storage, same version counter), so that the
-            # storages' use counts say when the caller is done with them
-            om._out_pool.put(n, o.device, getattr(stream_id, "value", stream_id), bases, counts, valid_idx, n_valid)
+            # storages' use counts say when the caller is done with them  (a graph's set stays out of the pool: `om._graph_sets`)
+            if graph_set is None:
+                om._out_pool.put(n, o.device, getattr(stream_id, "value", stream_id), bases, counts, valid_idx, n_valid)
             out_ori, out_dir, mask = bases[0].detach(), bases[1].detach(), bases[2].detach()
             bases = None
         if not need_bwd:
@@ -700,6 +722,7 @@ class Scene(StepwiseMixin):
         pool = getattr(om, "_out_pool", None)
         if pool is not None:
             pool.entries.clear()
+        om._graph_sets = []              # (only once every graph captured on this scene has been dropped: their replays use these buffers)
 
     # ------------------------------------------------------------------ refraction path
     def render_transparent(self, origin: torch.Tensor, ray_dir: torch.Tensor):

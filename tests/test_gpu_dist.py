@@ -76,9 +76,11 @@ def test_two_ranks_on_the_hip_path_equal_one_rank(tmp_path, fused):
     np.testing.assert_allclose(r0["losses"], losses, rtol=1e-12)
 
 
-def _graph_run(fused, graph, steps=4):
+def _graph_run(fused, graph, steps=4, recycle_min=None):
     """`steps` full-batch steps on one rank, eagerly or as replays of ONE captured hipGraph (bench.py --graph 1)."""
     from drt_amd import diffrender as Render, mesh_io, optim as O, views
+    if recycle_min is not None:
+        Render.RECYCLE_MIN_RAYS = recycle_min
     Render.intIOR = IOR
     Render.resx = Render.resy = RES
     mesh = mesh_io.read_ply(data_path("hand_vh.ply"))
@@ -121,6 +123,29 @@ def test_a_whole_step_captured_as_a_hip_graph_equals_eager_steps(fused):
     """The step has no host-side data dependence, so it can be captured once and replayed (internal streams, asynchronous build,
     late output fills and all): the parameters after warm-up + 4 steps equal the eager run's up to the order of the atomics."""
     eager, replayed = _graph_run(fused, False), _graph_run(fused, True)
+    scale = np.abs(eager).max()
+    assert scale > 1e-3 and np.isfinite(replayed).all()
+    assert np.abs(eager - replayed).max() <= 1e-11 * scale, np.abs(eager - replayed).max() / scale
+
+
+def test_a_captured_step_recycles_its_outputs_replay_after_replay():
+    """With recycling on for this size the capture takes a pooled output set for good (diffrender `graph_set`): the captured call zeroes the
+    rows of the set's row list and writes its own list into the same buffers, so every replay undoes what its predecessor set -- no dense
+    fill inside the graph.  Same parameters as eager steps with fresh outputs, over 6 replays with moving vertices."""
+    from drt_amd import diffrender as Render
+    old = (Render.RECYCLE_MIN_RAYS, Render.RECYCLE_OUTPUTS)
+    try:
+        Render.RECYCLE_OUTPUTS = False
+        eager = _graph_run(False, False, steps=6)
+        Render.RECYCLE_OUTPUTS = old[1]
+        if not Render.RECYCLE_OUTPUTS:
+            pytest.skip("this torch has no storage use count: no recycling")
+        Render.cache_report(reset=True)
+        replayed = _graph_run(False, True, steps=6, recycle_min=0)
+        rep = Render.cache_report()
+    finally:
+        Render.RECYCLE_MIN_RAYS, Render.RECYCLE_OUTPUTS = old
+    assert rep.get("recycle_graph_set", 0) == 1 and rep.get("recycle_off_capture", 0) == 0, rep      # the capture DID take a pooled set
     scale = np.abs(eager).max()
     assert scale > 1e-3 and np.isfinite(replayed).all()
     assert np.abs(eager - replayed).max() <= 1e-11 * scale, np.abs(eager - replayed).max() / scale
