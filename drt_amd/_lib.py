@@ -54,6 +54,8 @@ SIGNATURES = {
     "drt_edge_sample_forward": (_c.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _P, _P]),
     "drt_edge_sample_backward": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _c.c_int, _P, _P]),
     "drt_edge_sample_backward_rows": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _I64, _P, _c.c_int, _P, _P]),
+    "drt_vh_term": (_c.c_int, [_P, _P, _I64, _P, _c.c_int, _c.c_int, _P, _P, _P]),
+    "drt_edge_sample_backward_term": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _P, _c.c_int, _P, _P]),
     "drt_edge_tables_workspace": (_I64, [_I64]),
     "drt_edge_tables": (_c.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "drt_subdivide_midpoint": (_c.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _c.c_int, _P, _P, _P]),

@@ -111,10 +111,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_edge_sample_fwd(TraceCtx c, con
 // DiffRender.py:236-242, 263-267), chained through the projection to the two vertices.
 __global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restrict__ verts, const int64_t* __restrict__ edges, int64_t n,
                                                          const Camera* __restrict__ cam, const float* __restrict__ f,
-                                                         const double* __restrict__ coef, int detach_depth, double* grad_verts) {
+                                                         const double* __restrict__ coef, int detach_depth, double* grad_verts,
+                                                         const double* __restrict__ g32 /* optional device scalar: coef is scaled by (float)*g32 */) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const double w = (double)f[e] * coef[e];
+    const double w = (double)f[e] * (g32 ? coef[e] * (double)(float)*g32 : coef[e]);
     if (w == 0.0) return;
     const Camera cm = *cam;
     const int64_t ia = edges[2 * e], ib = edges[2 * e + 1];
@@ -125,6 +126,27 @@ __global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restric
     const AtomicAdd3 add{grad_verts};
     add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
     add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
+}
+
+// The loss expression of ONE view over the samples drt_edge_sample_forward left in place (all E rows, `keep` marks the samples):
+// sum over kept rows of |soft[y, x] - 0.5| (reference optim.py:78 with `output` = 0.5) and, per row, d term / d output = -sign(soft - 0.5)
+// (0 for dropped rows) -- what the drop-in pair's LAZY return values evaluate when the caller writes the reference's expression
+// (drt_amd/diffrender.py SampleSet): no compaction, no host round trip.
+__global__ void __launch_bounds__(256) k_vh_term(const int64_t* __restrict__ index, const uint8_t* __restrict__ keep, int64_t n,
+                                                 const double* __restrict__ soft, int resx, double* loss, double* __restrict__ dterm) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double t = 0.0;
+    if (e < n) {
+        double dsign = 0.0;
+        if (keep[e]) {
+            const double m = soft[index[2 * e + 1] * resx + index[2 * e]] - 0.5;
+            t = fabs(m);
+            dsign = m > 0.0 ? -1.0 : (m < 0.0 ? 1.0 : 0.0);
+        }
+        dterm[e] = dsign;
+    }
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0 && t != 0.0) unsafeAtomicAdd(loss, t);
 }
 
 // ---- fused silhouette loss: Loss_calculator.vh_loss (reference optim.py:73-78) with no host round trip:
@@ -335,7 +357,18 @@ int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int6
     if (n_edges == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_camera || !d_f || !d_coef || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
     k_edge_sample_bwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_coef, detach_depth, d_grad_verts);
+        d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_coef, detach_depth, d_grad_verts, nullptr);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_edge_sample_backward_term(const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera, const float* d_f,
+                                  const double* d_dterm, const double* d_g, int detach_depth, double* d_grad_verts, void* stream) {
+    if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_verts || !d_edges || !d_camera || !d_f || !d_dterm || !d_g || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
+    k_edge_sample_bwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_dterm, detach_depth, d_grad_verts, d_g);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -381,6 +414,16 @@ int drt_limit_sgd_step(double* d_param, double* d_grad, double* d_buf, int64_t n
     if (n == 0) return DRT_OK;
     if (!d_param || !d_grad || (momentum != 0.0 && !d_buf)) return fail(DRT_E_INVALID, "null pointer argument");
     k_limit_sgd<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_buf, n, lr, momentum, nesterov, first, max_abs, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_vh_term(const int64_t* d_index, const uint8_t* d_keep, int64_t n_edges, const double* d_soft_mask, int resx, int resy,
+                double* d_loss, double* d_dterm, void* stream) {
+    if (n_edges < 0 || resx <= 0 || resy <= 0) return fail(DRT_E_INVALID, "bad sizes");
+    if (n_edges == 0) return DRT_OK;
+    if (!d_index || !d_keep || !d_soft_mask || !d_loss || !d_dterm) return fail(DRT_E_INVALID, "null pointer argument");
+    k_vh_term<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_index, d_keep, n_edges, d_soft_mask, resx, d_loss, d_dterm);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from . import _lib, mesh_io
-from .optix_mesh import optix_mesh, _stream
+from .optix_mesh import optix_mesh, _stream, _on
 from .stepwise import Intersection, StepwiseMixin  # noqa: F401  (Dintersect / refract_ray / trace2 / project_vert)
 
 # What the caches below did since import (or since cache_report(reset=True)): cache_report().  They are transparent by design -- a call that
@@ -363,7 +363,7 @@ class _RenderTransparent(torch.autograd.Function):
         took = ent if recycle and bases is not None else None
         if bases is not None:
             if pre is not None:
-                with torch.cuda.device(o.device):
+                with _on(o.device):
                     _lib.check(_lib.lib().drt_prefill_wait(om._h, stream_id))
                 pre = None
             out_ori, out_dir, mask = bases
@@ -372,7 +372,7 @@ class _RenderTransparent(torch.autograd.Function):
             out_dir = torch.empty((n, 3), dtype=torch.float64, device=o.device)
         else:
             if pre is not None:          # another size: let the zeroing finish (on this stream's timeline) before the memory goes back to the allocator
-                with torch.cuda.device(o.device):
+                with _on(o.device):
                     _lib.check(_lib.lib().drt_prefill_wait(om._h, stream_id))
             out_ori = torch.empty((n, 3), dtype=torch.float64, device=o.device)
             mask = torch.empty((n, 3), dtype=torch.uint8, device=o.device)
@@ -395,7 +395,7 @@ class _RenderTransparent(torch.autograd.Function):
         else:
             valid_idx = torch.empty(n, dtype=torch.int32, device=o.device) if want_list else None
             n_valid = torch.empty(1, dtype=torch.int64, device=o.device) if want_list else None
-        with torch.cuda.device(o.device):
+        with _on(o.device):
             # The library is handed raw pointers of buffers only this frame keeps alive (`took`: the pooled outputs and their row list):
             # nothing that can raise sits between the registration and the call that consumes it, and a call that fails withdraws them
             # itself (drt_render_forward) -- a request left behind would have the next call zero "rows" of freed memory.
@@ -455,7 +455,7 @@ class _RenderTransparent(torch.autograd.Function):
         # (the usual step -- one ray_loss, eager stash, nothing dense -- is ONE small launch: stash * scale)
         grad_v = None if (g_ori is None and g_dir is None and pending and all(e[0] is None for e in pending)) else torch.zeros_like(v)
         h = ctx.scene.optix_mesh._h
-        with torch.cuda.device(o.device):
+        with _on(o.device):
             if g_ori is not None or g_dir is not None:
                 g_ori = None if g_ori is None else _f64c(g_ori, "grad_out_ori")
                 g_dir = None if g_dir is None else _f64c(g_dir, "grad_out_dir")
@@ -497,7 +497,7 @@ class _RayLoss(torch.autograd.Function):
                  and out_ori._version == 0 and out_dir._version == 0)
         rows = torch.empty(n, dtype=torch.int32, device=oo.device) if need and not eager else None     # (the eager form needs no row list)
         n_rows = torch.zeros(1, dtype=torch.int32, device=oo.device) if need and not eager else None
-        with torch.cuda.device(oo.device):
+        with _on(oo.device):
             if eager:
                 # loss + unit-seed vertex gradient in one pass over the completed paths (see EAGER_LOSS_GRAD)
                 scene, v, o, d, face1, face2, ior = link.render
@@ -550,7 +550,7 @@ class _RayLoss(torch.autograd.Function):
                                    "cannot be rescaled -- recompute the loss instead of re-using the graph")
             sc = sc / ctx.applied
         ctx.applied = new
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             _lib.check(_lib.lib().drt_scale_rows3(g.data_ptr(), rows.data_ptr(), n_rows.data_ptr(), sc.data_ptr(), _stream()))
         return None, g, None, None, None, None
 
@@ -567,7 +567,7 @@ class _RenderRayLossFused(torch.autograd.Function):
         va = _flag_bytes(valid, "valid", o.shape[0])
         loss = torch.zeros((), dtype=torch.float64, device=o.device)
         grad_v = torch.zeros_like(v)
-        with torch.cuda.device(o.device):
+        with _on(o.device):
             _arm_seed(scene.optix_mesh._h, grid, o.shape[0])
             _lib.check(_lib.lib().drt_render_ray_loss_fused(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), o.shape[0],
@@ -616,7 +616,7 @@ def edge_tables(F, V, want_rows=False):
     E2F = torch.empty((n_e, 2, 3), dtype=torch.long, device=dev)
     rows = torch.empty(3 * n_f, dtype=torch.int32, device=dev)
     out = torch.zeros(2, dtype=torch.float64, device=dev)           # [mean_len, status (int32 in the low bytes of word 1)]
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = torch.empty(int(_lib.lib().drt_edge_tables_workspace(n_f)), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib().drt_edge_tables(Fc.data_ptr(), n_f, Vc.data_ptr(), n_v, ws.data_ptr(), Edges.data_ptr(), E2F.data_ptr(),
                                               rows.data_ptr(), out.data_ptr(), out[1:].data_ptr(), _stream()))
@@ -664,7 +664,7 @@ class Scene(StepwiseMixin):
         n_v, n_f, n_e = V.shape[0], F.shape[0], self.Edges.shape[0]
         V2 = torch.empty((n_v + n_e, 3), dtype=torch.float64, device=V.device)
         F2 = torch.empty((4 * n_f, 3), dtype=torch.long, device=V.device)
-        with torch.cuda.device(V.device):
+        with _on(V.device):
             _lib.check(_lib.lib().drt_subdivide_midpoint(F.data_ptr(), n_f, V.data_ptr(), n_v, self.Edges.contiguous().data_ptr(), n_e,
                                                          self._row2edge.data_ptr(), int(float32_positions), F2.data_ptr(), V2.data_ptr(), _stream()))
         self._set_topology(V2, F2)
@@ -714,7 +714,7 @@ class Scene(StepwiseMixin):
         """Drops the dense outputs this scene keeps for re-use (RECYCLE_OUTPUTS: up to two sets of 55 B per ray) and the buffers zeroed
         ahead of time (PREFILL_NEXT); the next render call allocates and fills fresh ones."""
         om = self.optix_mesh
-        with torch.cuda.device(self._dev):
+        with _on(self._dev):
             _lib.check(_lib.lib().drt_outputs_cancel(om._h))
             if getattr(om, "_prefilled", None) is not None:
                 _lib.check(_lib.lib().drt_prefill_wait(om._h, _stream()))
@@ -755,7 +755,7 @@ class Scene(StepwiseMixin):
         o = _f64c(origin.detach(), "origin")
         n = self.E2F.shape[0]
         flags = torch.empty(n, dtype=torch.uint8, device=v.device)
-        with torch.cuda.device(v.device):
+        with _on(v.device):
             _lib.check(_lib.lib().drt_silhouette_flags(v.data_ptr(), self.E2F.data_ptr(), n, o.data_ptr(), flags.data_ptr(), _stream()))
         if LAZY_SILHOUETTE:
             return SilhouetteEdges(self.Edges, flags)
@@ -765,6 +765,12 @@ class Scene(StepwiseMixin):
         """(index int64 [M,2] (x, y), output float32 [M]) of the in-view silhouette samples (DiffRender.py:459-479)."""
         if isinstance(silhouette_edge, SilhouetteEdges):      # (unwrapped here: autograd.Function.apply should see plain tensors / tuples)
             silhouette_edge = (silhouette_edge._edges, silhouette_edge._flags) if silhouette_edge._t is None else silhouette_edge.tensor()
+        if LAZY_VISIBILITY and isinstance(silhouette_edge, tuple) and not torch.cuda.is_current_stream_capturing():
+            # The samples are computed NOW (projection, probe rays: the geometry of this call), their compaction -- a boolean index, i.e. a
+            # device->host round trip per view -- only if somebody looks at them: the reference's loop feeds the pair straight into
+            # `(mask.view(resy, resx)[index[:, 1], index[:, 0]] - output).abs().sum()` (optim.py:78), which SampleSet evaluates in place.
+            ss = SampleSet(self, self.vertices, silhouette_edge, camera_M, origin, bool(detach_depth), int(resx), int(resy))
+            return LazyIndex(ss), LazyOutput(ss)
         return _EdgeSample.apply(self.vertices, silhouette_edge, camera_M, origin, self, bool(detach_depth), int(resx), int(resy))
 
     def vh_loss_fused(self, camera_M, origin, soft_mask):
@@ -843,6 +849,189 @@ class SilhouetteEdges:
         return func(*args, **kwargs)
 
 
+LAZY_VISIBILITY = os.environ.get("DRT_LAZY_VISIBILITY", "1") != "0"
+
+
+class SampleSet:
+    """The silhouette samples of one ``primary_visibility`` call, left where the kernel wrote them: for ALL E unique edges an index row,
+    f = hit(+) - hit(-) and a `keep` flag (|f| > 1e-5 and inside the view: DiffRender.py:244, 478).  The reference returns the compacted
+    (index [M,2], output [M]); that compaction is ``materialise()`` -- taken by anything that looks at the pair as tensors.  The one
+    expression the reference's loop applies to the pair (optim.py:78) is recognised step by step by the lazy objects below and evaluated by
+    ``term()`` over the uncompacted rows: same samples, same terms, a float64 sum in another order."""
+
+    def __init__(self, scene, vertices, sil, camera_M, origin, detach_depth, res_x, res_y):
+        self.scene, self.vertices, self.sil, self.camera_M, self.origin = scene, vertices, sil, camera_M, origin
+        self.detach_depth, self.res_x, self.res_y = detach_depth, res_x, res_y
+        self.v = _f64c(vertices.detach(), "vertices")
+        edges, flags = sil
+        self.edges = edges.contiguous()
+        assert self.edges.dtype == torch.long and self.edges.dim() == 2 and self.edges.shape[1] == 2
+        self.cam = pack_camera(camera_M)
+        o = _f64c(origin.detach(), "origin")
+        n = self.edges.shape[0]
+        dev = self.v.device
+        w8 = torch.empty(3 * n, dtype=torch.long, device=dev)           # (two allocations instead of four: index | d term / d output ; f | keep)
+        w1 = torch.empty(5 * n, dtype=torch.uint8, device=dev)
+        self.index, self.dterm = w8[:2 * n].view(n, 2), w8[2 * n:].view(torch.float64)
+        self.f, self.keep = w1[:4 * n].view(torch.float32), w1[4 * n:]
+        with _on(dev):
+            _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, self.v.data_ptr(), self.edges.data_ptr(), n, self.cam.data_ptr(),
+                                                          o.data_ptr(), self.index.data_ptr(), self.f.data_ptr(), self.keep.data_ptr(), res_x, res_y,
+                                                          _lib.ptr(flags), _stream()))
+        self._pair = None
+        _stats["visibility_lazy"] += 1
+
+    def materialise(self):
+        """(index int64 [M,2], output float32 [M]) as the reference returns them, differentiable w.r.t. the vertices."""
+        if self._pair is None:
+            _stats["visibility_materialised"] += 1
+            self._pair = _EdgeSample.apply(self.vertices, self.sil, self.camera_M, self.origin, self.scene, self.detach_depth, self.res_x, self.res_y,
+                                           (self.index, self.f, self.keep))
+        return self._pair
+
+    def term(self, image):
+        """sum |image[y, x] - output| over the samples (optim.py:78), a scalar differentiable w.r.t. the vertices."""
+        _stats["visibility_term_in_place"] += 1
+        return _VhTermLazy.apply(self.vertices, self, image)
+
+
+class _LazyTensor:
+    """A stand-in that behaves as the tensor ``self.tensor()`` for everything it does not recognise."""
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, k):
+        return self.tensor()[k]
+
+    def __len__(self):
+        return len(self.tensor())
+
+    def __iter__(self):
+        return iter(self.tensor())
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.tensor()!r})"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], tuple) and len(args[1]) == 2:
+            # image[index[:, 1], index[:, 0]]  (optim.py:78)
+            img, (iy, ix) = args
+            if (isinstance(iy, LazyColumn) and isinstance(ix, LazyColumn) and iy._ss is ix._ss and (iy._col, ix._col) == (1, 0) and isinstance(img, torch.Tensor)
+                    and img.dim() == 2 and img.shape == (iy._ss.res_y, iy._ss.res_x) and img.dtype == torch.float64 and img.is_cuda and img.is_contiguous()
+                    and not img.requires_grad and iy._ss._pair is None):
+                return LazyGather(iy._ss, img)
+        un = _unlazy
+        return func(*un(args), **{k: un(v) for k, v in (kwargs or {}).items()})
+
+
+def _unlazy(a):
+    if isinstance(a, _LazyTensor):
+        return a.tensor()
+    if isinstance(a, (list, tuple)):
+        return type(a)(_unlazy(b) for b in a)
+    return a
+
+
+class LazyIndex(_LazyTensor):
+    def __init__(self, ss):
+        self._ss = ss
+
+    def tensor(self):
+        return self._ss.materialise()[0]
+
+    def __getitem__(self, k):
+        if isinstance(k, tuple) and len(k) == 2 and k[0] == slice(None) and type(k[1]) is int and k[1] in (0, 1) and self._ss._pair is None:
+            return LazyColumn(self._ss, k[1])
+        return self.tensor()[k]
+
+
+class LazyColumn(_LazyTensor):
+    def __init__(self, ss, col):
+        self._ss, self._col = ss, col
+
+    def tensor(self):
+        return self._ss.materialise()[0][:, self._col]
+
+
+class LazyOutput(_LazyTensor):
+    def __init__(self, ss):
+        self._ss = ss
+
+    def tensor(self):
+        return self._ss.materialise()[1]
+
+
+class LazyGather(_LazyTensor):
+    """image[index[:, 1], index[:, 0]]"""
+
+    def __init__(self, ss, image):
+        self._ss, self._image = ss, image
+
+    def tensor(self):
+        idx = self._ss.materialise()[0]
+        return self._image[idx[:, 1], idx[:, 0]]
+
+    def __sub__(self, other):
+        if isinstance(other, LazyOutput) and other._ss is self._ss and self._ss._pair is None:
+            return LazyDiff(self._ss, self._image, 0)
+        return self.tensor() - _unlazy(other)
+
+
+class LazyDiff(_LazyTensor):
+    """image[...] - output (stage 0), its .abs() (stage 1); .sum() of stage 1 is SampleSet.term."""
+
+    def __init__(self, ss, image, stage):
+        self._ss, self._image, self._stage = ss, image, stage
+
+    def tensor(self):
+        idx, out = self._ss.materialise()
+        d = self._image[idx[:, 1], idx[:, 0]] - out
+        return d.abs() if self._stage else d
+
+    def abs(self):
+        if self._stage == 0 and self._ss._pair is None:
+            return LazyDiff(self._ss, self._image, 1)
+        return self.tensor().abs()
+
+    def sum(self, *args, **kwargs):
+        if self._stage == 1 and not args and not kwargs and self._ss._pair is None:
+            return self._ss.term(self._image)
+        return self.tensor().sum(*args, **kwargs)
+
+
+class _VhTermLazy(torch.autograd.Function):
+    """sum over the kept samples of |image[y, x] - 0.5| as a function of the vertices (SampleSet.term)."""
+
+    @staticmethod
+    def forward(ctx, vertices, ss, image):
+        n = ss.edges.shape[0]
+        dev = ss.v.device
+        loss = torch.zeros((), dtype=torch.float64, device=dev)
+        dterm = ss.dterm
+        with _on(dev):
+            _lib.check(_lib.lib().drt_vh_term(ss.index.data_ptr(), ss.keep.data_ptr(), n, image.data_ptr(), ss.res_x, ss.res_y,
+                                              loss.data_ptr(), dterm.data_ptr(), _stream()))
+        ctx.ss = ss
+        ctx.save_for_backward(dterm)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (dterm,) = ctx.saved_tensors
+        ss = ctx.ss
+        grad_v = torch.zeros_like(ss.v)
+        # (the reference's `output` is float32: the incoming gradient reaches primary_edge_sample.backward rounded to float32, DiffRender.py:251, 263-267)
+        g = g_loss if (g_loss.dtype == torch.float64 and g_loss.is_cuda and g_loss.numel() == 1) else g_loss.to(device=ss.v.device, dtype=torch.float64).reshape(1)
+        with _on(ss.v.device):
+            _lib.check(_lib.lib().drt_edge_sample_backward_term(ss.v.data_ptr(), ss.edges.data_ptr(), ss.edges.shape[0], ss.cam.data_ptr(), ss.f.data_ptr(),
+                                                                dterm.data_ptr(), g.data_ptr(), int(ss.detach_depth), grad_v.data_ptr(), _stream()))
+        return grad_v, None, None
+
+
 class _Dihedral(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vertices, E2F):
@@ -851,7 +1040,7 @@ class _Dihedral(torch.autograd.Function):
         assert e2f.dtype == torch.long and e2f.shape[1:] == (2, 3)
         n = e2f.shape[0]
         out = torch.empty(n, dtype=torch.float64, device=v.device)
-        with torch.cuda.device(v.device):
+        with _on(v.device):
             _lib.check(_lib.lib().drt_dihedral_forward(v.data_ptr(), e2f.data_ptr(), n, out.data_ptr(), _stream()))
         ctx.save_for_backward(v, e2f)
         return out
@@ -861,7 +1050,7 @@ class _Dihedral(torch.autograd.Function):
         v, e2f = ctx.saved_tensors
         grad_v = torch.zeros_like(v)
         g = _f64c(g_cos, "grad")
-        with torch.cuda.device(v.device):
+        with _on(v.device):
             _lib.check(_lib.lib().drt_dihedral_backward(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], g.data_ptr(), grad_v.data_ptr(), _stream()))
         return grad_v, None
 
@@ -873,7 +1062,7 @@ class _SmLossFused(torch.autograd.Function):
         e2f = E2F.contiguous()
         loss = torch.zeros((), dtype=torch.float64, device=v.device)
         grad_v = torch.zeros_like(v)
-        with torch.cuda.device(v.device):
+        with _on(v.device):
             _lib.check(_lib.lib().drt_sm_loss_fused(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], loss.data_ptr(), grad_v.data_ptr(), _stream()))
         ctx.save_for_backward(grad_v)
         return loss
@@ -889,7 +1078,7 @@ class _EdgeSample(torch.autograd.Function):
     as one function of the vertices."""
 
     @staticmethod
-    def forward(ctx, vertices, sil_edges, camera_M, origin, scene, detach_depth, res_x, res_y):
+    def forward(ctx, vertices, sil_edges, camera_M, origin, scene, detach_depth, res_x, res_y, computed=None):
         v = _f64c(vertices.detach(), "vertices")
         flags = None
         if isinstance(sil_edges, tuple):
@@ -901,13 +1090,16 @@ class _EdgeSample(torch.autograd.Function):
         cam = pack_camera(camera_M)
         o = _f64c(origin.detach(), "origin")
         n = edges.shape[0]
-        index = torch.empty((n, 2), dtype=torch.long, device=v.device)
-        f = torch.empty(n, dtype=torch.float32, device=v.device)           # (the kernel writes f and keep of every row, 0 for unflagged edges)
-        keep = torch.empty(n, dtype=torch.uint8, device=v.device)
-        with torch.cuda.device(v.device):
-            _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), n, cam.data_ptr(),
-                                                          o.data_ptr(), index.data_ptr(), f.data_ptr(), keep.data_ptr(), int(res_x), int(res_y),
-                                                          _lib.ptr(flags), _stream()))
+        if computed is not None:           # (a SampleSet that is being materialised: the kernel ran when primary_visibility was called)
+            index, f, keep = computed
+        else:
+            index = torch.empty((n, 2), dtype=torch.long, device=v.device)
+            f = torch.empty(n, dtype=torch.float32, device=v.device)           # (the kernel writes f and keep of every row, 0 for unflagged edges)
+            keep = torch.empty(n, dtype=torch.uint8, device=v.device)
+            with _on(v.device):
+                _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), n, cam.data_ptr(),
+                                                              o.data_ptr(), index.data_ptr(), f.data_ptr(), keep.data_ptr(), int(res_x), int(res_y),
+                                                              _lib.ptr(flags), _stream()))
         # |f| > 1e-5 (DiffRender.py:244) and inside the view (DiffRender.py:478), decided by the kernel: ONE boolean index, one host sync.
         # (An ordered compaction by one block of our own in place of the library's three-launch select: 58 us against 34 -- not kept.)
         sel = torch.nonzero(keep).squeeze(1)             # (the host sync; the row numbers also serve the backward, which then needs none)
@@ -923,12 +1115,12 @@ class _EdgeSample(torch.autograd.Function):
         v, edges, cam, f, sel = ctx.saved_tensors
         grad_v = torch.zeros_like(v)
         g = grad_output if grad_output.dtype == torch.float32 and grad_output.is_contiguous() else grad_output.to(torch.float32).contiguous()
-        with torch.cuda.device(v.device):
+        with _on(v.device):
             # (the kept rows and their float32 gradients as they are: no zero-filled [Es] coefficient vector, cast and scatter per view)
             _lib.check(_lib.lib().drt_edge_sample_backward_rows(v.data_ptr(), edges.data_ptr(), edges.shape[0], cam.data_ptr(), f.data_ptr(),
                                                                 sel.data_ptr(), sel.shape[0], g.data_ptr(), int(ctx.detach_depth),
                                                                 grad_v.data_ptr(), _stream()))
-        return grad_v, None, None, None, None, None, None, None, None
+        return grad_v, None, None, None, None, None, None, None, None, None
 
 
 class _VhLossFused(torch.autograd.Function):
@@ -947,7 +1139,7 @@ class _VhLossFused(torch.autograd.Function):
             keep += [o, sm]
             cams[k], orgs[k], softs[k] = flat[3 * k].data_ptr(), o.data_ptr(), sm.data_ptr()
         edges, e2f = scene.Edges, scene.E2F
-        with torch.cuda.device(v.device):
+        with _on(v.device):
             _lib.check(_lib.lib().drt_vh_loss_fused(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), e2f.data_ptr(), e2f.shape[0], n,
                                                     cams, orgs, softs, res_x, res_y, 1, loss.data_ptr(), grad_v.data_ptr(), _stream()))
         ctx.save_for_backward(grad_v)

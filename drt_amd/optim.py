@@ -166,7 +166,7 @@ class FusedLimitSGD:
 
     def step(self):
         from . import _lib
-        from .optix_mesh import _stream
+        from .optix_mesh import _stream, _on
         p, g = self.parameter, self.parameter.grad
         if g is None:
             return
@@ -174,7 +174,7 @@ class FusedLimitSGD:
         first = self.buf is None
         if first and self.momentum != 0.0:
             self.buf = torch.empty_like(p)
-        with torch.cuda.device(p.device):
+        with _on(p.device):
             _lib.check(_lib.lib().drt_limit_sgd_step(p.data_ptr(), g.data_ptr(), _lib.ptr(self.buf), p.numel(), self.param_groups[0]["lr"], self.momentum,
                                                       int(self.nesterov), int(first), self.max_abs, _stream()))
 

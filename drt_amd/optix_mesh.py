@@ -24,8 +24,37 @@ import torch
 from . import _lib
 
 
+# The host side of an iteration is a chain of ~100 small calls, and torch's public accessors are Python: `torch.cuda.current_stream()` builds a
+# Stream object (10 us), `with _on(d):` resolves its argument and exchanges the device twice (5-10 us) -- together a quarter of
+# the host time of the reference-shaped iteration (tools/vh_host_profile.py).  The raw accessors behind them are used where they exist.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device, as a ctypes pointer."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _NoContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
+def _on(device):
+    """``with _on(device):`` -- torch.cuda.device(device), or nothing at all when that device is the current one already (the usual case)."""
+    idx = device if isinstance(device, int) else getattr(device, "index", None)
+    if idx is not None and _raw_device is not None and _raw_device() == idx:
+        return _NO_CONTEXT
+    return torch.cuda.device(device)
 
 
 def _require(t, dtype, cols, name):
@@ -46,7 +75,7 @@ class optix_mesh:
             raise _lib.DrtError("no GPU visible: drt_amd needs an MI355X (gfx950) device")
         self.device = int(cuda_device)
         h = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_create(self.device, ctypes.byref(h)))
         self._h = h
         self.builded = False
@@ -71,7 +100,7 @@ class optix_mesh:
         V = _require(V, torch.float32, 3, "V")
         self._check_device(F, "F")
         self._check_device(V, "V")
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_update_mesh(self._h, F.data_ptr(), F.size(0), V.data_ptr(), V.size(0), _stream()))
         self.n_faces, self.n_verts = F.size(0), V.size(0)
         self.builded = True
@@ -80,7 +109,7 @@ class optix_mesh:
         assert self.builded, "update_mesh must be called first"
         V = _require(V, torch.float32, 3, "V")
         self._check_device(V, "V")
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_update_vert(self._h, V.data_ptr(), V.size(0), _stream()))
 
     def update_vert_f64(self, V):
@@ -88,7 +117,7 @@ class optix_mesh:
         assert self.builded, "update_mesh must be called first"
         V = _require(V.detach(), torch.float64, 3, "V")
         self._check_device(V, "V")
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_update_vert_f64(self._h, V.data_ptr(), V.size(0), _stream()))
 
     def intersect(self, Ray):
@@ -98,7 +127,7 @@ class optix_mesh:
         n = Ray.size(0)
         T = torch.empty(n, dtype=torch.float32, device=Ray.device)
         ID = torch.empty(n, dtype=torch.int32, device=Ray.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_intersect(self._h, Ray.data_ptr(), n, T.data_ptr(), ID.data_ptr(), _stream()))
         return [T, ID]
 
@@ -110,7 +139,7 @@ class optix_mesh:
         self._check_device(Ray, "Ray")
         n = Ray.size(0)
         hit = torch.empty(n, dtype=torch.uint8, device=Ray.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_intersect_any(self._h, Ray.data_ptr(), n, hit.data_ptr(), _stream()))
         return hit.view(torch.bool)
 
@@ -120,7 +149,7 @@ class optix_mesh:
         n = Ray.size(0)
         T = torch.empty(n, dtype=torch.float32, device=Ray.device)
         ID = torch.empty(n, dtype=torch.int32, device=Ray.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_intersect_bruteforce(self._h, Ray.data_ptr(), n, T.data_ptr(), ID.data_ptr(), _stream()))
         return [T, ID]
 
@@ -133,7 +162,7 @@ class optix_mesh:
         dist = torch.empty(n, dtype=torch.float64, device=points.device)
         face = torch.empty(n, dtype=torch.int32, device=points.device) if want_face else None
         closest = torch.empty(n, 3, dtype=torch.float64, device=points.device) if want_point else None
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_closest_point(self._h, points.data_ptr(), n, dist.data_ptr(), face.data_ptr() if want_face else None,
                                                     closest.data_ptr() if want_point else None, _stream()))
         return dist, face, closest
@@ -144,7 +173,7 @@ class optix_mesh:
         v = ctypes.c_int64()
         hgt = ctypes.c_int32()
         wide = ctypes.c_int32()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_bvh_check(self._h, _stream(), ctypes.byref(v), ctypes.byref(hgt), ctypes.byref(wide)))
         self.wide_depth = wide.value
         return v.value, hgt.value
@@ -157,13 +186,13 @@ class optix_mesh:
     def build_params(self):
         """(lo[3], 1/extent[3], leaf padding) of the scene box the last build derived from the vertices; synchronises."""
         out = (ctypes.c_float * 7)()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_build_params(self._h, out, _stream()))
         return list(out)
 
     def sorted_faces(self):
         out = torch.empty(self.n_faces, dtype=torch.int32, device=f"cuda:{self.device}")
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_bvh_sorted_faces(self._h, out.data_ptr(), _stream()))
         return out
 
@@ -173,7 +202,7 @@ class optix_mesh:
         """1: bracket every pipeline kernel with hipEvents on its launch stream (bench.py's live timing);
         2: also collect traversal statistics (perturbs timing); 3: timers with the pipelines serialised on one internal
         stream (each kernel timed alone); 0: off."""
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_profile_enable(self._h, int(on)))
 
     def profile_select(self, stages=None):
@@ -187,7 +216,7 @@ class optix_mesh:
         ms = (ctypes.c_double * n)()
         launches = (ctypes.c_int64 * n)()
         items = (ctypes.c_int64 * n)()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().drt_profile_read(self._h, ms, launches, items))
         return {k: (ms[i], launches[i], items[i]) for i, k in enumerate(self.STAGES)}
 

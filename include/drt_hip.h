@@ -279,6 +279,19 @@ int drt_edge_sample_backward_rows(const double* d_verts, const int64_t* d_edges,
                                   const double* d_camera, const float* d_f, const int64_t* d_rows, int64_t n_rows,
                                   const float* d_g, int detach_depth, double* d_grad_verts, void* stream);
 
+/* drt_vh_term <- the loss expression of ONE view, optim.py:78 `(mask.view(resy, resx)[index[:,1], index[:,0]] - output).abs().sum()`, over
+ * the samples a drt_edge_sample_forward call left in place: d_index int64 [E,2] and d_keep uint8 [E] as that call wrote them (rows with
+ * keep = 0 are not read), d_soft_mask float64 [resy*resx], `output` = 0.5.  *d_loss += the sum (zero it first); d_dterm float64 [E] =
+ * d term / d output per row (-sign(mask - 0.5); 0 for dropped rows) -- times the incoming gradient it is drt_edge_sample_backward's
+ * `coef`.  Lets the drop-in pair evaluate the reference's own expression without compacting the samples (no device->host round trip). */
+int drt_vh_term(const int64_t* d_index, const uint8_t* d_keep, int64_t n_edges, const double* d_soft_mask, int resx, int resy,
+                double* d_loss, double* d_dterm, void* stream);
+/* drt_edge_sample_backward with coef[e] = d_dterm[e] * float32(*d_g): drt_vh_term's per-row derivative times the incoming scalar gradient of
+ * the view's term (a float64 DEVICE scalar), rounded to float32 as autograd rounds it on its way into the reference's float32 `output`
+ * (DiffRender.py:251, 263-267) -- the backward of the lazily evaluated expression in one launch. */
+int drt_edge_sample_backward_term(const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera, const float* d_f,
+                                  const double* d_dterm, const double* d_g, int detach_depth, double* d_grad_verts, void* stream);
+
 /* drt_vh_loss_fused <- Loss_calculator.vh_loss (optim.py:73-78) for n_views views: silhouette_edge +
  * primary_visibility + sum |soft_mask[y, x] - output| and its vertex gradient, entirely on the device
  * (the drop-in methods above return dynamically sized tensors and cost two host syncs per view; here the
