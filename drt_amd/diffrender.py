@@ -928,6 +928,21 @@ class _LazyTensor:
         return func(*un(args), **{k: un(v) for k, v in (kwargs or {}).items()})
 
 
+def _delegate(name):
+    def op(self, *args, **kwargs):
+        return getattr(self.tensor(), name)(*_unlazy(args), **{k: _unlazy(v) for k, v in kwargs.items()})
+    op.__name__ = name
+    return op
+
+
+# operators are looked up on the TYPE, not through __getattr__: every one a tensor has goes to the materialised tensor
+for _name in ("add radd sub rsub mul rmul truediv rtruediv floordiv rfloordiv mod rmod pow rpow matmul rmatmul neg pos abs invert and rand or ror xor rxor "
+              "lshift rshift eq ne lt le gt ge bool float int index contains").split():
+    if not hasattr(_LazyTensor, f"__{_name}__") or _name in ("eq", "ne", "lt", "le", "gt", "ge"):
+        setattr(_LazyTensor, f"__{_name}__", _delegate(f"__{_name}__"))
+_LazyTensor.__hash__ = lambda self: id(self)
+
+
 def _unlazy(a):
     if isinstance(a, _LazyTensor):
         return a.tensor()
