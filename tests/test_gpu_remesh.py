@@ -1,4 +1,5 @@
-"""The remesher on the device (drt_amd/remesh_gpu.py, csrc/drt_remesh_gpu.hip) against its checker, the sequential host version
+"""The remesher on the device (drt_amd/remesh_gpu.py, csrc/drt_remesh_gpu.hip) against (i) oracle/remesh_oracle.py -- the contract of the reference's
+MeshLab parameter set (optim.py:17-32), measured with numpy alone -- and (ii) the sequential host version
 (drt_amd/remesh.py, csrc/drt_remesh.cpp): same invariants -- closed oriented manifold of the same genus, on the input surface, edge
 lengths concentrated around the target, no folds, deterministic -- and, statistically, the same mesh: face count, edge-length
 histogram, valence distribution, two-sided distance between the two results.  (Neither can be held against MeshLab, reference
@@ -69,6 +70,10 @@ def test_device_remesh_has_the_host_versions_invariants_and_statistics(hand, L):
     n = np.cross(tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0])
     n /= np.linalg.norm(n, axis=2, keepdims=True)
     assert (n[:, 0] * n[:, 1]).sum(1).min() > -0.9                            # no folded pairs
+    # ---- the contract of the reference's MeshLab parameter set, measured by the independent oracle (numpy only, no product helpers)
+    from oracle import remesh_oracle as ro
+    rep, bad = ro.check(hand.vertices, hand.faces, dev.vertices, dev.faces, L, max_surf_dist=1.0, max_samples=1500)
+    assert not bad, (bad, rep)
     # ---- the same mesh as the host version's, statistically
     assert abs(len(dev.faces) / len(host.faces) - 1) < 0.03, (len(dev.faces), len(host.faces))
     bins = np.linspace(0.5 * L, 1.6 * L, 12)

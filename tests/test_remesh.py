@@ -58,6 +58,36 @@ def test_remesh_hand(hand, L):
     assert (n[:, 0] * n[:, 1]).sum(1).min() > -0.9
 
 
+@pytest.mark.parametrize("L", [6.0, 3.0])
+def test_host_remesh_meets_the_contract_of_the_references_meshlab_parameters(hand, L):
+    """oracle/remesh_oracle.py: the contract of reference optim.py:17-32 (Iterations 3, TargetLen L, MaxSurfDist 1, all five steps),
+    measured with numpy alone -- none of the product's mesh helpers."""
+    from oracle import remesh_oracle as ro
+    out = remesh.isotropic_remesh(hand, L)
+    rep, bad = ro.check(hand.vertices, hand.faces, out.vertices, out.faces, L, max_surf_dist=1.0, max_samples=1500)
+    assert not bad, (bad, rep)
+    assert rep["topology"]["genus_sum"] == 0 and rep["topology"]["components"] == 1
+
+
+def test_the_remesh_oracle_rejects_broken_outputs(hand):
+    """Negative controls: a flipped face, a vertex pulled off the surface, and the untouched input (nothing like the target length)."""
+    from oracle import remesh_oracle as ro
+    L = 4.0
+    out = remesh.isotropic_remesh(hand, L)
+    F2 = out.faces.copy()
+    F2[0] = F2[0][[1, 0, 2]]
+    assert any("manifold" in b for b in ro.check(hand.vertices, hand.faces, out.vertices, F2, L, max_samples=300)[1])
+    V2 = out.vertices.copy()
+    V2[10] += 3.0
+    assert any("off the input surface" in b for b in ro.check(hand.vertices, hand.faces, V2, out.faces, L, max_samples=len(V2))[1])
+    bad = ro.check(hand.vertices, hand.faces, hand.vertices, hand.faces, L, max_samples=300)[1]
+    assert any("in [4/5 L, 4/3 L]" in b for b in bad)
+    # the distance routine of this oracle against the one the rest of the suite uses
+    P = np.random.default_rng(1).standard_normal((200, 3)) * 60 + hand.vertices.mean(0)
+    d2, _ = orc.point_mesh_distance(P, hand.vertices, hand.faces)
+    assert np.abs(ro.distance_to_surface(P, hand.vertices, hand.faces) - np.asarray(d2)).max() < 1e-10
+
+
 def test_remesh_is_deterministic_and_float32(hand):
     a = remesh.isotropic_remesh(hand, 4.0)
     b = remesh.isotropic_remesh(hand, 4.0)
