@@ -301,7 +301,7 @@ def smooth_fixture(DR, optim, scene, mesh, center, extent):
                         param0=steps[0]["param"], param1=steps[1]["param"], loss_str0=steps[0]["loss_str"], loss_str1=steps[1]["loss_str"])
 
 
-def trajectory_fixture(DR, optim, mesh, center, extent, iters=60, every=10, res=64, seed=12):
+def trajectory_fixture(DR, optim, mesh, center, extent, iters=60, every=10, res=64, seed=12, tag="hand_trajectory", name="hand", sigma=0.4):
     """One pass of the reference's own loop (optim.py:190-215: update_verticex -> all_loss -> backward -> limit_hook -> SGD
     nesterov), `iters` iterations at the reference's hyper-parameters (config.py:18-39: lr = start_lr of pass 0), with the
     reference's own Loss_calculator and its own stochastic view order: the imported captured_data.Data's
@@ -319,7 +319,7 @@ def trajectory_fixture(DR, optim, mesh, center, extent, iters=60, every=10, res=
         mesh_io.write_ply(path, Vs, mesh.faces)
         scene = DR.Scene(path)
     DR.resx = DR.resy = res
-    gt = views.displaced_ground_truth(mesh_io.TriMesh(Vs, mesh.faces), sigma=0.4, seed=5)
+    gt = views.displaced_ground_truth(mesh_io.TriMesh(Vs, mesh.faces), sigma=sigma, seed=5)
     gt_mesh = orc.Mesh(gt.faces, torch.tensor(gt.vertices))
 
     def render_gt(o, d):
@@ -331,7 +331,7 @@ def trajectory_fixture(DR, optim, mesh, center, extent, iters=60, every=10, res=
 
     vs = views.make_views(render_gt, hit_gt, center, extent, 72, res, res)
     data = cd.Data.__new__(cd.Data)
-    data.name, data.num_view, data.resx, data.resy = "hand", 72, res, res
+    data.name, data.num_view, data.resx, data.resy = name, 72, res, res
     data.Views = vs
     schedule = {"ray": [], "silh": []}
     get_view = data.get_view
@@ -375,7 +375,7 @@ def trajectory_fixture(DR, optim, mesh, center, extent, iters=60, every=10, res=
             print("trajectory", it, loss_str, "LOSS", loss.item(), "gmax", rec["gmax"][-1])
     used = sorted(set(schedule["ray"]))
     np.savez_compressed(
-        os.path.join(OUT, "hand_trajectory.npz"), vertices=Vs.astype(np.float32), res=res, lr=lr, momentum=HP["momentum"], ior=IOR,
+        os.path.join(OUT, tag + ".npz"), vertices=Vs.astype(np.float32), faces=np.asarray(mesh.faces, dtype=np.int32), res=res, lr=lr, momentum=HP["momentum"], ior=IOR,
         ray_w=HP["ray_w"], sm_w=HP["sm_w"], vh_w=HP["vh_w"], mean_len=scene.mean_len, seed=seed,
         ray_schedule=np.array(schedule["ray"]), silh_schedule=np.array(schedule["silh"]),
         # inputs of the synthetic capture: targets of the refraction views that were used, soft masks of all 72 views (float32 holds them exactly:
@@ -384,7 +384,7 @@ def trajectory_fixture(DR, optim, mesh, center, extent, iters=60, every=10, res=
         soft_mask=np.stack([vs[k][2].numpy() for k in range(72)]),
         loss=np.array(rec["loss"]), loss_str=np.array(rec["loss_str"]), gmax=np.array(rec["gmax"]),
         param_its=np.array(rec["param_its"]), params=np.stack(rec["params"]))
-    print("wrote hand_trajectory.npz: loss", rec["loss"][0], "->", rec["loss"][-1], "distinct ray views", len(used))
+    print("wrote", tag + ".npz: loss", rec["loss"][0], "->", rec["loss"][-1], "distinct ray views", len(used))
 
 
 def degenerate_fixture(DR, optim, mesh, center, extent):
@@ -544,6 +544,14 @@ def horse_fixture(DR, optim):
     print("horse fixture:", rec["n_faces"], "faces,", os.path.getsize(f), "bytes")
 
 
+def horse_trajectory(DR, optim):
+    """The same pass of the reference's loop on the HEADLINE mesh (horse_vh.ply x 4 = 50 248 triangles, smoothed like the hand hull so that
+    sm_loss is finite): 40 iterations, checkpoints at 20 and 40."""
+    hull = mesh_io.subdivide_midpoint(mesh_io.read_ply(os.path.join(REPO, "data", "horse_vh.ply")))
+    center, extent = views.mesh_frame(hull.vertices)
+    trajectory_fixture(DR, optim, hull, center, extent, iters=40, every=20, res=64, seed=21, tag="horse50k_trajectory", name="horse", sigma=0.3)
+
+
 def main():
     torch.manual_seed(0)
     np.random.seed(0)
@@ -559,6 +567,8 @@ def main():
         return horse_fixture(DR, optim)
     if only == {"trajectory"}:
         return trajectory_fixture(DR, optim, mesh, center, extent)
+    if only == {"horse_trajectory"}:
+        return horse_trajectory(DR, optim)
     if only == {"mouse"}:       # BASELINE.json configs[2]: mouse_vh.ply subdivided to 36 984 triangles
         return big_mesh_fixture(DR, optim, "mouse", 29, "mouse37k_r256_v29")
     scene = DR.Scene(path)
@@ -570,6 +580,7 @@ def main():
             render_fixture(DR, optim, scene, mesh, center, extent, res, view_id, f"hand_r{res}_v{view_id}")
     smooth_fixture(DR, optim, scene, mesh, center, extent)
     trajectory_fixture(DR, optim, mesh, center, extent)
+    horse_trajectory(DR, optim)
     degenerate_fixture(DR, optim, mesh, center, extent)
     horse_fixture(DR, optim)
     big_mesh_fixture(DR, optim, "mouse", 29, "mouse37k_r256_v29")
