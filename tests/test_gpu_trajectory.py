@@ -31,11 +31,13 @@ PARAM_ATOL = 1e-12
 LOSS_RTOL = 1e-12
 
 
-@pytest.fixture()
-def case():
+@pytest.fixture(params=["hand_trajectory", "horse50k_trajectory"])
+def case(request):
+    """hand_trajectory: 60 iterations on the smoothed hand hull (4 390 triangles); horse50k_trajectory: 40 iterations on the HEADLINE mesh
+    (horse_vh x 4 = 50 248 triangles, smoothed), checkpoints at 20 and 40."""
     from drt_amd import diffrender as Render, optim as O
-    g = tc.load()
-    hand = mesh_io.read_ply(data_path("hand_vh.ply"))
+    g = tc.load(request.param)
+    hand = tc.frame_mesh(request.param)
     Render.intIOR = float(g["ior"])
     Render.resx = Render.resy = int(g["res"])
     Vs = g["vertices"].astype(np.float64)

@@ -350,6 +350,42 @@ def test_degenerate_faces_follow_the_reference(hand):
     close(param, g["step_param"], rtol=1e-8, atol=1e-13)
 
 
+def test_headline_mesh_trajectory_first_iterations():
+    """The first two iterations of the same recorded pass on the HEADLINE mesh (tests/golden/horse50k_trajectory.npz: 50 248 triangles) by
+    the oracle (brute-force tracer: about a second per iteration here)."""
+    import trajectory_case as tc
+    from drt_amd import mesh_io
+    g = tc.load("horse50k_trajectory")
+    hull = tc.frame_mesh("horse50k_trajectory")
+    faces = hull.faces
+    assert np.array_equal(np.asarray(g["faces"]), np.asarray(faces, dtype=np.int32))
+    data = tc.RecordedCapture(g, hull.vertices, "cpu")
+    res = data.resx
+    Vs = torch.tensor(g["vertices"].astype(np.float64))
+    Edges, E2F, _ = (torch.tensor(np.asarray(a)) if not np.isscalar(a) else a for a in mesh_io.edge_tables(mesh_io.TriMesh(Vs.numpy(), faces)))
+    ray_view, silh_view = data.ray_view_generator(), data.silh_view_generator()
+    param, buf = torch.zeros_like(Vs), None
+    for it in range(2):
+        p = param.clone().requires_grad_(True)
+        V = Vs + p
+        mesh = orc.Mesh(faces, V)
+        sp, valid, _, o, d, _ = data.get_view(next(ray_view))
+        oo, od, mk = orc.render_transparent(mesh, o, d, float(g["ior"]))
+        ray = orc.ray_loss(oo, od, mk, sp, valid)
+        vh = 0
+        for _ in range(8):
+            _, _, soft, o_k, _, cam = data.get_view(next(silh_view))
+            vh = vh + orc.vh_loss_view(mesh, Edges, E2F, cam, o_k[0], soft, res, res)
+        sm = orc.sm_loss(V, E2F)
+        loss = orc.total_loss(ray, vh, sm, res, float(g["mean_len"]))
+        assert loss.item() == pytest.approx(float(g["loss"][it]), rel=1e-9), it
+        assert f"ray={ray:g} vh={vh:g} sm={sm:g}" == str(g["loss_str"][it]), it
+        grad, = torch.autograd.grad(loss, p)
+        grad = orc.limit_grad(grad)
+        assert grad.abs().max().item() == pytest.approx(float(g["gmax"][it]), rel=1e-7)
+        param, buf = orc.sgd_nesterov_step(param, grad, buf, float(g["lr"]), float(g["momentum"]))
+
+
 def test_long_trajectory_first_iterations(hand):
     """The first 20 iterations of the recorded pass of the reference's loop (tests/golden/hand_trajectory.npz: optim.py:190-215 with the
     reference's own Loss_calculator, 1 stochastic refraction view + 8 silhouette views + smoothness per iteration, limit_hook, nesterov)
