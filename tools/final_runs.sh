@@ -2,7 +2,7 @@
 # The measurement batch whose outputs go to profiles/ at the end of a round (run on the GPU box through gpurun).
 # usage: bash tools/final_runs.sh <prefix>      e.g. r02
 set -u
-P=${1:-r04}
+P=${1:-r05}
 O=gpurun_out/final_$P; mkdir -p $O
 {
   for cfg in "--mesh hand --res 512 --views 72" "--mesh mouse --res 1024 --views 72" "--mesh horse --res 1024 --views 72" "--mesh monkey --res 1024 --views 72" "--mesh monkey --res 1024 --views 144"; do
@@ -12,24 +12,10 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg ::', d['ms_
   done
 } > $O/configs.txt 2>&1
 {
-  # (DRT_BENCH_NOPROF: no event pairs inside the timed region, as in a run with more than one rank)
-  for v in 72 36 18 9; do
-    DRT_BENCH_NOPROF=1 python bench.py --views $v --no-cpu-baseline --no-extras --steps 40 --warmup 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
-  done
-  for v in 36 18 9; do
-    python bench.py --views $v --graph 1 --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v whole-step hipGraph (what N > 1 runs)', d['ms_per_step'], 'ms/step', d['value'], 'M rays/s')"
-  done
-  # the RCCL path of a step with ONE rank (communicator, collective launch, its capture): DRT_DIST_FORCE
-  DRT_DIST_FORCE=1 python bench.py --views 9 --graph 1 --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views 9 whole-step hipGraph with the all-reduce issued through RCCL (one rank)', d['ms_per_step'], 'ms/step')"
-  # the one-kernel path (k_path, opt-in) at the same shares: the negative result of DESIGN.md section 6
+  bash tools/scaling_proxy.sh
+  # the one-kernel path (k_path, opt-in) at the same shares: the negative result of DESIGN_HISTORY.md A.1
   for v in 18 9; do
-    DRT_MEGA_MAX_LOG2=25 DRT_BENCH_NOPROF=1 python bench.py --views $v --no-cpu-baseline --no-extras --steps 40 --warmup 5 2>/dev/null | python -c "
+    DRT_MEGA_MAX_LOG2=25 DRT_BENCH_NOPROF=1 python bench.py --views $v --graph 0 --no-cpu-baseline --no-extras --steps 40 --warmup 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager, DRT_MEGA_MAX_LOG2=25 (k_path)', d['ms_per_step'], 'ms/step')"
   done

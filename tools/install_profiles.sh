@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the outputs of tools/final_runs.sh <P> (merged back into gpurun_out/) into profiles/ (tracked).  usage: tools/install_profiles.sh r04
 set -eu
-P=${1:-r04}; O=gpurun_out/final_$P
+P=${1:-r05}; O=gpurun_out/final_$P
 cd "$(dirname "$0")/.."
 cp $O/pmc.json profiles/pmc.json
 cp gpurun_out/$P/kernel_summary.txt profiles/${P}_kernel_summary.txt; cp gpurun_out/$P/kernel_stats.csv profiles/${P}_rocprofv3_kernel_stats.csv; cp gpurun_out/$P/traffic_raw.json profiles/${P}_traffic_raw.json
