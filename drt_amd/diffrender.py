@@ -959,7 +959,8 @@ class LazyIndex(_LazyTensor):
         return self._ss.materialise()[0]
 
     def __getitem__(self, k):
-        if isinstance(k, tuple) and len(k) == 2 and k[0] == slice(None) and type(k[1]) is int and k[1] in (0, 1) and self._ss._pair is None:
+        if (isinstance(k, tuple) and len(k) == 2 and isinstance(k[0], slice) and k[0] == slice(None) and type(k[1]) is int and k[1] in (0, 1)
+                and self._ss._pair is None):
             return LazyColumn(self._ss, k[1])
         return self.tensor()[k]
 
