@@ -68,6 +68,7 @@ int drt_create(int device, drt_scene_t** out) {
     if (const char* ev = getenv("DRT_STREAMS")) { const int v = atoi(ev); if (v >= 1 && v <= drt_scene::kMaxSub) s->n_sub = v; }
     if (const char* ev = getenv("DRT_RASTER")) s->use_raster = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_HIT_SEED")) s->hit_seed = atoi(ev) != 0;
+    if (const char* ev = getenv("DRT_SEED_TILED")) s->seed_tiled = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_GRID_CANARY")) s->grid_canary = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_FILL_OVERLAP")) s->fill_overlap = atoi(ev) != 0;
     if (const char* ev = getenv("DRT_FILL_AFTER_SHADE1")) s->fill_after_shade1 = atoi(ev) != 0;

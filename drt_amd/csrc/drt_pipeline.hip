@@ -1519,7 +1519,7 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
       unsigned long long* stats = s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr;
       if (seed2 && s->hit_seed)       // the refracted rays start from last call's exit triangle of their pixel (TraceSeed)
           k_trace<false, 0, true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats,
-                                                                        TraceSeed{p.r1.idx, seed2, s->slot_of_face});
+                                                                        TraceSeed{p.r1.idx, seed2, s->slot_of_face, tile_w > 0 && s->seed_tiled ? (unsigned)tile_w : 0u});
       else
           k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats); }
     if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));     // k_shade2 is the first kernel that writes rows of the dense outputs

@@ -195,6 +195,7 @@ struct drt_scene {
     bool fill_overlap = true;      // DRT_FILL_OVERLAP=0: the dense-output memsets of a DRT_GRID_TRUST call stay in front of the projection pass
     bool grid_canary = true;       // DRT_GRID_CANARY=0: a trusted image is re-checked on its fixed 8x8 lattice only (k_check_views)
     unsigned canary_salt = 0;      // changes with every trusted projection pass
+    bool seed_tiled = true;        // DRT_SEED_TILED=0: the seed buffer of a whole-image call is indexed by ray number instead of by 4x4-pixel tile
     bool hit_seed = true;          // DRT_HIT_SEED=0: drt_render_seed's seeds are ignored (A/B measurement)
     bool use_raster = true;        // DRT_RASTER=0: every primary ray takes the BVH path (A/B measurement)
     bool built = false;

@@ -67,7 +67,15 @@ struct TraceSeed {
     const int32_t* list_idx;        // list slot -> camera-ray index within the sub-batch (RayList::idx)
     int32_t* store;                 // [rays of the sub-batch] face id per camera ray, read at refill, written at emit
     const int32_t* slot_of_face;    // [n_tris] face id -> slot of its record in TraceCtx::tris (k_refit)
+    unsigned tile_w;                // > 0: the sub-batch is whole images `tile_w` wide and `store` is laid out in 4 x 4-pixel tiles like the key
+                                    // buffer (drt_raster.h raster_slot): the 16 x 4-pixel run of rays a wave picks up from a list in tile order then
+                                    // reads and writes four adjacent 64-byte tiles instead of four pieces of four image rows (a quarter of the lines)
 };
+__device__ __forceinline__ int64_t seed_index(const TraceSeed& sd, int32_t ray) {
+    if (sd.tile_w == 0) return ray;
+    const unsigned y = (unsigned)ray / sd.tile_w, x = (unsigned)ray - y * sd.tile_w;
+    return raster_slot(x, y, sd.tile_w);
+}
 
 template <int MODE>
 __device__ __forceinline__ const float* trace_ray(const float* __restrict__ rays, const TraceOut& out, unsigned slot) {
@@ -91,7 +99,7 @@ __device__ __forceinline__ void trace_redo_push(int32_t* redo_list, unsigned* re
 template <bool ANY, int MODE, bool SEED = false>
 __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float* __restrict__ rays, const unsigned* __restrict__ n_ptr,
                                                        TraceOut out, int32_t* __restrict__ redo_list, unsigned* redo_count, unsigned* done_count,
-                                                       int refill_min, int inner_min, unsigned long long* stats, TraceSeed sd = TraceSeed{nullptr, nullptr, nullptr}) {
+                                                       int refill_min, int inner_min, unsigned long long* stats, TraceSeed sd = TraceSeed{nullptr, nullptr, nullptr, 0u}) {
     static_assert(!SEED || (!ANY && MODE == 0), "seeds: closest hit over a pipeline list");
     __shared__ int32_t lds[kStackFast + 1 + kGuardRows][kPathBlock];     // 20 x 1 KB x 8 blocks = the CU's 160 KB; the top FOUR rows are FastStack's spare entries
     FastStack st;
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         if ((refill || idle == ~0ull) && fin) {
             if (trav_winner_ok(c.tris, s)) {
                 trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
-                if (SEED && s.best_face >= 0) sd.store[sd.list_idx[slot]] = s.best_face;
+                if (SEED && s.best_face >= 0) sd.store[seed_index(sd, sd.list_idx[slot])] = s.best_face;
             } else {
                 trace_redo_push(redo_list, redo_count, slot);
             }
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                     float seed_t = INFINITY;
                     int32_t seed_face = -1, seed_slot = -1;
                     if (SEED) {
-                        const int32_t f = sd.store[sd.list_idx[k]];
+                        const int32_t f = sd.store[seed_index(sd, sd.list_idx[k])];
                         if ((uint32_t)f < (uint32_t)c.n_tris) trav_seed(c.tris, ro, rd, sd.slot_of_face[f], seed_t, seed_face, seed_slot);
                     }
                     trav_init(s, st, ro, rd);

@@ -113,7 +113,12 @@ _GRID_BYTES = 104      # DRT_GRID_CACHE_BYTES of include/drt_hip.h
 # int32 [N] buffer with the face each pixel's refracted ray left the object through in the previous call on it; the traversal of the
 # refracted rays starts from that triangle's distance.  Bit-identical results with any buffer content; 4 B per ray next to the 96 B of the
 # ray itself.  Created outside graph captures only (a captured fill would reset the seeds at every replay).
-HIT_SEED = os.environ.get("DRT_HIT_SEED", "1") != "0"
+# OFF by default (round 5, measured on MI355X, 72 x 1024^2): right seeds take 5 % of the node visits and 6 % of the vector instructions off
+# the traversal of the refracted rays (0.394 -> 0.368 ms per launch with the GPU to itself) -- and nothing off the step (1.80 vs 1.82 ms,
+# 7.08 vs 7.10 with the object filling the image), while the launch moves 55 % more HBM bytes (a 4-byte gather and scatter per ray into a
+# 300 MB array).  A refracted ray starts ON the surface: its visits are the boxes around its origin and along the chord to the exit point,
+# which no distance bound removes.  DRT_HIT_SEED=1 / HIT_SEED = True turns them on (tests/test_gpu_seed.py runs with them on).
+HIT_SEED = os.environ.get("DRT_HIT_SEED", "0") != "0"
 GRID_CANARY = os.environ.get("DRT_GRID_CANARY", "1") != "0"      # (read by the library itself at scene creation; here for cache_report)
 
 

@@ -195,7 +195,9 @@ int drt_outputs_cancel(drt_scene_t* s);
  * second hit keep their value).  Results are identical bit for bit with any buffer content (drt_amd/csrc/drt_trace_kernel.h TraceSeed):
  * the optimisation loop moves vertices by at most lr x clamp per step (reference optim.py:155-171), so last step's face is nearly always
  * this step's -- what the seed buys is node visits.  The reference has no counterpart (OptiX Prime keeps no state between queries).
- * The buffer must stay valid until the call it is consumed by has finished on its stream.  DRT_HIT_SEED=0 disables. */
+ * The buffer must stay valid until the call it is consumed by has finished on its stream.  DRT_HIT_SEED=0 disables.  The ORDER of the
+ * entries is the library's business (ray number, or 4 x 4-pixel tiles of the image for whole-image calls: fewer cache lines per wave); a
+ * caller only ever initialises the buffer (-1) and hands it back. */
 int drt_render_seed(drt_scene_t* s, int32_t* d_seed_face2, int64_t n_rays);
 /* ray_loss (reference optim.py:91-108) AND its vertex gradient in one pass over the forward's list of completed paths
  * (drt_render_forward's d_valid_idx / d_n_valid, face ids from the same call): *d_loss += the loss (float64 scalar, zero it first)

@@ -75,6 +75,11 @@ def test_seeded_calls_equal_unseeded_ones_over_moving_vertices(setup):
     f2 = got[-1][4]
     hit = got[-1][2][:, 0]
     assert int(hit.sum()) > 500
+    # (whole images: the buffer is laid out in 4 x 4-pixel tiles, like the key buffer of the projection pass -- drt_raster.h raster_slot)
+    i = torch.arange(len(seed), device="cuda")
+    y, x = i // RES, i % RES
+    slot = ((((y >> 2) * (RES >> 2) + (x >> 2)) << 4) | ((y & 3) << 2) | (x & 3))
+    seed = seed[slot]
     assert torch.equal(seed[hit], f2[hit])
     assert int((seed >= 0).sum()) >= int(hit.sum())            # (refracted rays that hit but whose path died later are seeded too)
 
