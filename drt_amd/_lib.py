@@ -65,7 +65,6 @@ SIGNATURES = {
     "drt_closest_point": (_c.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "drt_vh_loss_fused": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "drt_remesh_isotropic": (_c.c_int, [_P, _I64, _P, _I64, _D, _c.c_int, _D, _c.c_uint, _c.POINTER(_P)]),
-    "drt_rm_csr": (_c.c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
     "drt_rm_split_faces": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "drt_rm_vertex_normals": (_c.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
     "drt_rm_collapse_eval": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _D, _D, _c.c_int, _P, _P, _P, _P]),

@@ -353,69 +353,9 @@ __global__ void k_rm_revert(double* __restrict__ V, const double* __restrict__ o
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
-// ---- vertex -> incident faces (CSR) without a sort: count, scan, fill, then every vertex orders its own few entries ------------------
-// (the driver built these lists with a stable argsort + searchsorted of torch: ~20 launches per call, ~35 calls per remesh; the result
-// here is the same arrays -- ascending face ids inside a vertex -- in six)
-__global__ void k_rm_csr_count(const int64_t* __restrict__ F, int64_t n_corners, unsigned long long* __restrict__ start1 /* = vf_start + 1 */) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c < n_corners) atomicAdd(&start1[F[c]], 1ull);
-}
-// inclusive scan of a[0..n) in place by ONE block of 1024 threads (n ~ 1e5: a chunk per thread, a block scan of the chunk sums)
-__global__ void __launch_bounds__(1024) k_rm_scan(unsigned long long* __restrict__ a, int64_t n) {
-    __shared__ unsigned long long part[1024];
-    const int64_t chunk = (n + 1023) / 1024, lo = threadIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    unsigned long long sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += a[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0ull;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned long long run = threadIdx.x ? part[threadIdx.x - 1] : 0ull;
-    for (int64_t i = lo; i < hi; ++i) { run += a[i]; a[i] = run; }
-}
-__global__ void k_rm_csr_fill(const int64_t* __restrict__ F, int64_t n_corners, const int64_t* __restrict__ vf_start, unsigned* __restrict__ cursor,
-                              int64_t* __restrict__ vf_face) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= n_corners) return;
-    const int64_t v = F[c];
-    vf_face[vf_start[v] + atomicAdd(&cursor[v], 1u)] = c / 3;
-}
-__global__ void k_rm_csr_order(const int64_t* __restrict__ vf_start, int64_t n_verts, int64_t* __restrict__ vf_face) {
-    const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (v >= n_verts) return;
-    const int64_t lo = vf_start[v], hi = vf_start[v + 1];
-    for (int64_t i = lo + 1; i < hi; ++i) {            // insertion sort: a handful of entries (the valence)
-        const int64_t x = vf_face[i];
-        int64_t j = i;
-        while (j > lo && vf_face[j - 1] > x) { vf_face[j] = vf_face[j - 1]; --j; }
-        vf_face[j] = x;
-    }
-}
-
 }  // namespace
 
 extern "C" {
-
-int drt_rm_csr(const int64_t* d_faces, int64_t n_faces, int64_t n_verts, int64_t* d_vf_start, int64_t* d_vf_face, uint32_t* d_cursor, void* stream) {
-    if (n_faces < 0 || n_verts < 0) return fail(DRT_E_INVALID, "negative size");
-    if (!d_vf_start || (n_verts > 0 && !d_cursor)) return fail(DRT_E_INVALID, "null pointer argument");
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(d_vf_start, 0, sizeof(int64_t) * (n_verts + 1), st));
-    if (n_faces == 0 || n_verts == 0) return DRT_OK;
-    if (!d_faces || !d_vf_face) return fail(DRT_E_INVALID, "null pointer argument");
-    HIP_TRY(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * n_verts, st));
-    unsigned long long* start = reinterpret_cast<unsigned long long*>(d_vf_start);
-    k_rm_csr_count<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, start + 1);
-    k_rm_scan<<<1, 1024, 0, st>>>(start + 1, n_verts);
-    k_rm_csr_fill<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, d_vf_start, d_cursor, d_vf_face);
-    k_rm_csr_order<<<blocks_for(n_verts), 256, 0, st>>>(d_vf_start, n_verts, d_vf_face);
-    HIP_TRY(hipGetLastError());
-    return DRT_OK;
-}
 
 int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int32_t* d_row2edge, const int64_t* d_mid_of_edge, const double* d_verts,
                        int64_t* d_count, const int64_t* d_offset, int64_t* d_faces_out, void* stream) {

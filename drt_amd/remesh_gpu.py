@@ -40,7 +40,6 @@ SUB_ROUNDS = int(__import__("os").environ.get("DRT_REMESH_SUB_ROUNDS", 3))     #
                            # serves several independent sets: candidates whose neighbourhood an earlier pair of the round touched sit out until the next evaluation)
 TAIL_CUT = int(__import__("os").environ.get("DRT_REMESH_TAIL_CUT", 32))       # a step ends when a round applies less than 1 / TAIL_CUT of what its first round applied
 DEBUG = False
-CSR_KERNEL = __import__("os").environ.get("DRT_REMESH_CSR_KERNEL", "1") != "0"      # vertex -> face lists by drt_rm_csr instead of torch's sort
 
 
 def _check(rc):
@@ -67,14 +66,6 @@ class _Work:
 
     def csr(self):
         """vertex -> incident faces: vf_start int64 [V+1], vf_face int64 [3F] (ascending face order inside a vertex)."""
-        nv, nf = self.V.shape[0], self.F.shape[0]
-        if CSR_KERNEL:
-            # count / scan / fill / per-vertex ordering in the library (six launches; the stable argsort + searchsorted below were ~20)
-            vf_start = torch.empty(nv + 1, dtype=torch.long, device=self.dev)
-            vf_face = torch.empty(3 * nf, dtype=torch.long, device=self.dev)
-            cursor = torch.empty(nv, dtype=torch.int32, device=self.dev)
-            _check(_lib.lib().drt_rm_csr(self.F.data_ptr(), nf, nv, vf_start.data_ptr(), vf_face.data_ptr(), cursor.data_ptr(), _stream()))
-            return vf_start, vf_face
         flat = self.F.reshape(-1)
         order = torch.argsort(flat, stable=True)
         vf_face = (order // 3).contiguous()

@@ -339,10 +339,6 @@ int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double*
  *   drt_rm_face_agreement   cosine between each face normal and the consensus of its corners, float64 [F] (before a move).
  *   drt_rm_move_check       after vertices moved: every face that degenerated or folded (against d_a0) takes its three vertices back from
  *                           d_old; *d_n_bad = their number (the caller repeats, four rounds at most). */
-/*   drt_rm_csr              d_vf_start int64 [V+1] / d_vf_face int64 [3F] of the current faces (face indices must lie in [0, V); vertices
- *                           no face uses get an empty run); d_cursor: uint32 [V] workspace.  Same arrays as a stable sort of the corners by
- *                           vertex gives, in six launches instead of twenty. */
-int drt_rm_csr(const int64_t* d_faces, int64_t n_faces, int64_t n_verts, int64_t* d_vf_start, int64_t* d_vf_face, uint32_t* d_cursor, void* stream);
 int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int32_t* d_row2edge, const int64_t* d_mid_of_edge, const double* d_verts,
                        int64_t* d_count, const int64_t* d_offset, int64_t* d_faces_out, void* stream);
 int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,

@@ -208,26 +208,3 @@ def test_device_remesh_on_random_shapes(seed):
         assert abs(len(dev.faces) / len(host.faces) - 1) < 0.08, (len(dev.faces), len(host.faces))
         # (chords cut corners: an 80-face shape coarsened loses 15 % of its volume -- in both versions alike)
         assert abs(_volume(dev) / _volume(mesh) - 1) < 0.25 and abs(_volume(dev) / _volume(host) - 1) < 0.03, (_volume(dev) / _volume(mesh), _volume(host) / _volume(mesh))
-
-
-def test_csr_kernel_equals_the_stable_sort(hand):
-    """drt_rm_csr (count / scan / fill / per-vertex ordering) gives exactly the arrays the stable argsort + searchsorted gave, also with
-    vertices no face uses (what a collapse round leaves behind before the call's final compaction)."""
-    from drt_amd import remesh_gpu as RG
-    big = mesh_io.subdivide_midpoint(hand)
-    F = torch.tensor(big.faces, device="cuda")
-    keep = torch.ones(len(F), dtype=torch.bool, device="cuda")
-    keep[::5] = False                                           # drop a fifth of the faces: open mesh, some vertices lose faces
-    keep[:4000] = False                                         # ... and a block of them: vertices without any face
-    F = F[keep].contiguous()
-    V = torch.tensor(big.vertices, device="cuda")
-    old = RG.CSR_KERNEL
-    try:
-        RG.CSR_KERNEL = False
-        s0, f0 = RG._Work(V, F, None, float("inf")).csr()
-        RG.CSR_KERNEL = True
-        s1, f1 = RG._Work(V, F, None, float("inf")).csr()
-    finally:
-        RG.CSR_KERNEL = old
-    assert int((s0[1:] == s0[:-1]).sum()) > 0                 # empty runs exist
-    assert torch.equal(s0, s1) and torch.equal(f0, f1)
