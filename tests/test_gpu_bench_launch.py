@@ -78,5 +78,5 @@ def test_bench_as_a_whole_step_graph_recycles_its_outputs():
     # (the two runs take a different number of untimed steps -- the capture needs eager warm-up steps and one replay of its own -- so their
     # final losses are those of neighbouring iterations; that replays equal eager steps is tests/test_gpu_dist.py's business)
     a, b = eager["config"]["final_loss"], graph["config"]["final_loss"]
-    assert a > 0 and b > 0 and abs(a - b) <= 0.05 * a, (a, b)
+    assert 0 < b < a, (a, b)          # (more steps taken: further down the same descent)
     assert graph["repeats"]["n"] == 2 and len(graph["repeats"]["ms_per_step"]) == 2
