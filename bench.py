@@ -389,9 +389,19 @@ def main():
                          "-1 (default): graph when N > 1 AND the rank's share is below 24 views x 1024^2 camera rays (a chain of small launches: "
                          "9 views 0.655 vs 0.691 ms eager, 18 views 0.792 vs 0.819; above, the eager step is the faster one: 36 views 1.177 vs 1.204) "
                          "-- eager otherwise; falls back to eager if the capture fails")
-    ap.add_argument("--repeats", type=int, default=5,
-                    help="the timed region (exactly --steps steps between two barrier + synchronize pairs) is run this many times back to back; "
-                         "`value` / `ms_per_step` are those of the MEDIAN repeat, all of them are listed under `repeats`")
+    ap.add_argument("--repeats", type=int, default=int(os.environ.get("DRT_BENCH_REPEATS", "0")),
+                    help="the timed region (exactly --steps steps between two barrier + synchronize pairs) is run this many times back to back. "
+                         "0 (default): SUSTAINED mode -- at least 5 repeats and as many as it takes for --min-seconds of timed steps; `value` / "
+                         "`ms_per_step` are then those of the median repeat among the ones that STARTED after the first --settle-seconds of timed "
+                         "steps (the chip's clocks settle over the first few hundred milliseconds of sustained load), the first repeat's figure "
+                         "is reported beside it.  R > 0: exactly R repeats, the median of all of them")
+    ap.add_argument("--min-seconds", type=float, default=float(os.environ.get("DRT_BENCH_MIN_SECONDS", "3.0")),
+                    help="sustained mode: total length of the timed regions (s)")
+    ap.add_argument("--settle-seconds", type=float, default=1.0, help="sustained mode: repeats that start before this much timed time has passed do not count for `value`")
+    ap.add_argument("--reset-every", type=int, default=200,
+                    help="between two repeats (outside the timed regions) the parameter and the momentum buffer are put back to their initial state once this many "
+                         "steps were taken since the last reset, so that a long sustained run stays within the first iterations of a pass "
+                         "(BASELINE.json: 200 iterations per pass) instead of timing whatever mesh 2 000 steps of descent on synthetic targets produce; 0 = never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras after the timed region (fused-mode comparison, traversal statistics); "
@@ -530,7 +540,21 @@ def main():
     # observer's utilisation samples to see the GPU busy), every repeat is listed.
     repeats = []
     ms0 = torch.cuda.memory_stats(dev)
-    for rep in range(max(1, args.repeats)):
+    sustained = args.repeats <= 0
+    timed_total, since_reset, n_resets = 0.0, max(args.warmup, 3), 0
+    starts = []                                      # timed seconds in front of each repeat
+    while True:
+        rep = len(repeats)
+        if (not sustained and rep >= args.repeats) or (sustained and rep >= 5 and timed_total >= args.min_seconds) or rep >= 2000:
+            break
+        if args.reset_every > 0 and since_reset + args.steps > args.reset_every and rep > 0:
+            # (untimed, between two regions; in place, so that a captured graph sees it too: momentum buffer 0 = a first step)
+            with torch.no_grad():
+                parameter.zero_()
+                if getattr(opt, "buf", None) is not None:
+                    opt.buf.zero_()
+            since_reset, n_resets = 0, n_resets + 1
+        since_reset += args.steps
         if live_profile:
             scene.optix_mesh.profile_read()          # (drops the event pairs of the previous repeat: the stage rows are the last repeat's)
         ddist.barrier()
@@ -547,9 +571,12 @@ def main():
         ddist.barrier()
         torch.cuda.synchronize()
         repeats.append((ddist.allreduce_max_float(time.perf_counter() - t0, dev), [1e3 * (b - a) for a, b in zip([t0] + host_marks[:-1], host_marks)]))
+        starts.append(timed_total)
+        timed_total += repeats[-1][0]                # (the max over ranks: every rank takes the same number of repeats)
     ms1 = torch.cuda.memory_stats(dev)
-    order = sorted(range(len(repeats)), key=lambda k: repeats[k][0])
-    elapsed, host_ms = repeats[order[(len(order) - 1) // 2]]      # the median repeat (the lower one of an even count)
+    counted = [k for k in range(len(repeats)) if sustained and starts[k] >= args.settle_seconds] or list(range(len(repeats)))
+    order = sorted(counted, key=lambda k: repeats[k][0])
+    elapsed, host_ms = repeats[order[(len(order) - 1) // 2]]      # the median repeat (the lower one of an even count) among the counted ones
     # the host's own pace (enqueue only): a step whose enqueue takes as long as the step itself means the host, not the GPU, set the time
     # device-level allocator traffic inside the timed region (a hipMalloc / hipFree there would be a host-side stall of milliseconds)
     alloc_stats = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
@@ -562,9 +589,15 @@ def main():
         "metric": "M camera-rays/s (forward+backward) on 50k-tri mesh, 72 views",
         "value": round(value, 3), "unit": "M camera-rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
-        "repeats": {"n": len(repeats), "reported": "median", "ms_per_step": [round(1e3 * t / args.steps, 3) for t, _ in repeats],
-                    "min": round(1e3 * min(t for t, _ in repeats) / args.steps, 3), "median": round(1e3 * elapsed / args.steps, 3),
-                    "max": round(1e3 * max(t for t, _ in repeats) / args.steps, 3), "timed_region_ms_total": round(1e3 * sum(t for t, _ in repeats), 1)},
+        "repeats": {"n": len(repeats), "reported": f"median of the {len(counted)} repeats that started after {args.settle_seconds} s of timed steps" if sustained and len(counted) < len(repeats) else "median",
+                    "ms_per_step": [round(1e3 * t / args.steps, 3) for t, _ in repeats],
+                    "min": round(1e3 * min(repeats[k][0] for k in counted) / args.steps, 3), "median": round(1e3 * elapsed / args.steps, 3),
+                    "max": round(1e3 * max(repeats[k][0] for k in counted) / args.steps, 3), "timed_region_ms_total": round(1e3 * sum(t for t, _ in repeats), 1),
+                    "first_repeat": round(1e3 * repeats[0][0] / args.steps, 3), "sustained": sustained, "n_counted": len(counted),
+                    # the plateau, visibly: median ms/step of the repeats that started within each successive half second of timed steps
+                    "by_half_second": [round(1e3 * sorted(repeats[k][0] for k in ks)[(len(ks) - 1) // 2] / args.steps, 3)
+                                       for ks in ([k for k in range(len(repeats)) if int(starts[k] / 0.5) == b] for b in range(int(timed_total / 0.5) + 1)) if ks],
+                    "parameter_resets": n_resets, "reset_every_steps": args.reset_every},
         "vs_baseline": None, "dtype": "f32 traversal + f64 shading/gradients", "data": "synthetic",
         "config": {"workload": f"{mesh_src} = {n_faces} tris / {n_verts} verts, {args.views} turntable views, "
                                f"{res}x{res} rays/view, LBVH rebuilt every step, forward+ray_loss+backward+all-reduce+SGD"

@@ -21,6 +21,8 @@ _D = _c.c_double
 SIGNATURES = {
     "drt_last_error": (_c.c_char_p, []),
     "drt_version": (_c.c_int, []),
+    "drt_deterministic": (_c.c_int, [_c.c_int]),
+    "drt_fx_finalize": (_c.c_int, [_P, _I64, _P, _c.c_int, _P]),
     "drt_create": (_c.c_int, [_c.c_int, _c.POINTER(_P)]),
     "drt_destroy": (None, [_P]),
     "drt_update_mesh": (_c.c_int, [_P, _P, _I64, _P, _I64, _P]),

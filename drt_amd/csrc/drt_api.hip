@@ -28,10 +28,39 @@ int ensure_slow_stack(drt_scene* s, hipStream_t st) {
     return DRT_OK;
 }
 
+// drt_deterministic: -1 = not decided yet (DRT_DETERMINISTIC read on first use)
+static int g_det = -1;
+bool det_mode() {
+    if (g_det < 0) { const char* ev = getenv("DRT_DETERMINISTIC"); g_det = ev && atoi(ev) != 0 ? 1 : 0; }
+    return g_det != 0;
+}
+// cells -> float64, correctly rounded (drt_fixed.h)
+__global__ void __launch_bounds__(256) k_fx_finalize(const FxCell* __restrict__ cells, int64_t n, double* __restrict__ out, int accumulate) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const FxCell c = cells[i];
+        const double v = fx_to_double(Fx128{c.hi, c.lo}, (uint32_t)c.flags);
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
 extern "C" {
 
 const char* drt_last_error(void) { return g_err; }
-int drt_version(void) { return 1; }
+int drt_version(void) { return 2; }
+
+int drt_deterministic(int on) {
+    const int was = det_mode() ? 1 : 0;
+    if (on >= 0) g_det = on != 0;
+    return was;
+}
+int drt_fx_finalize(const void* d_cells, int64_t n, double* d_out, int accumulate, void* stream) {
+    if (n < 0) return fail(DRT_E_INVALID, "negative size");
+    if (n == 0) return DRT_OK;
+    if (!d_cells || !d_out) return fail(DRT_E_INVALID, "null pointer argument");
+    k_fx_finalize<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(static_cast<const FxCell*>(d_cells), n, d_out, accumulate);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
 
 int drt_create(int device, drt_scene_t** out) {
     if (!out) return fail(DRT_E_INVALID, "out is null");

@@ -74,3 +74,38 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+
+// ---- the two accumulation modes of every gradient / loss target (drt_fixed.h; include/drt_hip.h drt_deterministic) --------------------
+// DET = false: float64 atomics into double[] (order-dependent at 1e-16 relative).  DET = true: the SAME pointer is an array of FxCell
+// -- one 24-byte cell per float64 element, same element numbers -- and contributions are added as 128-bit integers: any order, same bits.
+template <bool DET>
+struct GradAdd3 {
+    double* g;
+    __device__ __forceinline__ void operator()(int32_t v, d3 a) const {
+        if (DET) {
+            FxCell* c = reinterpret_cast<FxCell*>(g) + 3 * (int64_t)v;
+            fx_atomic_add(c, a.x); fx_atomic_add(c + 1, a.y); fx_atomic_add(c + 2, a.z);
+        } else {
+            AtomicAdd3{g}(v, a);
+        }
+    }
+};
+// A thread's share of a kernel's scalar loss: summed per thread, then per wave, one atomic per wave.  The fixed-point form is exact at every
+// level, so it does not matter which items a thread, or which threads a wave, happened to get (the path lists are SETS: their order varies).
+template <bool DET> struct LossAcc;
+template <> struct LossAcc<false> {
+    double v = 0.0;
+    __device__ __forceinline__ void add(double x) { v += x; }
+    __device__ __forceinline__ void flush(double* loss) {
+        v = wave_sum(v);
+        if ((threadIdx.x & 63) == 0 && v != 0.0) unsafeAtomicAdd(loss, v);
+    }
+};
+template <> struct LossAcc<true> {
+    FxAcc a;
+    __device__ __forceinline__ void add(double x) { a.add(x); }
+    __device__ __forceinline__ void flush(double* loss) {
+        a = fx_wave_sum(a);
+        if ((threadIdx.x & 63) == 0) fx_atomic_add(reinterpret_cast<FxCell*>(loss), a.v, a.flags);
+    }
+};

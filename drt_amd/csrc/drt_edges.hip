@@ -20,11 +20,11 @@ __global__ void __launch_bounds__(256) k_dihedral_fwd(const double* __restrict__
 
 // MODE 0: adjoint of k_dihedral_fwd for a given d loss / d cos.
 // MODE 1: sm_loss = sum -log(1 + cos) (reference optim.py:82-89) and its vertex gradient in one pass.
-template <int MODE>
+template <bool DET, int MODE>
 __global__ void __launch_bounds__(256) k_dihedral_bwd(const double* __restrict__ verts, const int64_t* __restrict__ e2f, int64_t n,
                                                       const double* __restrict__ g_cos, double* loss, double* grad_verts) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    double term = 0.0;
+    LossAcc<DET> term;
     if (e < n) {
         d3 v0, v1, v2;
         FaceNormal a, b;
@@ -37,22 +37,19 @@ __global__ void __launch_bounds__(256) k_dihedral_bwd(const double* __restrict__
             g = g_cos[e];
         } else {
             const double c = dot(a.n, b.n);
-            term = -log(1.0 + c);
+            term.add(-log(1.0 + c));
             g = -1.0 / (1.0 + c);
         }
         const d3 z{0.0, 0.0, 0.0};
         d3 g0 = z, g1 = z, g2 = z;
-        const AtomicAdd3 add{grad_verts};
+        const GradAdd3<DET> add{grad_verts};
         face_normal_backward(a, g * b.n, g0, g1, g2);
         add((int32_t)fa[0], g0); add((int32_t)fa[1], g1); add((int32_t)fa[2], g2);
         g0 = z; g1 = z; g2 = z;
         face_normal_backward(b, g * a.n, g0, g1, g2);
         add((int32_t)fb[0], g0); add((int32_t)fb[1], g1); add((int32_t)fb[2], g2);
     }
-    if (MODE == 1) {
-        term = wave_sum(term);
-        if ((threadIdx.x & 63) == 0 && term != 0.0) unsafeAtomicAdd(loss, term);
-    }
+    if (MODE == 1) term.flush(loss);
 }
 
 // silhouette test per unique edge (reference DiffRender.py:445-457)
@@ -109,6 +106,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_edge_sample_fwd(TraceCtx c, con
 
 // Adjoint: dE_pos[e, endpoint, :] = -N_e * f_e * coef_e for both endpoints (reference
 // DiffRender.py:236-242, 263-267), chained through the projection to the two vertices.
+template <bool DET>
 __global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restrict__ verts, const int64_t* __restrict__ edges, int64_t n,
                                                          const Camera* __restrict__ cam, const float* __restrict__ f,
                                                          const double* __restrict__ coef, int detach_depth, double* grad_verts,
@@ -123,7 +121,7 @@ __global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restric
     project_endpoint(cm, load_d3(verts, ia), pa);
     project_endpoint(cm, load_d3(verts, ib), pb);
     const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
-    const AtomicAdd3 add{grad_verts};
+    const GradAdd3<DET> add{grad_verts};
     add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
     add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
 }
@@ -132,21 +130,21 @@ __global__ void __launch_bounds__(256) k_edge_sample_bwd(const double* __restric
 // sum over kept rows of |soft[y, x] - 0.5| (reference optim.py:78 with `output` = 0.5) and, per row, d term / d output = -sign(soft - 0.5)
 // (0 for dropped rows) -- what the drop-in pair's LAZY return values evaluate when the caller writes the reference's expression
 // (drt_amd/diffrender.py SampleSet): no compaction, no host round trip.
+template <bool DET>
 __global__ void __launch_bounds__(256) k_vh_term(const int64_t* __restrict__ index, const uint8_t* __restrict__ keep, int64_t n,
                                                  const double* __restrict__ soft, int resx, double* loss, double* __restrict__ dterm) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    double t = 0.0;
+    LossAcc<DET> t;
     if (e < n) {
         double dsign = 0.0;
         if (keep[e]) {
             const double m = soft[index[2 * e + 1] * resx + index[2 * e]] - 0.5;
-            t = fabs(m);
+            t.add(fabs(m));
             dsign = m > 0.0 ? -1.0 : (m < 0.0 ? 1.0 : 0.0);
         }
         dterm[e] = dsign;
     }
-    t = wave_sum(t);
-    if ((threadIdx.x & 63) == 0 && t != 0.0) unsafeAtomicAdd(loss, t);
+    t.flush(loss);
 }
 
 // ---- fused silhouette loss: Loss_calculator.vh_loss (reference optim.py:73-78) with no host round trip:
@@ -183,13 +181,14 @@ __global__ void __launch_bounds__(kPathBlock) k_vh_cull(const double* __restrict
     }
 }
 
+template <bool DET>
 __global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const double* __restrict__ verts, const int64_t* __restrict__ edges,
                                                            uint32_t n_edges, const uint32_t* __restrict__ list, const unsigned* __restrict__ count,
                                                            VhViews vw, int resx, int resy, int detach_depth, double* loss, double* grad_verts) {
     __shared__ int32_t lds[kStackFast][kTraceBlock];
     Stack st = make_stack(lds, c);
     const unsigned n = *count;
-    double acc = 0.0;
+    LossAcc<DET> acc;
     // Two lanes per edge, one probe ray each: the rays graze the silhouette and take a few hundred node visits, and with
     // only a few thousand edges per view the kernel lasts as long as its longest lane -- tracing the two probes of an
     // edge one after the other in one lane doubled that.
@@ -217,17 +216,16 @@ __global__ void __launch_bounds__(kTraceBlock) k_vh_fused(TraceCtx c, const doub
         const int64_t x = (int64_t)s.midx, y = (int64_t)s.midy;   // trunc, like Tensor.to(torch.long)
         if (!(x < resx - 1 && y < resy - 1 && x >= 0 && y >= 0)) continue;   // out of view (DiffRender.py:478)
         const double m = vw.soft[view][y * resx + x] - 0.5;       // output is float32 0.5: exact
-        acc += fabs(m);
+        acc.add(fabs(m));
         const double coef = m > 0.0 ? -1.0 : (m < 0.0 ? 1.0 : 0.0);   // d |mask - output| / d output
         const double w = f * coef;
         if (w == 0.0) continue;
         const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
-        const AtomicAdd3 add{grad_verts};
+        const GradAdd3<DET> add{grad_verts};
         add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
         add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+    acc.flush(loss);
 }
 
 // limit_hook + one SGD(nesterov) step (reference optim.py:155-171, 215) in one pass over the [V,3] parameter: the gradient is
@@ -266,6 +264,28 @@ __global__ void __launch_bounds__(256) k_limit_sgd(double* __restrict__ param, d
     }
 }
 
+// The same for the KEPT rows only: rows[k] = edge row of the k-th kept sample, g[k] = d loss / d output of that sample in the float32 of
+// `output` -- what the caller has after its one boolean index; spares it a zero-filled float64 [Es] coefficient vector, a cast and a scatter.
+template <bool DET>
+__global__ void __launch_bounds__(256) k_edge_sample_bwd_rows(const double* __restrict__ verts, const int64_t* __restrict__ edges, const Camera* __restrict__ cam,
+                                                              const float* __restrict__ f, const int64_t* __restrict__ rows, int64_t n_rows,
+                                                              const float* __restrict__ g, int detach_depth, double* grad_verts) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n_rows) return;
+    const int64_t e = rows[k];
+    const double w = (double)f[e] * (double)g[k];
+    if (w == 0.0) return;
+    const Camera cm = *cam;
+    const int64_t ia = edges[2 * e], ib = edges[2 * e + 1];
+    Projected pa, pb;
+    project_endpoint(cm, load_d3(verts, ia), pa);
+    project_endpoint(cm, load_d3(verts, ib), pb);
+    const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
+    const GradAdd3<DET> add{grad_verts};
+    add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
+    add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
+}
+
 extern "C" {
 
 int drt_dihedral_forward(const double* d_verts, const int64_t* d_e2f, int64_t n_edges, double* d_cos, void* stream) {
@@ -282,7 +302,8 @@ int drt_dihedral_backward(const double* d_verts, const int64_t* d_e2f, int64_t n
     if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
     if (n_edges == 0) return DRT_OK;
     if (!d_verts || !d_e2f || !d_grad_cos || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
-    k_dihedral_bwd<0><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, d_grad_cos, nullptr, d_grad_verts);
+    if (det_mode()) k_dihedral_bwd<true, 0><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, d_grad_cos, nullptr, d_grad_verts);
+    else k_dihedral_bwd<false, 0><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, d_grad_cos, nullptr, d_grad_verts);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -291,7 +312,8 @@ int drt_sm_loss_fused(const double* d_verts, const int64_t* d_e2f, int64_t n_edg
     if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
     if (n_edges == 0) return DRT_OK;
     if (!d_verts || !d_e2f || !d_loss || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
-    k_dihedral_bwd<1><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, nullptr, d_loss, d_grad_verts);
+    if (det_mode()) k_dihedral_bwd<true, 1><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, nullptr, d_loss, d_grad_verts);
+    else k_dihedral_bwd<false, 1><<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_verts, d_e2f, n_edges, nullptr, d_loss, d_grad_verts);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -319,34 +341,12 @@ int drt_edge_sample_forward(drt_scene_t* s, const double* d_verts, const int64_t
     return DRT_OK;
 }
 
-// The same for the KEPT rows only: rows[k] = edge row of the k-th kept sample, g[k] = d loss / d output of that sample in the float32 of
-// `output` -- what the caller has after its one boolean index; spares it a zero-filled float64 [Es] coefficient vector, a cast and a scatter.
-__global__ void __launch_bounds__(256) k_edge_sample_bwd_rows(const double* __restrict__ verts, const int64_t* __restrict__ edges, const Camera* __restrict__ cam,
-                                                              const float* __restrict__ f, const int64_t* __restrict__ rows, int64_t n_rows,
-                                                              const float* __restrict__ g, int detach_depth, double* grad_verts) {
-    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (k >= n_rows) return;
-    const int64_t e = rows[k];
-    const double w = (double)f[e] * (double)g[k];
-    if (w == 0.0) return;
-    const Camera cm = *cam;
-    const int64_t ia = edges[2 * e], ib = edges[2 * e + 1];
-    Projected pa, pb;
-    project_endpoint(cm, load_d3(verts, ia), pa);
-    project_endpoint(cm, load_d3(verts, ib), pb);
-    const double gx = -(pa.py - pb.py) * w, gy = -(pb.px - pa.px) * w;
-    const AtomicAdd3 add{grad_verts};
-    add((int32_t)ia, project_endpoint_backward(cm, pa, gx, gy, detach_depth != 0));
-    add((int32_t)ib, project_endpoint_backward(cm, pb, gx, gy, detach_depth != 0));
-}
-
 int drt_edge_sample_backward_rows(const double* d_verts, const int64_t* d_edges, int64_t n_edges, const double* d_camera, const float* d_f,
                                   const int64_t* d_rows, int64_t n_rows, const float* d_g, int detach_depth, double* d_grad_verts, void* stream) {
     if (n_edges < 0 || n_rows < 0) return fail(DRT_E_INVALID, "negative count");
     if (n_edges == 0 || n_rows == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_camera || !d_f || !d_rows || !d_g || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
-    k_edge_sample_bwd_rows<<<(unsigned)((n_rows + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        d_verts, d_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_rows, n_rows, d_g, detach_depth, d_grad_verts);
+    DET_LAUNCH(k_edge_sample_bwd_rows, (unsigned)((n_rows + 255) / 256), 256, (hipStream_t)stream, d_verts, d_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_rows, n_rows, d_g, detach_depth, d_grad_verts);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -356,8 +356,7 @@ int drt_edge_sample_backward(const double* d_verts, const int64_t* d_edges, int6
     if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
     if (n_edges == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_camera || !d_f || !d_coef || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
-    k_edge_sample_bwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_coef, detach_depth, d_grad_verts, nullptr);
+    DET_LAUNCH(k_edge_sample_bwd, (unsigned)((n_edges + 255) / 256), 256, (hipStream_t)stream, d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_coef, detach_depth, d_grad_verts, nullptr);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -367,8 +366,7 @@ int drt_edge_sample_backward_term(const double* d_verts, const int64_t* d_edges,
     if (n_edges < 0) return fail(DRT_E_INVALID, "negative edge count");
     if (n_edges == 0) return DRT_OK;
     if (!d_verts || !d_edges || !d_camera || !d_f || !d_dterm || !d_g || !d_grad_verts) return fail(DRT_E_INVALID, "null pointer argument");
-    k_edge_sample_bwd<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_dterm, detach_depth, d_grad_verts, d_g);
+    DET_LAUNCH(k_edge_sample_bwd, (unsigned)((n_edges + 255) / 256), 256, (hipStream_t)stream, d_verts, d_edges, n_edges, reinterpret_cast<const Camera*>(d_camera), d_f, d_dterm, detach_depth, d_grad_verts, d_g);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -400,7 +398,7 @@ int drt_vh_loss_fused(drt_scene_t* s, const double* d_verts, const int64_t* d_ed
         // (the silhouette flags need the vertices only; the probe rays are the first thing that needs the tree: the flags of eight views
         // are found while the asynchronous build finishes)
         { int rc = wait_build(s, st); if (rc) return rc; }
-        k_vh_fused<<<4 * s->n_cu, kTraceBlock, 0, st>>>(trace_ctx(s), d_verts, d_edges, (uint32_t)n_edges, s->vh_list, s->vcount + 1,
+        DET_LAUNCH(k_vh_fused, 4 * s->n_cu, kTraceBlock, st, trace_ctx(s), d_verts, d_edges, (uint32_t)n_edges, s->vh_list, s->vcount + 1,
                                                         vw, resx, resy, detach_depth, d_loss, d_grad_verts);
     }
     HIP_TRY(hipGetLastError());
@@ -423,7 +421,7 @@ int drt_vh_term(const int64_t* d_index, const uint8_t* d_keep, int64_t n_edges, 
     if (n_edges < 0 || resx <= 0 || resy <= 0) return fail(DRT_E_INVALID, "bad sizes");
     if (n_edges == 0) return DRT_OK;
     if (!d_index || !d_keep || !d_soft_mask || !d_loss || !d_dterm) return fail(DRT_E_INVALID, "null pointer argument");
-    k_vh_term<<<(unsigned)((n_edges + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_index, d_keep, n_edges, d_soft_mask, resx, d_loss, d_dterm);
+    DET_LAUNCH(k_vh_term, (unsigned)((n_edges + 255) / 256), 256, (hipStream_t)stream, d_index, d_keep, n_edges, d_soft_mask, resx, d_loss, d_dterm);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -957,6 +957,16 @@ __device__ __forceinline__ void hash_flush(int32_t* keys, double* sums, double* 
     __syncthreads();
 }
 
+// The vertex-gradient sink of the path kernels in the two accumulation modes (drt_device.h GradAdd3): the LDS hash in front of float64
+// atomics, or -- deterministic mode -- 128-bit fixed-point cells straight in memory (integer sums need no particular order, and no table).
+template <bool DET>
+struct PathSink {
+    HashAdd3 h;
+    __device__ __forceinline__ void operator()(int32_t v, d3 a) const {
+        if (DET) GradAdd3<true>{h.g}(v, a); else h(v, a);
+    }
+};
+
 // Backward without a saved list: compact the rays whose path completed (face2 >= 0).
 __global__ void __launch_bounds__(kPathBlock) k_collect_valid(const int32_t* __restrict__ face2, int64_t n, int64_t chunk_base,
                                                                int32_t* __restrict__ list, unsigned* counter) {
@@ -970,6 +980,7 @@ __global__ void __launch_bounds__(kPathBlock) k_collect_valid(const int32_t* __r
 
 // Backward (full waves over the list of valid rays): recompute both bounces from (face1, face2),
 // reverse them, scatter the six vertex gradients.
+template <bool DET>
 __global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                     const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
                                                     const double* __restrict__ g_out_ori, const double* __restrict__ g_out_dir,
@@ -978,9 +989,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __r
     __shared__ int32_t hkeys[kHashSize];
     __shared__ double hsums[3 * kHashSize];
     const int64_t n = n_i64 ? *n_i64 : (int64_t)*n_u32;
-    const HashAdd3 add{hkeys, hsums, grad_verts};
+    const PathSink<DET> add{HashAdd3{hkeys, hsums, grad_verts}};
     for (int64_t base = blockIdx.x * (int64_t)kBwdBatch; base < n; base += (int64_t)gridDim.x * kBwdBatch) {
-        hash_clear(hkeys, hsums);
+        if (!DET) hash_clear(hkeys, hsums);
         const int64_t end = base + kBwdBatch < n ? base + kBwdBatch : n;
         for (int64_t k = base + threadIdx.x; k < end; k += blockDim.x) {
             const int64_t i = list[k];
@@ -989,7 +1000,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __r
             const d3 g_dir = g_out_dir ? load_d3(g_out_dir, i) : z;
             path_recompute_backward(c, load_d3(origin, i), load_d3(dir, i), face1[i], face2[i], g_ori, g_dir, add);
         }
-        hash_flush(hkeys, hsums, grad_verts);
+        if (!DET) hash_flush(hkeys, hsums, grad_verts);
     }
 }
 
@@ -1006,6 +1017,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(PathCtx c, const double* __r
 struct alignas(16) Dbl2 { double a, b; };
 constexpr int kLossRays = 4;                        // rays per thread
 constexpr int kLossBuf = 2048;                      // >= 2 x the 1024 rows one block iteration can add
+template <bool DET>
 __global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
                                                           const uint8_t* __restrict__ mask, const double* __restrict__ screen_pixel,
                                                           const uint8_t* __restrict__ valid, int64_t n, double* loss,
@@ -1026,7 +1038,7 @@ __global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restric
         if (threadIdx.x == 0) s_tmp[kPathWaves] = 0u;
         __syncthreads();
     };
-    double acc = 0.0;
+    LossAcc<DET> acc;
     const int64_t span = (int64_t)kLossRays * kPathBlock;
     for (int64_t base = blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
         const int64_t i0 = base + kLossRays * (int64_t)threadIdx.x;
@@ -1045,7 +1057,7 @@ __global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restric
             for (int k = 0; k < kLossRays; ++k) on[k] = i0 + k < n && valid[i0 + k] && mask[3 * (i0 + k)];
         }
         for (int k = 0; k < kLossRays; ++k)
-            if (on[k]) acc += ray_loss_term(load_d3(out_ori, i0 + k), load_d3(out_dir, i0 + k), load_d3(screen_pixel, i0 + k), g[k]);
+            if (on[k]) acc.add(ray_loss_term(load_d3(out_ori, i0 + k), load_d3(out_dir, i0 + k), load_d3(screen_pixel, i0 + k), g[k]));
         if (g_out_dir) {
             const int64_t w0 = i0 - kLossRays * (int64_t)lane;                  // first ray of this wave: 256 rays = 6144 contiguous bytes
             if (w0 + kLossRays * 64 <= n) {
@@ -1082,19 +1094,19 @@ __global__ void __launch_bounds__(kPathBlock) k_ray_loss(const double* __restric
         }
     }
     if (list) flush();
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+    acc.flush(loss);
 }
 
 // ray_loss over the forward's list of completed paths (the rays with mask = 1) instead of a pass over all N rays: loss and
 // the list of contributing rows (valid target) for drt_render_backward_ray_loss.  O(valid paths), a few per cent of N.
+template <bool DET>
 __global__ void __launch_bounds__(256) k_ray_loss_listed(const double* __restrict__ out_ori, const double* __restrict__ out_dir,
                                                          const double* __restrict__ screen_pixel, const uint8_t* __restrict__ valid,
                                                          const int32_t* __restrict__ paths, const int64_t* __restrict__ n_paths, double* loss,
                                                          int32_t* __restrict__ rows, unsigned* n_rows) {
     __shared__ unsigned s_tmp[kPathWaves + 1];
     const int64_t n = *n_paths;
-    double acc = 0.0;
+    LossAcc<DET> acc;
     for (int64_t base = blockIdx.x * 256ll; base < n; base += (int64_t)gridDim.x * 256) {
         const int64_t k = base + threadIdx.x;
         bool on = false;
@@ -1102,15 +1114,14 @@ __global__ void __launch_bounds__(256) k_ray_loss_listed(const double* __restric
         if (k < n) {
             i = paths[k];
             on = valid[i] != 0;
-            if (on) { d3 g; acc += ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g); }
+            if (on) { d3 g; acc.add(ray_loss_term(load_d3(out_ori, i), load_d3(out_dir, i), load_d3(screen_pixel, i), g)); }
         }
         if (rows) {
             const int slot = block_push(on, n_rows, s_tmp);
             if (slot >= 0) rows[slot] = i;
         }
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+    acc.flush(loss);
 }
 
 // x[list[k], 0..2] *= *scale
@@ -1125,6 +1136,7 @@ __global__ void __launch_bounds__(256) k_scale_rows3(double* __restrict__ x, con
 }
 
 // Fused loss, last stage (full waves over Q2): recompute the path in float64, loss term, adjoint.
+template <bool DET>
 __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                         const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
                                                         const int32_t* __restrict__ face2, Pipe p, double* loss, double* grad_verts,
@@ -1132,11 +1144,11 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
     __shared__ int32_t hkeys[kHashSize];
     __shared__ double hsums[3 * kHashSize];
     const unsigned n2 = p.count[2];
-    const HashAdd3 add{hkeys, hsums, grad_verts};
-    double acc = 0.0;
+    const PathSink<DET> add{HashAdd3{hkeys, hsums, grad_verts}};
+    LossAcc<DET> acc;
     unsigned cnt = 0;
     for (unsigned base = blockIdx.x * kBwdBatch; base < n2; base += gridDim.x * kBwdBatch) {
-        hash_clear(hkeys, hsums);
+        if (!DET) hash_clear(hkeys, hsums);
         const unsigned end = base + kBwdBatch < n2 ? base + kBwdBatch : n2;
         for (unsigned k = base + threadIdx.x; k < end; k += blockDim.x) {
             if (p.r2.face[k] >= 0) continue;   // occluded exit ray
@@ -1151,7 +1163,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
             load_tri64(c, f2, v0, v1, v2, vid2);
             bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
             d3 g_dir;
-            acc += ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
+            acc.add(ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir));
             ++cnt;
             const d3 z{0.0, 0.0, 0.0};
             d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
@@ -1161,10 +1173,9 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
             bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
             add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
         }
-        hash_flush(hkeys, hsums, grad_verts);
+        if (!DET) hash_flush(hkeys, hsums, grad_verts);
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+    acc.flush(loss);
     if (n_valid && cnt) atomicAdd(n_valid, (unsigned long long)cnt);
 }
 
@@ -1172,6 +1183,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd_fused(PathCtx c, const double*
 // Backward of render_transparent + ray_loss for the rows ray_loss reported as contributing (drt_ray_loss's list):
 // the loss gradient d loss / d out_dir = 2 (out_dir - target) * scale is recomputed from the path (bit-identical to the
 // stored outputs: same code) instead of being read from a dense [N,3] tensor that is zero almost everywhere.
+template <bool DET>
 __global__ void __launch_bounds__(256) k_render_bwd_rows(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                          const double* __restrict__ screen_pixel, const int32_t* __restrict__ face1,
                                                          const int32_t* __restrict__ face2, const int32_t* __restrict__ rows,
@@ -1180,9 +1192,9 @@ __global__ void __launch_bounds__(256) k_render_bwd_rows(PathCtx c, const double
     __shared__ double hsums[3 * kHashSize];
     const unsigned n = *n_rows;
     const double sc = *scale;
-    const HashAdd3 add{hkeys, hsums, grad_verts};
+    const PathSink<DET> add{HashAdd3{hkeys, hsums, grad_verts}};
     for (unsigned base = blockIdx.x * kBwdBatch; base < n; base += gridDim.x * kBwdBatch) {
-        hash_clear(hkeys, hsums);
+        if (!DET) hash_clear(hkeys, hsums);
         const unsigned end = base + kBwdBatch < n ? base + kBwdBatch : n;
         for (unsigned k = base + threadIdx.x; k < end; k += blockDim.x) {
             const int64_t i = rows[k];
@@ -1204,7 +1216,7 @@ __global__ void __launch_bounds__(256) k_render_bwd_rows(PathCtx c, const double
             bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
             add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
         }
-        hash_flush(hkeys, hsums, grad_verts);
+        if (!DET) hash_flush(hkeys, hsums, grad_verts);
     }
 }
 
@@ -1213,6 +1225,7 @@ __global__ void __launch_bounds__(256) k_render_bwd_rows(PathCtx c, const double
 // recomputed every path and its loss term.  The gradient is accumulated with a UNIT seed into a stash the caller scales by the
 // incoming d / d loss when (if) the backward pass arrives; the loss term of a path recomputed from its face ids is the term of
 // the stored out_ori / out_dir rows bit for bit (same code).
+template <bool DET>
 __global__ void __launch_bounds__(256) k_loss_bwd_listed(PathCtx c, const double* __restrict__ origin, const double* __restrict__ dir,
                                                          const double* __restrict__ screen_pixel, const uint8_t* __restrict__ valid,
                                                          const int32_t* __restrict__ face1, const int32_t* __restrict__ face2,
@@ -1225,10 +1238,10 @@ __global__ void __launch_bounds__(256) k_loss_bwd_listed(PathCtx c, const double
     const int64_t first = first_ptr ? (int64_t)*first_ptr : 0;
     paths += first;
     const int64_t n = (n32_ptr ? (int64_t)*n32_ptr : *n_paths) - first;
-    const HashAdd3 add{hkeys, hsums, grad_verts};
-    double acc = 0.0;
+    const PathSink<DET> add{HashAdd3{hkeys, hsums, grad_verts}};
+    LossAcc<DET> acc;
     for (int64_t base = blockIdx.x * (int64_t)kBwdBatch; base < n; base += (int64_t)gridDim.x * kBwdBatch) {
-        hash_clear(hkeys, hsums);
+        if (!DET) hash_clear(hkeys, hsums);
         const int64_t end = base + kBwdBatch < n ? base + kBwdBatch : n;
         for (int64_t k = base + threadIdx.x; k < end; k += blockDim.x) {
             const int64_t i = paths[k];
@@ -1241,7 +1254,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd_listed(PathCtx c, const double
             load_tri64(c, face2[i], v0, v1, v2, vid2);
             bounce_forward(b1.new_o, b1.wt, v0, v1, v2, c.ior_ext, c.ior_int, b2);
             d3 g_dir;
-            acc += ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir);
+            acc.add(ray_loss_term(b2.new_o, b2.wt, load_d3(screen_pixel, i), g_dir));
             const d3 z{0.0, 0.0, 0.0};
             d3 ga = z, gb = z, gc = z, g_o, g_d, g_o0, g_d0;
             bounce_backward(b2, z, g_dir, ga, gb, gc, g_o, g_d);
@@ -1250,10 +1263,9 @@ __global__ void __launch_bounds__(256) k_loss_bwd_listed(PathCtx c, const double
             bounce_backward(b1, g_o, g_d, ga, gb, gc, g_o0, g_d0);
             add(vid1[0], ga); add(vid1[1], gb); add(vid1[2], gc);
         }
-        hash_flush(hkeys, hsums, grad_verts);
+        if (!DET) hash_flush(hkeys, hsums, grad_verts);
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) unsafeAtomicAdd(loss, acc);
+    acc.flush(loss);
 }
 
 __global__ void k_prof_counts(const unsigned* __restrict__ qcount, unsigned long long n_rays, unsigned long long* __restrict__ tot, int fused, int raster, bool mega) {
@@ -1787,7 +1799,7 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
     if (d_valid_idx) {   // the forward's list of completed paths: no pass over the dense arrays at all
         StageTimer t(s, st, kStageBackward);
-        k_render_bwd<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+        DET_LAUNCH(k_render_bwd, DRT_BWD_BPC * s->n_cu, 256, st, pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
                                                    d_valid_idx, nullptr, d_n_valid);
     } else {             // no list saved: compact face2 >= 0 first (on the caller's stream, workspace of sub-stream 0)
         drt_scene::Sub& w = s->sub[0];
@@ -1800,7 +1812,7 @@ int drt_render_backward(drt_scene_t* s, const double* d_verts, const double* d_o
             { StageTimer t(s, st, kStageCollect);
               k_collect_valid<<<grid_for(n, kPathBlock, 8 * s->n_cu), kPathBlock, 0, st>>>(d_face2 + b, n, b, w.q_idx[0], s->vcount); }
             { StageTimer t(s, st, kStageBackward);
-              k_render_bwd<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
+              DET_LAUNCH(k_render_bwd, DRT_BWD_BPC * s->n_cu, 256, st, pc, d_origin, d_dir, d_face1, d_face2, d_grad_out_ori, d_grad_out_dir, d_grad_verts,
                                                          w.q_idx[0], s->vcount, nullptr); }
             if (s->prof_on) k_prof_counts_bwd<<<1, 64, 0, st>>>(s->vcount, (unsigned long long)n, s->prof_counts);
         }
@@ -1822,7 +1834,7 @@ int drt_render_backward_ray_loss(drt_scene_t* s, const double* d_verts, const do
     hipStream_t st = (hipStream_t)stream;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
     { StageTimer t(s, st, kStageBackward);
-      k_render_bwd_rows<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_face1, d_face2, d_rows, d_n_rows, d_scale, d_grad_verts); }
+      DET_LAUNCH(k_render_bwd_rows, DRT_BWD_BPC * s->n_cu, 256, st, pc, d_origin, d_dir, d_screen_pixel, d_face1, d_face2, d_rows, d_n_rows, d_scale, d_grad_verts); }
     if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1835,7 +1847,7 @@ int drt_ray_loss(const double* d_out_ori, const double* d_out_dir, const uint8_t
     if (n_rays == 0) return DRT_OK;
     if (!d_out_ori || !d_out_dir || !d_mask || !d_screen_pixel || !d_valid || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_list == nullptr) != (d_n_list == nullptr)) return fail(DRT_E_INVALID, "d_list and d_n_list go together");
-    k_ray_loss<<<grid_for((n_rays + kLossRays - 1) / kLossRays, kPathBlock, 4096), kPathBlock, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays,
+    DET_LAUNCH(k_ray_loss, grid_for((n_rays + kLossRays - 1) / kLossRays, kPathBlock, 4096), kPathBlock, (hipStream_t)stream, d_out_ori, d_out_dir, d_mask, d_screen_pixel, d_valid, n_rays,
                                                                                           d_loss, d_grad_out_dir, d_list, d_n_list);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1848,7 +1860,7 @@ int drt_ray_loss_listed(const double* d_out_ori, const double* d_out_dir, const 
     if (n_rays == 0) return DRT_OK;
     if (!d_out_ori || !d_out_dir || !d_screen_pixel || !d_valid || !d_paths || !d_n_paths || !d_loss) return fail(DRT_E_INVALID, "null pointer argument");
     if ((d_rows == nullptr) != (d_n_rows == nullptr)) return fail(DRT_E_INVALID, "d_rows and d_n_rows go together");
-    k_ray_loss_listed<<<1024, 256, 0, (hipStream_t)stream>>>(d_out_ori, d_out_dir, d_screen_pixel, d_valid, d_paths, d_n_paths, d_loss, d_rows, d_n_rows);
+    DET_LAUNCH(k_ray_loss_listed, 1024, 256, (hipStream_t)stream, d_out_ori, d_out_dir, d_screen_pixel, d_valid, d_paths, d_n_paths, d_loss, d_rows, d_n_rows);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -1865,7 +1877,7 @@ int drt_ray_loss_listed_grad(drt_scene_t* s, const double* d_verts, const double
     hipStream_t st = (hipStream_t)stream;
     const PathCtx pc = path_ctx(s, d_verts, ior_int, ior_ext);
     { StageTimer t(s, st, kStageBackward);
-      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, nullptr, nullptr, d_loss, d_grad_verts); }
+      DET_LAUNCH(k_loss_bwd_listed, DRT_BWD_BPC * s->n_cu, 256, st, pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, nullptr, nullptr, d_loss, d_grad_verts); }
     if (s->prof_on) s->prof_stream = st;
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -1891,11 +1903,11 @@ int drt_ray_loss_listed_grad_split(drt_scene_t* s, const double* d_verts, const 
     // segment 0 (never moved by the join) on the internal stream that produced it: it starts as soon as that pipeline is through, beside
     // the tail of the other one; the rest of the list on the caller's stream, behind the join; the caller's stream then waits for both.
     { StageTimer t(s, w.stream, kStageBackward);
-      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, w.stream>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, nullptr, nullptr,
+      DET_LAUNCH(k_loss_bwd_listed, DRT_BWD_BPC * s->n_cu, 256, w.stream, pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, nullptr, nullptr,
                                                                   s->seg_counts, d_loss, d_grad_verts); }
     HIP_TRY(hipEventRecord(w.done, w.stream));
     { StageTimer t(s, st, kStageBackward);
-      k_loss_bwd_listed<<<DRT_BWD_BPC * s->n_cu, 256, 0, st>>>(pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, s->seg_counts,
+      DET_LAUNCH(k_loss_bwd_listed, DRT_BWD_BPC * s->n_cu, 256, st, pc, d_origin, d_dir, d_screen_pixel, d_valid, d_face1, d_face2, d_paths, d_n_paths, s->seg_counts,
                                                            nullptr, d_loss, d_grad_verts); }
     HIP_TRY(hipStreamWaitEvent(st, w.done, 0));
     if (s->prof_on) s->prof_stream = st;
@@ -1943,7 +1955,7 @@ int drt_render_ray_loss_fused(drt_scene_t* s, const double* d_verts, const doubl
                                 st, b, nullptr, &finished, seed2 ? seed2 + b : nullptr);
         if (rc) return rc;
         { StageTimer t(s, w.stream, kStageLossBwdFused);
-          k_loss_bwd_fused<<<DRT_BWD_BPC * s->n_cu, 256, 0, w.stream>>>(pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
+          DET_LAUNCH(k_loss_bwd_fused, DRT_BWD_BPC * s->n_cu, 256, w.stream, pc, d_origin + 3 * b, d_dir + 3 * b, d_screen_pixel + 3 * b, w.tmp_face1, w.tmp_face2, p,
                                                                d_loss, d_grad_verts, reinterpret_cast<unsigned long long*>(d_n_valid)); }
         if (s->prof_on) k_prof_counts<<<1, 64, 0, w.stream>>>(w.qcount, (unsigned long long)n, s->prof_counts, 1, raster_on(s, n, tile_w, tile_h), finished);
     }

@@ -18,6 +18,7 @@
 #include "drt_common.h"
 #include "drt_closest.h"
 #include "drt_edge.h"
+#include "drt_fixed.h"
 #include "drt_lbvh.h"
 #include "drt_path.h"
 #include "drt_raster.h"
@@ -214,6 +215,13 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
 
 // defined in drt_api.hip
 int ensure_slow_stack(drt_scene* s, hipStream_t st);
+bool det_mode();        // drt_deterministic / DRT_DETERMINISTIC: gradient and loss targets are FxCell accumulators (drt_fixed.h)
+// a kernel template whose first parameter is the accumulation mode
+#define DET_LAUNCH(kern, grid, block, st, ...)                                        \
+    do {                                                                              \
+        if (det_mode()) kern<true><<<grid, block, 0, st>>>(__VA_ARGS__);              \
+        else kern<false><<<grid, block, 0, st>>>(__VA_ARGS__);                        \
+    } while (0)
 // -DDRT_CHECK=1: the stack-invariant counters of the two translation units that instantiate the traversal kernels
 int check_counters_pipeline(unsigned long long* out4);
 int check_counters_trace(unsigned long long* out4);

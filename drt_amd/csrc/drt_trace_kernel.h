@@ -128,6 +128,9 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
     int32_t slot = -1;
     TravState s;
     unsigned long long wave_steps = 0, lane_steps = 0, leaf_steps = 0;   // wave-uniform diagnostics (scalar registers)
+#if defined(DRT_PROBE_VISITS)
+    unsigned nvis = 0;          // (tools/ubench/reorder_probe.py: a probe build reports a ray's node visits in place of T)
+#endif
     for (;;) {
         // Finished rays leave here, in ONE place between the phases (where only the ray's own state is alive) and only when the wave
         // refills anyway, or is through: the deferred hit-point condition on the winner (trav_leaf<ANY, true>) reads the winner's record
@@ -138,6 +141,9 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
         const bool refill = idle != 0 && taken < my_rays && ((int)__popcll(idle) >= refill_min || idle == ~0ull);
         if ((refill || idle == ~0ull) && fin) {
             if (trav_winner_ok(c.tris, s)) {
+#if defined(DRT_PROBE_VISITS)
+                if (MODE == 1 && !ANY && s.best_face >= 0) s.best_t = (float)nvis;
+#endif
                 trace_emit<ANY, MODE>(out, slot, s.best_t, s.best_face);
                 if (SEED && s.best_face >= 0) sd.store[seed_index(sd, sd.list_idx[slot])] = s.best_face;
             } else {
@@ -164,6 +170,9 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
                     if (SEED) { s.best_t = seed_t; s.best_face = seed_face; s.best_slot = seed_slot; }
                     st.overflow = false;
                     slot = (int32_t)k;
+#if defined(DRT_PROBE_VISITS)
+                    nvis = 0;
+#endif
                     lds[kStackFast][threadIdx.x] = 0;            // (nothing parked: DRT_LEAF_PARK)
                 }
             }
@@ -186,6 +195,9 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             ++wave_steps;
             lane_steps += (unsigned long long)__popcll(mi);
             if (at_inner) {
+#if defined(DRT_PROBE_VISITS)
+                ++nvis;
+#endif
                 const bool done = trav_inner<ANY>(c.nodes, s, st);
                 if (st.overflow) {              // LDS stack exhausted (rare): hand the ray to the second pass (epilogue)
                     trace_redo_push(redo_list, redo_count, slot);
@@ -205,6 +217,9 @@ __global__ void __launch_bounds__(kPathBlock, 8) k_trace(TraceCtx c, const float
             ++wave_steps; ++leaf_steps;
             lane_steps += (unsigned long long)__popcll(mh);
             if (pk != 0) {
+#if defined(DRT_PROBE_VISITS)
+                ++nvis;
+#endif
                 lds[kStackFast][threadIdx.x] = 0;
                 if (trav_leaf_test<ANY, true>(c.tris, s, pk)) s.cur = kFinished;      // (any-hit: done)
                 else if (s.cur == kDrained) s.cur = kFinished;

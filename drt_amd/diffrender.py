@@ -28,7 +28,7 @@ import weakref
 import numpy as np
 import torch
 
-from . import _lib, mesh_io
+from . import _lib, det, mesh_io
 from .optix_mesh import optix_mesh, _stream, _on
 from .stepwise import Intersection, StepwiseMixin  # noqa: F401  (Dintersect / refract_ray / trace2 / project_vert)
 
@@ -390,7 +390,7 @@ class _RenderTransparent(torch.autograd.Function):
         face1 = torch.empty(n, dtype=torch.int32, device=o.device)
         face2 = torch.empty(n, dtype=torch.int32, device=o.device)
         if (SPLIT_LOSS and need_bwd and EAGER_LOSS_GRAD and link is not None and not capturing and n >= SPLIT_LOSS_MIN_RAYS):
-            link.pre = (torch.zeros_like(v), torch.zeros((), dtype=torch.float64, device=o.device))
+            link.pre = (det.acc(v), det.scalar(o.device))
         _render_seq[0] += 1
         if link is not None:
             link.seq = _render_seq[0]
@@ -458,7 +458,7 @@ class _RenderTransparent(torch.autograd.Function):
         if g_dir is not None and link.is_token(g_dir):
             g_dir = None                        # ray_loss's placeholder: its gradient is in `pending`
         # (the usual step -- one ray_loss, eager stash, nothing dense -- is ONE small launch: stash * scale)
-        grad_v = None if (g_ori is None and g_dir is None and pending and all(e[0] is None for e in pending)) else torch.zeros_like(v)
+        grad_v = None if (g_ori is None and g_dir is None and pending and all(e[0] is None for e in pending)) else det.acc(v)
         h = ctx.scene.optix_mesh._h
         with _on(o.device):
             if g_ori is not None or g_dir is not None:
@@ -474,6 +474,8 @@ class _RenderTransparent(torch.autograd.Function):
                 _lib.check(_lib.lib().drt_render_backward_ray_loss(
                     h, v.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0], ctx.ior[0], ctx.ior[1], face1.data_ptr(), face2.data_ptr(),
                     rows.data_ptr(), n_rows.data_ptr(), sp.data_ptr(), scale.data_ptr(), grad_v.data_ptr(), _stream()))
+        if grad_v is not None:
+            grad_v = det.value(grad_v, v)          # (deterministic mode: the exact integer sums, rounded once)
         for rows, stash, _, scale in pending:
             if rows is None:
                 grad_v = torch.addcmul(grad_v, stash, scale) if grad_v is not None else stash * scale
@@ -491,7 +493,7 @@ class _RayLoss(torch.autograd.Function):
         n = oo.shape[0]
         m = _flag_bytes(mask, "mask", 3 * n)
         va = _flag_bytes(valid, "valid", n)
-        loss = torch.zeros((), dtype=torch.float64, device=oo.device)
+        loss = det.scalar(oo.device)
         need = ctx.needs_input_grad[1]
         ctx.link = link if need else None
         g = torch.empty_like(od) if need and link is None else None      # dense d loss / d out_dir only without a link
@@ -511,17 +513,19 @@ class _RayLoss(torch.autograd.Function):
                 if early:      # accumulators zeroed before the render call: the head of the list can be processed beside the pipelines (SPLIT_LOSS)
                     ctx.stash, loss = pre
                 else:
-                    ctx.stash = torch.zeros_like(v)
+                    ctx.stash = det.acc(v)
                 fn = _lib.lib().drt_ray_loss_listed_grad_split if early else _lib.lib().drt_ray_loss_listed_grad
                 _lib.check(fn(
                     scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, ior[0], ior[1], face1.data_ptr(), face2.data_ptr(),
                     sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(), link.paths[1].data_ptr(), loss.data_ptr(), ctx.stash.data_ptr(), _stream()))
+                ctx.stash = det.value(ctx.stash, v)
             elif own:
                 _lib.check(_lib.lib().drt_ray_loss_listed(oo.data_ptr(), od.data_ptr(), sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(),
                                                           link.paths[1].data_ptr(), n, loss.data_ptr(), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
             else:
                 _lib.check(_lib.lib().drt_ray_loss(oo.data_ptr(), od.data_ptr(), m.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
                                                    loss.data_ptr(), _lib.ptr(g), _lib.ptr(rows), _lib.ptr(n_rows), _stream()))
+        loss = det.value(loss)
         ctx.save_for_backward(g, rows, n_rows, sp if (need and link is not None) else None)
         ctx.applied = None                       # scale already multiplied into the saved rows (see backward)
         ctx.n_rays = n
@@ -570,15 +574,15 @@ class _RenderRayLossFused(torch.autograd.Function):
         d = _f64c(ray_dir, "ray_dir")
         sp = _f64c(screen_pixel, "screen_pixel")
         va = _flag_bytes(valid, "valid", o.shape[0])
-        loss = torch.zeros((), dtype=torch.float64, device=o.device)
-        grad_v = torch.zeros_like(v)
+        loss = det.scalar(o.device)
+        grad_v = det.acc(v)
         with _on(o.device):
             _arm_seed(scene.optix_mesh._h, grid, o.shape[0])
             _lib.check(_lib.lib().drt_render_ray_loss_fused(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), o.shape[0],
                 float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, *_tile_hint(o.shape[0]), grid[0], _lib.ptr(grid[1]), _stream()))
-        ctx.save_for_backward(grad_v)
-        return loss
+        ctx.save_for_backward(det.value(grad_v, v))
+        return det.value(loss)
 
     @staticmethod
     def backward(ctx, g_loss):
@@ -1031,26 +1035,26 @@ class _VhTermLazy(torch.autograd.Function):
     def forward(ctx, vertices, ss, image):
         n = ss.edges.shape[0]
         dev = ss.v.device
-        loss = torch.zeros((), dtype=torch.float64, device=dev)
+        loss = det.scalar(dev)
         dterm = ss.dterm
         with _on(dev):
             _lib.check(_lib.lib().drt_vh_term(ss.index.data_ptr(), ss.keep.data_ptr(), n, image.data_ptr(), ss.res_x, ss.res_y,
                                               loss.data_ptr(), dterm.data_ptr(), _stream()))
         ctx.ss = ss
         ctx.save_for_backward(dterm)
-        return loss
+        return det.value(loss)
 
     @staticmethod
     def backward(ctx, g_loss):
         (dterm,) = ctx.saved_tensors
         ss = ctx.ss
-        grad_v = torch.zeros_like(ss.v)
+        grad_v = det.acc(ss.v)
         # (the reference's `output` is float32: the incoming gradient reaches primary_edge_sample.backward rounded to float32, DiffRender.py:251, 263-267)
         g = g_loss if (g_loss.dtype == torch.float64 and g_loss.is_cuda and g_loss.numel() == 1) else g_loss.to(device=ss.v.device, dtype=torch.float64).reshape(1)
         with _on(ss.v.device):
             _lib.check(_lib.lib().drt_edge_sample_backward_term(ss.v.data_ptr(), ss.edges.data_ptr(), ss.edges.shape[0], ss.cam.data_ptr(), ss.f.data_ptr(),
                                                                 dterm.data_ptr(), g.data_ptr(), int(ss.detach_depth), grad_v.data_ptr(), _stream()))
-        return grad_v, None, None
+        return det.value(grad_v, ss.v), None, None
 
 
 class _Dihedral(torch.autograd.Function):
@@ -1069,11 +1073,11 @@ class _Dihedral(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_cos):
         v, e2f = ctx.saved_tensors
-        grad_v = torch.zeros_like(v)
+        grad_v = det.acc(v)
         g = _f64c(g_cos, "grad")
         with _on(v.device):
             _lib.check(_lib.lib().drt_dihedral_backward(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], g.data_ptr(), grad_v.data_ptr(), _stream()))
-        return grad_v, None
+        return det.value(grad_v, v), None
 
 
 class _SmLossFused(torch.autograd.Function):
@@ -1081,12 +1085,12 @@ class _SmLossFused(torch.autograd.Function):
     def forward(ctx, vertices, E2F):
         v = _f64c(vertices.detach(), "vertices")
         e2f = E2F.contiguous()
-        loss = torch.zeros((), dtype=torch.float64, device=v.device)
-        grad_v = torch.zeros_like(v)
+        loss = det.scalar(v.device)
+        grad_v = det.acc(v)
         with _on(v.device):
             _lib.check(_lib.lib().drt_sm_loss_fused(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], loss.data_ptr(), grad_v.data_ptr(), _stream()))
-        ctx.save_for_backward(grad_v)
-        return loss
+        ctx.save_for_backward(det.value(grad_v, v))
+        return det.value(loss)
 
     @staticmethod
     def backward(ctx, g_loss):
@@ -1134,22 +1138,22 @@ class _EdgeSample(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_index, grad_output):
         v, edges, cam, f, sel = ctx.saved_tensors
-        grad_v = torch.zeros_like(v)
+        grad_v = det.acc(v)
         g = grad_output if grad_output.dtype == torch.float32 and grad_output.is_contiguous() else grad_output.to(torch.float32).contiguous()
         with _on(v.device):
             # (the kept rows and their float32 gradients as they are: no zero-filled [Es] coefficient vector, cast and scatter per view)
             _lib.check(_lib.lib().drt_edge_sample_backward_rows(v.data_ptr(), edges.data_ptr(), edges.shape[0], cam.data_ptr(), f.data_ptr(),
                                                                 sel.data_ptr(), sel.shape[0], g.data_ptr(), int(ctx.detach_depth),
                                                                 grad_v.data_ptr(), _stream()))
-        return grad_v, None, None, None, None, None, None, None, None, None
+        return det.value(grad_v, v), None, None, None, None, None, None, None, None, None
 
 
 class _VhLossFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vertices, scene, res_x, res_y, *flat):
         v = _f64c(vertices.detach(), "vertices")
-        loss = torch.zeros((), dtype=torch.float64, device=v.device)
-        grad_v = torch.zeros_like(v)
+        loss = det.scalar(v.device)
+        grad_v = det.acc(v)
         n = len(flat) // 3
         cams, orgs, softs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
         keep = []
@@ -1163,9 +1167,9 @@ class _VhLossFused(torch.autograd.Function):
         with _on(v.device):
             _lib.check(_lib.lib().drt_vh_loss_fused(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), e2f.data_ptr(), e2f.shape[0], n,
                                                     cams, orgs, softs, res_x, res_y, 1, loss.data_ptr(), grad_v.data_ptr(), _stream()))
-        ctx.save_for_backward(grad_v)
+        ctx.save_for_backward(det.value(grad_v, v))
         ctx.n_in = len(flat)
-        return loss
+        return det.value(loss)
 
     @staticmethod
     def backward(ctx, g_loss):

@@ -232,8 +232,22 @@ class FusedIteration:
         with torch.no_grad(), torch.cuda.device(dev):
             vertices = self.init_vertices + self.parameter
             scene.update_verticex(vertices)
-            self.grads.zero_()
-            self.losses.zero_()
+            from . import det
+            if det.on():
+                # deterministic mode: the three terms accumulate into fixed-point cells (drt_amd/det.py), converted once all of them are in
+                if getattr(self, "_g_acc", None) is None:
+                    self._g_acc = torch.zeros(self.grads.numel() * 3, dtype=torch.int64, device=dev)
+                    self._l_acc = torch.zeros(3 * 3, dtype=torch.int64, device=dev)
+                self._g_acc.zero_()
+                self._l_acc.zero_()
+                per = self.grads[0].numel() * 3
+                g_ptr = [self._g_acc[k * per:].data_ptr() for k in range(3)]
+                l_ptr = [self._l_acc[3 * k:].data_ptr() for k in range(3)]
+            else:
+                self.grads.zero_()
+                self.losses.zero_()
+                g_ptr = [self.grads[k].data_ptr() for k in range(3)]
+                l_ptr = [self.losses[k:].data_ptr() for k in range(3)]
             h = scene.optix_mesh._h
             main = torch.cuda.current_stream()
             if self.side is not None:
@@ -246,13 +260,12 @@ class FusedIteration:
                 grid = R._grid_cache(origin, ray_dir, n, *R._tile_hint(n)) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
                 R._arm_seed(h, grid, n)
                 check(lib.drt_render_ray_loss_fused(h, vertices.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), n,
-                                                    float(R.intIOR), float(R.extIOR), self.losses[0:].data_ptr(), self.grads[0].data_ptr(), None,
+                                                    float(R.intIOR), float(R.extIOR), l_ptr[0], g_ptr[0], None,
                                                     *R._tile_hint(n), grid[0], ptr(grid[1]), _stream()))
             ctx = torch.cuda.stream(self.side) if self.side is not None else torch.no_grad()
             with ctx:
                 if hp["sm_w"] != 0:        # (first: it needs no tree, so it runs while the build finishes; the silhouette probes wait for the tree)
-                    check(lib.drt_sm_loss_fused(vertices.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], self.losses[2:].data_ptr(),
-                                                self.grads[2].data_ptr(), _stream()))
+                    check(lib.drt_sm_loss_fused(vertices.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], l_ptr[2], g_ptr[2], _stream()))
                 if hp["vh_w"] != 0:
                     import ctypes
                     k = self.N_SILHOUETTE_VIEWS
@@ -264,9 +277,12 @@ class FusedIteration:
                         keep += [cam, o3, sm_]
                         cams[j], orgs[j], softs[j] = cam.data_ptr(), o3.data_ptr(), sm_.data_ptr()
                     check(lib.drt_vh_loss_fused(h, vertices.data_ptr(), scene.Edges.data_ptr(), scene.E2F.data_ptr(), scene.E2F.shape[0], k,
-                                                cams, orgs, softs, int(data.resx), int(data.resy), 1, self.losses[1:].data_ptr(), self.grads[1].data_ptr(), _stream()))
+                                                cams, orgs, softs, int(data.resx), int(data.resy), 1, l_ptr[1], g_ptr[1], _stream()))
             if self.side is not None:
                 main.wait_stream(self.side)
+            if det.on():
+                det.value_into(self._g_acc, self.grads)
+                det.value_into(self._l_acc, self.losses)
             w = loss_weights(hp, data.resy, scene.mean_len)
             if self._w is None or self._w[0] != w:
                 self._w = (w, torch.tensor(w, dtype=Float, device=dev))

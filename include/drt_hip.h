@@ -32,7 +32,24 @@ extern "C" {
 typedef struct drt_scene drt_scene_t;
 
 const char* drt_last_error(void);
-int drt_version(void);
+int drt_version(void);       /* 2: drt_deterministic / drt_fx_finalize */
+
+/* ---- deterministic accumulation ("race detection / sanitizers"; reference optim.py:155-171 clamps the SUM) --------
+ * Every vertex gradient and loss of this library is a sum of contributions scattered with float64 atomics: the same inputs give results
+ * that differ from run to run at 1e-16 relative, in the order the hardware served the atomics.  drt_deterministic(1) -- or DRT_DETERMINISTIC=1
+ * in the environment, read at the first call that needs to know -- switches the whole PROCESS to order-independent accumulation: every
+ * `double* d_grad_verts` / `double* d_loss` / `d_stash` ACCUMULATION TARGET of the entry points below must then point to an array of
+ * accumulator cells instead of doubles, DRT_FX_BYTES_PER_VALUE bytes per float64 element (same element numbers), zero-filled by the
+ * caller; the kernels add every contribution as a 128-bit fixed-point integer (unit 2^-80, drt_amd/csrc/drt_fixed.h: integer addition
+ * is associative, so the sum is the same bit pattern whatever the order; contributions of magnitude >= 3.7e-9 enter exactly, smaller ones
+ * are truncated at 8e-25 absolute; |x| >= 7e13, +-inf and NaN set sticky flags and give +-inf / NaN).  drt_fx_finalize converts n cells to
+ * float64 with ONE rounding (nearest-even) of the exact sum: d_out[i] = value, or d_out[i] += value with `accumulate`.  Inputs that are
+ * READ as gradients (d_grad_out_dir, d_grad_cos, ...) and per-ray outputs stay plain float64.  Same result for eager launches and graph
+ * replays, any stream interleaving, any sub-batch split.  The price: no LDS pre-aggregation in the path kernels and two 64-bit integer
+ * atomics per component (DESIGN.md section 7 has the measured cost).  drt_deterministic(-1) only queries; returns the previous mode. */
+#define DRT_FX_BYTES_PER_VALUE 24
+int drt_deterministic(int on);
+int drt_fx_finalize(const void* d_cells, int64_t n, double* d_out, int accumulate, void* stream);
 
 /* ---- lifetime: replaces optix_mesh::optix_mesh(cuda_device), optix_extend.cpp:8-12 ---- */
 int drt_create(int device, drt_scene_t** out);

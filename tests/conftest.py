@@ -89,6 +89,11 @@ def hostsim():
     hs.hs_morton_key.argtypes = [_P, _P]
     hs.hs_raster.restype = _I64
     hs.hs_raster.argtypes = [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P, _P]
+    hs.hs_fx_from.argtypes = [_D, _P, _P, _P]
+    hs.hs_fx_to.restype = _D
+    hs.hs_fx_to.argtypes = [ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32]
+    hs.hs_fx_sum.restype = _D
+    hs.hs_fx_sum.argtypes = [_P, _I64]
     return hs
 
 

@@ -12,6 +12,7 @@
 
 #include "../../drt_amd/csrc/drt_closest.h"
 #include "../../drt_amd/csrc/drt_edge.h"
+#include "../../drt_amd/csrc/drt_fixed.h"
 #include "../../drt_amd/csrc/drt_lbvh.h"
 #include "../../drt_amd/csrc/drt_path.h"
 #include "../../drt_amd/csrc/drt_raster.h"
@@ -438,6 +439,16 @@ uint32_t hs_morton_key(const float* ext3, const float* p3) {
     const f3 v{p3[0], p3[1], p3[2]};
     const f3 inv{ext3[0] > 0 ? 1.0f / ext3[0] : 0.f, ext3[1] > 0 ? 1.0f / ext3[1] : 0.f, ext3[2] > 0 ? 1.0f / ext3[2] : 0.f};
     return morton_key(v, v, v, f3{0.f, 0.f, 0.f}, inv, p);
+}
+
+// drt_fixed.h: float64 -> 128-bit fixed point and back (the deterministic accumulation mode), checked against Python integers
+void hs_fx_from(double x, int64_t* hi, uint64_t* lo, uint32_t* flags) { Fx128 r; *flags = fx_from_double(x, r); *hi = r.hi; *lo = r.lo; }
+double hs_fx_to(int64_t hi, uint64_t lo, uint32_t flags) { return fx_to_double(Fx128{hi, lo}, flags); }
+// the sum of n float64 values the way a kernel accumulates it (any order gives the same cells), converted once
+double hs_fx_sum(const double* x, int64_t n) {
+    FxAcc a;
+    for (int64_t i = 0; i < n; ++i) a.add(x[i]);
+    return fx_to_double(a.v, a.flags);
 }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-ARGS = ["--steps", "2", "--warmup", "1", "--res", "256", "--views", "8", "--no-cpu-baseline", "--no-extras"]
+ARGS = ["--steps", "2", "--warmup", "1", "--res", "256", "--views", "8", "--no-cpu-baseline", "--no-extras", "--repeats", "3"]       # (a fixed number of repeats: the two runs must take the same number of steps)
 
 
 def _free_port():

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of one environment switch on ONE box: bench.py with VAR=0 and VAR=1 alternating, 2 rounds, full extras (per-stage numbers).
 # usage (via gpurun): bash tools/ab_env.sh DRT_HIT_SEED [bench args]
+export DRT_BENCH_REPEATS=${DRT_BENCH_REPEATS:-3}      # (bench.py without --repeats runs a >= 3 s sustained measurement: not what this script is after)
 var=$1; shift
 mkdir -p gpurun_out/ab
 for r in 1 2; do
