@@ -1502,9 +1502,9 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
           // a demotion inside this call did list waits for k_gen_late below
       } else if (rz.views) {       // only the R0 slots listed by k_cull (rays that are not grid rays)
           const TraceOut out{p.r0.face, nullptr, nullptr, w.gen_list};
-          k_trace<false, 2><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 3, out, p.redo, p.count + 4, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
+          launch_trace_list(kTraceClosestListed, s->grid_path, st, pc.tc, p.r0.ray, p.count + 3, out, p.redo, p.count + 4, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
       } else {
-          k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
+          launch_trace_list(kTraceClosest, s->grid_path, st, pc.tc, p.r0.ray, p.count + 0, TraceOut{p.r0.face, nullptr, nullptr, nullptr}, p.redo, p.count + 4, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 0 : nullptr);
       } }
     if (mega) {     // k_shade1 parks float64 rays in rows of the dense outputs: their zeroing must be through
         if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));
@@ -1530,16 +1530,16 @@ static int launch_chunk(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const P
     { StageTimer t(s, st, kStageTrace2);
       unsigned long long* stats = s->prof_stats ? s->prof_counts + kProfStages + 4 * 1 : nullptr;
       if (seed2 && s->hit_seed)       // the refracted rays start from last call's exit triangle of their pixel (TraceSeed)
-          k_trace<false, 0, true><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats,
+          launch_trace_list(kTraceClosestSeeded, s->grid_path, st, pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats,
                                                                         TraceSeed{p.r1.idx, seed2, s->slot_of_face, tile_w > 0 && s->seed_tiled ? (unsigned)tile_w : 0u});
       else
-          k_trace<false, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats); }
+          launch_trace_list(kTraceClosest, s->grid_path, st, pc.tc, p.r1.ray, p.count + 1, TraceOut{p.r1.face, nullptr, nullptr, nullptr}, p.redo, p.count + 5, p.count + 16, s->refill_min, s->inner_min, stats); }
     if (late_fill && fs != st) HIP_TRY(hipStreamWaitEvent(st, w.fill_join, 0));     // k_shade2 is the first kernel that writes rows of the dense outputs
     if (late_fill && pre_any) HIP_TRY(hipStreamWaitEvent(st, s->prefill_done, 0));
     { StageTimer t(s, st, kStageShade2);
       k_shade2<FUSED><<<gs, kPathBlock, 0, st>>>(pc, o, d, out_ori, out_dir, mask, face1, face2, p, park); }
     { StageTimer t(s, st, kStageTrace3);
-      k_trace<true, 0><<<s->grid_path, kPathBlock, 0, st>>>(pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
+      launch_trace_list(kTraceAny, s->grid_path, st, pc.tc, p.r2.ray, p.count + 2, TraceOut{p.r2.face, nullptr, nullptr, nullptr}, p.redo, p.count + 6, p.count + 16, s->refill_min, s->inner_min, s->prof_stats ? s->prof_counts + kProfStages + 4 * 2 : nullptr); }
     return DRT_OK;
 }
 }  // extern "C++"
@@ -1577,11 +1577,6 @@ int mega_blocks_per_cu() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path<false>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     int f = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, k_path<true>, kPathBlock, 0) == hipSuccess && f >= 1 && f < per_cu) per_cu = f;
-    return per_cu;
-}
-int pipeline_blocks_per_cu() {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, 0>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu;
 }
 

@@ -66,6 +66,25 @@ __global__ void __launch_bounds__(kTraceBlock) k_closest_point(TraceCtx c, const
     }
 }
 
+// The refraction pipeline's traversal launches (drt_pipeline.hip: lists R0 / R1 / R2).  The kernels are instantiated HERE, in the translation
+// unit that holds nothing else of the pipeline: k_trace runs at exactly 64 VGPRs and the compiler's register allocation for it was found to
+// change with the OTHER kernels of its translation unit (round 6: templating the gradient kernels of drt_pipeline.hip alone moved the seeded
+// instantiation's scratch use from 12 to 20 bytes and put a store in its prologue) -- an edit elsewhere must not perturb the hot kernel.
+void launch_trace_list(int variant, int grid, hipStream_t st, TraceCtx c, const float* rays, const unsigned* n_ptr, TraceOut out, int32_t* redo_list,
+                       unsigned* redo_count, unsigned* done_count, int refill_min, int inner_min, unsigned long long* stats, TraceSeed sd) {
+    switch (variant) {
+    case kTraceClosest: k_trace<false, 0><<<grid, kPathBlock, 0, st>>>(c, rays, n_ptr, out, redo_list, redo_count, done_count, refill_min, inner_min, stats); break;
+    case kTraceClosestListed: k_trace<false, 2><<<grid, kPathBlock, 0, st>>>(c, rays, n_ptr, out, redo_list, redo_count, done_count, refill_min, inner_min, stats); break;
+    case kTraceClosestSeeded: k_trace<false, 0, true><<<grid, kPathBlock, 0, st>>>(c, rays, n_ptr, out, redo_list, redo_count, done_count, refill_min, inner_min, stats, sd); break;
+    default: k_trace<true, 0><<<grid, kPathBlock, 0, st>>>(c, rays, n_ptr, out, redo_list, redo_count, done_count, refill_min, inner_min, stats); break;
+    }
+}
+int pipeline_blocks_per_cu() {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false, 0>, kPathBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    return per_cu;
+}
+
 #if defined(DRT_CHECK)
 int check_counters_trace(unsigned long long* out4) { return read_check_counters(out4); }
 #endif

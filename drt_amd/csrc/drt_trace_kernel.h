@@ -77,6 +77,12 @@ __device__ __forceinline__ int64_t seed_index(const TraceSeed& sd, int32_t ray) 
     return raster_slot(x, y, sd.tile_w);
 }
 
+// instantiated in drt_trace.hip (see there); `sd` only for kTraceClosestSeeded
+enum : int { kTraceClosest = 0, kTraceClosestListed = 1, kTraceClosestSeeded = 2, kTraceAny = 3 };
+void launch_trace_list(int variant, int grid, hipStream_t st, TraceCtx c, const float* rays, const unsigned* n_ptr, TraceOut out, int32_t* redo_list,
+                       unsigned* redo_count, unsigned* done_count, int refill_min, int inner_min, unsigned long long* stats,
+                       TraceSeed sd = TraceSeed{nullptr, nullptr, nullptr, 0u});
+
 template <int MODE>
 __device__ __forceinline__ const float* trace_ray(const float* __restrict__ rays, const TraceOut& out, unsigned slot) {
     return rays + 6 * (int64_t)(MODE != 0 ? out.idx[slot] : (int32_t)slot);

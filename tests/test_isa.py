@@ -59,12 +59,15 @@ def test_traversal_kernels_fit_eight_waves_per_simd():
     memory.  The loop is everything in front of the first barrier (the epilogue -- the second pass of the workgroup that retires last, a few
     rays per launch at most -- starts with one); the seeded instantiation keeps two registers of that epilogue in scratch, which is allowed."""
     out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + build.FLAGS + ["-S", "--cuda-device-only", "-o", "-",
-                         os.path.join(build.CSRC, "drt_pipeline.hip")], check=True, capture_output=True, text=True).stdout
+                         os.path.join(build.CSRC, "drt_trace.hip")], check=True, capture_output=True, text=True).stdout      # (every k_trace instantiation lives there)
     meta = re.findall(r"\.name:\s+(_Z7k_trace\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", out, re.S)
     assert len(meta) >= 3, "k_trace instantiations not found"
     for name, scratch, vgprs in meta:
         assert int(vgprs) <= 64, (name, vgprs)
-        assert int(scratch) <= 16, (name, scratch)
+        # k_trace<false, 0, true> (temporal hit seeds: opt-in, off by default) and k_trace<false, 1> (boundary B1: T and ID per ray number) may keep
+        # registers of their EPILOGUE in scratch; the pipeline's instantiations may not use scratch at all
+        relaxed = name.startswith(("_Z7k_traceILb0ELi0ELb1E", "_Z7k_traceILb0ELi1ELb0E"))
+        assert int(scratch) <= (32 if relaxed else 0), (name, scratch)
     kernels = re.findall(r"^(_Z7k_trace\w+):.*?\n(.*?)s_endpgm", out, re.S | re.M)
     assert len(kernels) >= 3
     for name, text in kernels:
@@ -79,7 +82,7 @@ def test_inner_visit_reads_bounds_as_float16_subnormals_and_issues_four_loads():
     worth it while no byte->float converts are left.  The child references must be loaded beside the three bound chunks (four
     16-byte loads of one node in a row), not inside the "a child was hit" branch as a second, dependent round trip."""
     out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + build.FLAGS + ["-S", "--cuda-device-only", "-o", "-",
-                         os.path.join(build.CSRC, "drt_pipeline.hip")], check=True, capture_output=True, text=True).stdout
+                         os.path.join(build.CSRC, "drt_trace.hip")], check=True, capture_output=True, text=True).stdout      # (every k_trace instantiation lives there)
     kernels = re.findall(r"^(_Z7k_trace\w+):.*?\n(.*?)s_endpgm", out, re.S | re.M)
     assert len(kernels) >= 2
     for name, text in kernels:
