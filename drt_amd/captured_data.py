@@ -58,6 +58,24 @@ class Data:
             cache[V_index] = hit
         return hit
 
+    def get_binding(self, scene, V_index):
+        """The rays (and targets) of view ``V_index`` as an explicit handle of ``scene`` (drt_amd.diffrender.RayBinding): the resident views
+        of a capture ARE constants, so the caller's loop need not rely on tensor-identity heuristics to get the trusted-grid path and
+        recycled outputs.  One handle per (scene, view), all of a scene's handles sharing one output set (a loop renders one view per
+        iteration, reference optim.py:95-97: the outputs of a call are valid until the next call on any view of this capture)."""
+        book = self.__dict__.setdefault("_bindings", {})
+        per_scene = book.get(id(scene))
+        if per_scene is None or per_scene[0]() is not scene:
+            import weakref
+            from . import diffrender
+            per_scene = book[id(scene)] = (weakref.ref(scene), {}, diffrender.RayBinding.Shared())
+        V_index = int(V_index)
+        b = per_scene[1].get(V_index)
+        if b is None:
+            screen_pixel, valid, _, origin, ray_dir, _ = self.get_view(V_index)
+            b = per_scene[1][V_index] = scene.bind_rays(origin, ray_dir, screen_pixel, valid, shared=per_scene[2])
+        return b
+
     def make_resident(self, ids=None):
         for k in (range(len(self.Views)) if ids is None else ids):
             self.get_view(k)

@@ -80,6 +80,7 @@ int drt_create(int device, drt_scene_t** out) {
         e = hipMemcpy(s->bounds_acc, init, sizeof(init), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(&s->vcount, sizeof(unsigned) * 4);
+    if (e == hipSuccess) e = hipMemset(s->vcount, 0, sizeof(unsigned) * 4);      // ([3]: the device-side canary counter of k_check_views)
     if (e == hipSuccess) e = hipMalloc(&s->seg_counts, sizeof(unsigned) * drt_scene::kMaxSeg);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->build_stream, hipStreamNonBlocking);

@@ -46,11 +46,20 @@ __device__ __forceinline__ uint32_t canary_hash(uint32_t a, uint32_t b, uint32_t
     return h;
 }
 __global__ void __launch_bounds__(64) k_check_views(const double* __restrict__ origin, const double* __restrict__ dir, int w, int h,
-                                                    ViewModel* __restrict__ cache, ViewModel* __restrict__ views, unsigned salt) {
+                                                    ViewModel* __restrict__ cache, ViewModel* __restrict__ views, unsigned salt, unsigned* __restrict__ salt_ctr) {
     __shared__ ViewModel vm;
+    __shared__ unsigned s_ctr;
     const int64_t base = (int64_t)blockIdx.x * w * h;
-    if (threadIdx.x == 0) vm = cache[blockIdx.x];
+    if (threadIdx.x == 0) {
+        vm = cache[blockIdx.x];
+        // The call's salt is a HOST counter: baked into a captured graph, every replay would re-check the same 64 pixels.  A DEVICE counter that
+        // every launch bumps is mixed in, so that replays move on like eager calls do (which value a block happens to read does not matter:
+        // any pixel is a legitimate canary).
+        s_ctr = salt_ctr ? __hip_atomic_load(salt_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (salt_ctr && blockIdx.x == 0) atomicAdd(salt_ctr, 1u);
+    }
     __syncthreads();
+    if (salt) salt = (salt ^ (s_ctr * 0x9E3779B1u)) | 1u;
     const bool trusted = vm.ok && vm.all;              // (k_store_models stores ok == all)
     const int sx = (int)(threadIdx.x & 7), sy = (int)(threadIdx.x >> 3);
     const int x = (int)(((int64_t)(w - 1) * sx) / 7), y = (int)(((int64_t)(h - 1) * sy) / 7);
@@ -252,7 +261,8 @@ int launch_raster(drt_scene* s, drt_scene::Sub& w, hipStream_t st, const double*
     const int n = (int)s->n_faces;
     HIP_TRY(hipMemsetAsync(w.big_count, 0, sizeof(unsigned), st));
     if (trusted) k_check_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, trusted, w.vmodel,           // models of an earlier call: lattice re-checked,
-                                                        s->grid_canary ? (++s->canary_salt ? s->canary_salt : ++s->canary_salt) : 0u);   // + 64 rays at this call's random pixels
+                                                        s->grid_canary ? (++s->canary_salt ? s->canary_salt : ++s->canary_salt) : 0u,    // + 64 rays at this call's random pixels
+                                                        s->vcount + 3);                                                                  //   (device counter: moves on under graph replay too)
     else k_fit_views<<<n_views, 64, 0, st>>>(d_origin, d_dir, iw, ih, w.vmodel);
     if (n > 0) {
         for (int pass = 0; pass < 2; ++pass) {

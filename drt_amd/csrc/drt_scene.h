@@ -165,7 +165,7 @@ struct drt_scene {
     Prefill prefill[3];
     int n_prefill = 0;
     hipEvent_t prefill_fork = nullptr, prefill_done = nullptr, prefill_done_cap = nullptr;   // (_cap: stands in for prefill_done inside a captured render call)
-    unsigned* vcount = nullptr;    // [0] valid rays of the whole call, [1] silhouette items of drt_vh_loss_fused
+    unsigned* vcount = nullptr;    // [0] valid rays of the whole call, [1] silhouette items of drt_vh_loss_fused, [3] canary counter bumped by every k_check_views launch
     uint32_t* vh_list = nullptr;   // (view, edge) items of drt_vh_loss_fused: its own buffer, so that the call may run on
     int64_t vh_cap = 0;            //   another stream than a pipeline call (which owns the Sub workspaces)
     // optional per-stage timing (drt_profile_*): hipEvent pairs on the launch stream

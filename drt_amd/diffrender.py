@@ -29,20 +29,11 @@ import numpy as np
 import torch
 
 from . import _lib, det, mesh_io
+from ._util import _f64c, _flag_bytes, _stats, _warn_once, _warned  # noqa: F401
 from .optix_mesh import optix_mesh, _stream, _on
 from .stepwise import Intersection, StepwiseMixin  # noqa: F401  (Dintersect / refract_ray / trace2 / project_vert)
-
-# What the caches below did since import (or since cache_report(reset=True)): cache_report().  They are transparent by design -- a call that
-# cannot use one simply takes the slower path -- so this is where a caller sees WHICH path its calls took, and why.
-_stats = collections.Counter()
-_warned = set()
-
-
-def _warn_once(key, msg):
-    if key not in _warned:
-        _warned.add(key)
-        warnings.warn("drt_amd.diffrender: " + msg, RuntimeWarning, stacklevel=3)
-
+from .silhouette import (LazyColumn, LazyDiff, LazyGather, LazyIndex, LazyOutput, LazySum, LazyTerm, SampleSet, SilhouetteEdges,  # noqa: F401
+                         _Dihedral, _EdgeSample, _SmLossFused, _VhLossFused, _VhTermLazy, force, pack_camera)
 
 def cache_report(reset=False):
     """Counters of the transparent caches of this module: grid verdict cache (`grid_trust` calls that relied on a verdict, `grid_establish`
@@ -90,17 +81,6 @@ def _tile_hint(n_rays):
     if resx >= 64 and resx % 64 == 0 and resy % 4 == 0 and n_rays % (resx * resy) == 0:
         return int(resx), int(resy)
     return 0, 0
-
-
-def _flag_bytes(t, name, n):
-    """bool / uint8 [n] flags as a contiguous uint8 view (the kernels read them with 4-byte packed loads)."""
-    if t.dtype not in (torch.bool, torch.uint8):
-        raise RuntimeError(f"{name} must be bool or uint8, got {t.dtype}")
-    if not t.is_cuda:
-        raise RuntimeError(f"{name} must be a GPU tensor")
-    if t.numel() != n:
-        raise RuntimeError(f"{name} must have {n} elements, got {t.numel()}")
-    return t.contiguous().view(torch.uint8)
 
 
 DENSE_FACE_IDS = False  # True: Scene.last_face1 / last_face2 hold -1 for every ray without a hit (diagnostics, tests); False: only the entries of
@@ -184,12 +164,77 @@ def _grid_cache(origin, ray_dir, n, w, h):
     return 1, cache
 
 
-def _f64c(t, name):
-    if t.dtype != torch.float64:
-        raise RuntimeError(f"{name} must be float64, got {t.dtype}")
-    if not t.is_cuda:
-        raise RuntimeError(f"{name} must be a GPU tensor")
-    return t.contiguous()
+class RayBinding:
+    """An explicit handle for the rays of a capture (round 6): ``handle = scene.bind_rays(origin, ray_dir[, screen_pixel, valid])``, then
+    ``scene.render_transparent(handle)`` every iteration.  The reference hands its loop fresh copies of constant tensors per call
+    (captured_data.py:44-59); the drop-in signature therefore has to RECOGNISE constants (tensor identity, version counters, storage use
+    counts: `_grid_cache`, `_OutputPool` below).  A caller that can say so instead gets the same fast path by CONTRACT:
+
+      * the bound tensors are constants -- whether their images are pinhole grids is established on the device by the first call and
+        trusted afterwards (still re-checked per call on the 8 x 8 lattice + 64 canary rays per image; an in-place write bumps the version
+        counter and re-establishes);
+      * the handle OWNS one set of dense outputs: the tensors a call returns -- and the autograd graph behind them -- are valid until the NEXT
+        ``render_transparent(handle)``; that call zeroes the rows this one set (55 B per completed path instead of a 51 B-per-ray fill)
+        and renders into the same memory.  ``backward()`` of a call whose outputs were recycled raises.  No storage use counts, no
+        private torch API, works the same inside a graph capture (replay = recycle);
+      * targets bound with the rays are known to be complete before any render call: the loss + gradient pass may start on the first
+        sub-batch while the second is still tracing (SPLIT_LOSS) without the identity bookkeeping of `_targets_seen_before`."""
+
+    class Shared:
+        """The output set(s) and call counter of one handle -- or of several handles that agree to share them (``shared=``: the views of one
+        capture, rendered one per iteration: a call on ANY of them recycles the outputs of the previous call on any of them)."""
+
+        def __init__(self):
+            self.sets, self.gen = {}, 0
+
+    def __init__(self, scene, origin, ray_dir, screen_pixel=None, valid=None, shared=None):
+        self.scene = scene
+        self._shared = shared if shared is not None else RayBinding.Shared()
+        self.origin, self.ray_dir = _f64c(origin.detach(), "origin"), _f64c(ray_dir.detach(), "ray_dir")
+        if self.origin.shape != self.ray_dir.shape or self.origin.dim() != 2 or self.origin.shape[1] != 3:
+            raise RuntimeError("bind_rays: origin and ray_dir must both be float64 [N, 3]")
+        self.n = self.origin.shape[0]
+        self.targets = (screen_pixel, valid) if screen_pixel is not None else None
+        self._cache = self._verdict = self._versions = self._seed = self._hint = None
+
+    def _grid(self):
+        """(grid_mode, verdict cache, hit seeds) of the next render call on the bound rays."""
+        w, h = _tile_hint(self.n)
+        versions = (self.origin._version, self.ray_dir._version, w, h)
+        if not GRID_CACHE or w <= 0 or self.n == 0:
+            return 0, None
+        if self._cache is None or versions != self._versions:
+            self._cache = torch.zeros((self.n // (w * h)) * _GRID_BYTES, dtype=torch.uint8, device=self.ray_dir.device)
+            self._versions, self._verdict = versions, None
+            _stats["grid_establish"] += 1
+            return 1, self._cache
+        if self._verdict is None and not torch.cuda.is_current_stream_capturing():
+            flags = self._cache.view(-1, _GRID_BYTES)[:, 96:104].contiguous().view(torch.int32)
+            self._verdict = bool((flags != 0).all().item())          # one host sync per handle, ever
+        _stats["grid_trust"] += 1
+        if HIT_SEED and self._seed is None and not torch.cuda.is_current_stream_capturing():
+            self._seed = torch.full((self.n,), -1, dtype=torch.int32, device=self.ray_dir.device)
+        return 2 | (32 if self._verdict else 0), self._cache, (self._seed if HIT_SEED else None)
+
+    def _outputs(self):
+        """The handle's output set, in the layout of an _OutputPool entry; zero-filled once."""
+        dev, sets = self.origin.device, self._shared.sets
+        ent = sets.get((self.n, dev))
+        if ent is None:
+            n = self.n
+            bases = (torch.zeros((n, 3), dtype=torch.float64, device=dev), torch.zeros((n, 3), dtype=torch.float64, device=dev),
+                     torch.zeros((n, 3), dtype=torch.uint8, device=dev))
+            ent = sets[(n, dev)] = [n, dev, None, bases, None, torch.empty(n, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)]
+        return ent
+
+    @property
+    def gen(self):
+        """render calls made on this handle (or the handles it shares outputs with): what the autograd graph of an EARLIER call checks in its backward"""
+        return self._shared.gen
+
+    def release(self):
+        self._shared.sets.clear()
+        self._shared.gen += 1
 
 
 # ray_loss's gradient w.r.t. out_dir is zero in all but a few per cent of the rows.  When the out_dir handed to
@@ -300,6 +345,7 @@ class _GradLink:
         self.mask = None
         self.out_ori = None
         self.render = None      # (scene handle owner, vertices, origin, ray_dir, face1, face2, (ior_int, ior_ext)) of the forward call
+        self.targets = None     # (screen_pixel, valid) bound with the rays (RayBinding): complete before any render call on the handle
 
     def token(self, n, device):
         if self._token is None or self._token.shape[0] != n:
@@ -315,8 +361,9 @@ class _RenderTransparent(torch.autograd.Function):
     """render_transparent as a function of the vertices (the reference's implicit input)."""
 
     @staticmethod
-    def forward(ctx, vertices, origin, ray_dir, scene, ior_int, ior_ext, link, grid=(0, None)):
+    def forward(ctx, vertices, origin, ray_dir, scene, ior_int, ior_ext, link, grid=(0, None), binding=None):
         ctx.link = link
+        ctx.binding = binding
         v = _f64c(vertices.detach(), "vertices")
         o = _f64c(origin.detach(), "origin")
         d = _f64c(ray_dir.detach(), "ray_dir")
@@ -324,7 +371,7 @@ class _RenderTransparent(torch.autograd.Function):
         om = scene.optix_mesh            # owns the buffers zeroed ahead of time: its drt_destroy waits for the zeroing before they are released
         capturing = torch.cuda.is_current_stream_capturing()
         need_bwd = ctx.needs_input_grad[0]
-        recycle = RECYCLE_OUTPUTS and n >= RECYCLE_MIN_RAYS                        # (any grid mode: a call that verifies every ray -- no cache, or the
+        recycle = binding is not None or (RECYCLE_OUTPUTS and n >= RECYCLE_MIN_RAYS)  # (any grid mode: a call that verifies every ray -- no cache, or the
                                                                                   #  establishing one -- then at least does not write the dead rows again)
         # Inside a graph capture: REPLAY = RECYCLE.  A set the eager warm-up calls left in the pool is taken out of it for good and becomes the
         # graph's static outputs; the captured call zeroes the rows of the set's row list and then writes ITS list into those very buffers, so
@@ -343,7 +390,16 @@ class _RenderTransparent(torch.autograd.Function):
         bases = counts = None
         if not recycle and RECYCLE_OUTPUTS:
             _stats["recycle_off_small"] += 1
-        if recycle:
+        ent = None
+        if binding is not None:
+            # the handle's own set, by contract (RayBinding): the same path a captured call takes with a pooled set -- this call's list goes where
+            # its predecessor's was, the set never enters the pool
+            graph_set = ent = binding._outputs()
+            bases, counts = ent[3], ent[4]
+            binding._shared.gen += 1
+            ctx.binding_gen = binding.gen
+            _stats["recycle_bound"] += 1
+        elif recycle:
             pool = getattr(om, "_out_pool", None)
             if pool is None:
                 pool = om._out_pool = _OutputPool()
@@ -354,11 +410,7 @@ class _RenderTransparent(torch.autograd.Function):
                 if ent is None:
                     recycle = False
                 else:
-                    graph_set = ent
-                    sets = getattr(om, "_graph_sets", None)
-                    if sets is None:
-                        sets = om._graph_sets = []
-                    sets.append(ent)                     # alive as long as the scene: the graph's replays read and write these buffers
+                    graph_set = ent                      # (registered in om._graph_sets once the captured call has gone through)
             else:
                 _stats["recycle_take" if ent is not None else ("recycle_miss_held" if any(e[0] == n for e in pool.entries) else "recycle_miss_empty")] += 1
             if ent is not None:
@@ -415,7 +467,16 @@ class _RenderTransparent(torch.autograd.Function):
                     _lib.ptr(valid_idx), _lib.ptr(n_valid), *_tile_hint(n), grid[0] | (0 if DENSE_FACE_IDS else 16), _lib.ptr(grid[1]), stream_id))
             except BaseException:
                 _lib.lib().drt_outputs_cancel(om._h)
+                if graph_set is not None and binding is None:      # the capture failed: the set goes back to the pool, the caller falls back to eager calls
+                    om._out_pool.entries.append(graph_set)
+                if binding is not None:
+                    binding.release()                    # (whatever state the failed call left its set in: the next call starts from fresh zeros)
                 raise
+            if graph_set is not None and binding is None:
+                sets = getattr(om, "_graph_sets", None)
+                if sets is None:
+                    sets = om._graph_sets = []
+                sets.append(graph_set)                   # alive as long as the scene (release_outputs(graph_sets=True)): the graph's replays read and write these buffers
             # (with recycling on: only for a caller who evidently KEEPS its outputs -- the pool had nothing to offer for this call and for the one
             # before it; the steady state of a loop that drops them never gets here)
             missed, om._recycle_missed = getattr(om, "_recycle_missed", 0), (0 if took is not None or not recycle else getattr(om, "_recycle_missed", 0) + 1)
@@ -454,6 +515,9 @@ class _RenderTransparent(torch.autograd.Function):
     def backward(ctx, g_ori, g_dir, g_mask):
         v, o, d, face1, face2, valid_idx, n_valid = ctx.saved_tensors
         link = ctx.link
+        if ctx.binding is not None and ctx.binding.gen != ctx.binding_gen and (g_ori is not None or (g_dir is not None and not link.is_token(g_dir)) or any(e[0] is not None for e in link.pending)):
+            raise RuntimeError("render_transparent(binding): the outputs of this call (and the list of its completed paths) were recycled by a later "
+                               "call on the same RayBinding -- run backward() before the next render_transparent(handle), or render without a handle")
         pending, link.pending = link.pending, []
         if g_dir is not None and link.is_token(g_dir):
             g_dir = None                        # ray_loss's placeholder: its gradient is in `pending`
@@ -479,7 +543,7 @@ class _RenderTransparent(torch.autograd.Function):
         for rows, stash, _, scale in pending:
             if rows is None:
                 grad_v = torch.addcmul(grad_v, stash, scale) if grad_v is not None else stash * scale
-        return grad_v, None, None, None, None, None, None, None
+        return grad_v, None, None, None, None, None, None, None, None
 
 
 class _RayLoss(torch.autograd.Function):
@@ -509,7 +573,8 @@ class _RayLoss(torch.autograd.Function):
                 # loss + unit-seed vertex gradient in one pass over the completed paths (see EAGER_LOSS_GRAD)
                 scene, v, o, d, face1, face2, ior = link.render
                 pre, link.pre = link.pre, None
-                early = pre is not None and _targets_seen_before(screen_pixel, valid, link.seq) and sp.data_ptr() == screen_pixel.data_ptr() and va.data_ptr() == valid.data_ptr()
+                bound = link.targets is not None and link.targets[0] is screen_pixel and link.targets[1] is valid
+                early = pre is not None and (bound or _targets_seen_before(screen_pixel, valid, link.seq)) and sp.data_ptr() == screen_pixel.data_ptr() and va.data_ptr() == valid.data_ptr()
                 if early:      # accumulators zeroed before the render call: the head of the list can be processed beside the pipelines (SPLIT_LOSS)
                     ctx.stash, loss = pre
                 else:
@@ -643,6 +708,7 @@ class Scene(StepwiseMixin):
         self.cuda_device = int(cuda_device)
         self.optix_mesh = optix_mesh(self.cuda_device)
         self._mesh_stale = False
+        self._epoch = 0          # bumped by every change of vertices / mesh: what a lazy result (SampleSet) is tied to
         self.update_mesh(mesh_path)
 
     # ------------------------------------------------------------------ mesh state
@@ -654,6 +720,7 @@ class Scene(StepwiseMixin):
         mesh = mesh_path if isinstance(mesh_path, mesh_io.TriMesh) else mesh_io.load(mesh_path, process=False)
         self._mesh = mesh
         self._mesh_stale = False
+        self._epoch += 1
         self.vertices = torch.tensor(mesh.vertices, dtype=Float, device=self._dev)
         self.faces = torch.tensor(mesh.faces, dtype=torch.long, device=self._dev)
         self.init_edge()                                  # also the watertightness assert of DiffRender.py:305
@@ -680,6 +747,7 @@ class Scene(StepwiseMixin):
 
     def _set_topology(self, vertices, faces):
         """Install device-resident vertices / faces as the new mesh (host record synced lazily, see `mesh`)."""
+        self._epoch += 1
         self.vertices, self.faces = vertices, faces
         self._mesh = mesh_io.TriMesh(np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64))
         self._mesh_stale = self._faces_stale = True
@@ -705,6 +773,7 @@ class Scene(StepwiseMixin):
     def update_verticex(self, vertices: torch.Tensor):
         if vertices.shape != self.vertices.shape:
             raise RuntimeError(f"vertices must have shape {tuple(self.vertices.shape)}")
+        self._epoch += 1
         self.vertices = vertices
         self.optix_mesh.update_vert_f64(vertices)
         self._mesh_stale = True
@@ -719,9 +788,12 @@ class Scene(StepwiseMixin):
         optix_ray = torch.cat([origin.detach().to(torch.float32), ray_dir.detach().to(torch.float32)], dim=1)
         return self.optix_mesh.intersect_any(optix_ray).to(Float)
 
-    def release_outputs(self):
+    def release_outputs(self, graph_sets=False):
         """Drops the dense outputs this scene keeps for re-use (RECYCLE_OUTPUTS: up to two sets of 55 B per ray) and the buffers zeroed
-        ahead of time (PREFILL_NEXT); the next render call allocates and fills fresh ones."""
+        ahead of time (PREFILL_NEXT); the next render call allocates and fills fresh ones.
+        ``graph_sets=True`` also drops the output sets that CAPTURED render calls took for good (a graph's replays read and write those
+        buffers: they were allocated before the capture, so the graph's own memory pool does not keep them alive) -- only legal once every
+        graph captured on this scene has been destroyed; left alone (the default) they live as long as the scene."""
         om = self.optix_mesh
         with _on(self._dev):
             _lib.check(_lib.lib().drt_outputs_cancel(om._h))
@@ -731,13 +803,24 @@ class Scene(StepwiseMixin):
         pool = getattr(om, "_out_pool", None)
         if pool is not None:
             pool.entries.clear()
-        om._graph_sets = []              # (only once every graph captured on this scene has been dropped: their replays use these buffers)
+        if graph_sets:
+            om._graph_sets = []
 
     # ------------------------------------------------------------------ refraction path
-    def render_transparent(self, origin: torch.Tensor, ray_dir: torch.Tensor):
+    def bind_rays(self, origin, ray_dir, screen_pixel=None, valid=None, shared=None):
+        """A handle for constant rays (and, optionally, their constant targets): see RayBinding.  ``render_transparent(handle)``."""
+        return RayBinding(self, origin, ray_dir, screen_pixel, valid, shared)
+
+    def render_transparent(self, origin, ray_dir=None):
         link = _GradLink()
-        grid = _grid_cache(origin, ray_dir, origin.shape[0], *_tile_hint(origin.shape[0])) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
-        out_ori, out_dir, mask = _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR, link, grid)
+        binding = origin if isinstance(origin, RayBinding) else None
+        if binding is not None:
+            origin, ray_dir = binding.origin, binding.ray_dir
+            grid = binding._grid()
+            link.targets = binding.targets
+        else:
+            grid = _grid_cache(origin, ray_dir, origin.shape[0], *_tile_hint(origin.shape[0])) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
+        out_ori, out_dir, mask = _RenderTransparent.apply(self.vertices, origin, ray_dir, self, intIOR, extIOR, link, grid, binding)
         out_dir._drt_link = link            # lets ray_loss hand its gradient over as a row list (see _GradLink)
         link.mask = weakref.ref(mask)
         link.out_ori = weakref.ref(out_ori)
@@ -745,6 +828,9 @@ class Scene(StepwiseMixin):
 
     def ray_loss_fused(self, origin, ray_dir, screen_pixel, valid):
         """ray_loss of this view without materialising out_ori/out_dir/mask."""
+        if isinstance(origin, RayBinding):
+            b = origin
+            return _RenderRayLossFused.apply(self.vertices, b.origin, b.ray_dir, screen_pixel, valid, self, intIOR, extIOR, b._grid())
         grid = _grid_cache(origin, ray_dir, origin.shape[0], *_tile_hint(origin.shape[0])) if origin.is_contiguous() and ray_dir.is_contiguous() else (0, None)
         return _RenderRayLossFused.apply(self.vertices, origin, ray_dir, screen_pixel, valid, self, intIOR, extIOR, grid)
 
@@ -760,6 +846,8 @@ class Scene(StepwiseMixin):
     # ------------------------------------------------------------------ silhouette branch
     def silhouette_edge(self, origin: torch.Tensor):
         assert origin.dim() == 1
+        if LAZY_SILHOUETTE and not torch.cuda.is_current_stream_capturing():
+            return SilhouetteEdges(self.Edges, None, scene=self, origin=origin)       # (flags and edge set computed when somebody needs them)
         v = _f64c(self.vertices.detach(), "vertices")
         o = _f64c(origin.detach(), "origin")
         n = self.E2F.shape[0]
@@ -772,14 +860,15 @@ class Scene(StepwiseMixin):
 
     def primary_visibility(self, silhouette_edge, camera_M, origin, detach_depth=False):
         """(index int64 [M,2] (x, y), output float32 [M]) of the in-view silhouette samples (DiffRender.py:459-479)."""
-        if isinstance(silhouette_edge, SilhouetteEdges):      # (unwrapped here: autograd.Function.apply should see plain tensors / tuples)
-            silhouette_edge = (silhouette_edge._edges, silhouette_edge._flags) if silhouette_edge._t is None else silhouette_edge.tensor()
-        if LAZY_VISIBILITY and isinstance(silhouette_edge, tuple) and not torch.cuda.is_current_stream_capturing():
-            # The samples are computed NOW (projection, probe rays: the geometry of this call), their compaction -- a boolean index, i.e. a
-            # device->host round trip per view -- only if somebody looks at them: the reference's loop feeds the pair straight into
-            # `(mask.view(resy, resx)[index[:, 1], index[:, 0]] - output).abs().sum()` (optim.py:78), which SampleSet evaluates in place.
+        lazy_ok = LAZY_VISIBILITY and not torch.cuda.is_current_stream_capturing()
+        if isinstance(silhouette_edge, SilhouetteEdges) and silhouette_edge._t is None and lazy_ok:
+            # NOTHING is computed now: the reference's loop feeds the pair straight into `(mask.view(resy, resx)[index[:, 1], index[:, 0]] -
+            # output).abs().sum()` (optim.py:78) and adds the views' terms up (optim.py:72-80) -- SampleSet / LazySum evaluate that sum with one
+            # fused launch; anything else that looks at the pair gets the sampling kernel, the compaction and the reference's tensors.
             ss = SampleSet(self, self.vertices, silhouette_edge, camera_M, origin, bool(detach_depth), int(resx), int(resy))
             return LazyIndex(ss), LazyOutput(ss)
+        if isinstance(silhouette_edge, SilhouetteEdges):      # (unwrapped here: autograd.Function.apply should see plain tensors / tuples)
+            silhouette_edge = (silhouette_edge._edges, silhouette_edge._flags) if silhouette_edge._t is None else silhouette_edge.tensor()
         return _EdgeSample.apply(self.vertices, silhouette_edge, camera_M, origin, self, bool(detach_depth), int(resx), int(resy))
 
     def vh_loss_fused(self, camera_M, origin, soft_mask):
@@ -793,388 +882,12 @@ class Scene(StepwiseMixin):
         flat = []
         for camera_M, origin, soft_mask in views:
             flat += [pack_camera(camera_M), origin, soft_mask]
-        return _VhLossFused.apply(self.vertices, self, int(resx), int(resy), *flat)
-
-
-
-_camera_cache = {}
-
-
-def pack_camera(camera_M):
-    """camera_M = (R 4x4, K 3x3, R^-1, K^-1) -> one float64 [50] device tensor (layout of drt_edge.h Camera).
-    Cached per camera tuple (keyed on the identity and in-place version of its four tensors): a capture's
-    cameras are constants and the silhouette loss packs eight of them per iteration."""
-    key = tuple(id(t) for t in camera_M)
-    ent = _camera_cache.get(key)
-    if ent is not None and all(r() is t and ver == t._version for r, ver, t in zip(ent[0], ent[1], camera_M)):
-        return ent[2]
-    R, K, R_inverse, K_inverse = camera_M
-    packed = torch.cat([R.reshape(-1), K.reshape(-1), R_inverse.reshape(-1), K_inverse.reshape(-1)]).to(torch.float64).contiguous()
-    if len(_camera_cache) > 4096:
-        _camera_cache.clear()
-    _camera_cache[key] = (tuple(weakref.ref(t) for t in camera_M), tuple(t._version for t in camera_M), packed)
-    return packed
+        return _VhLossFused.apply(self.vertices, self, int(resx), int(resy), True, *flat)
 
 
 LAZY_SILHOUETTE = True
-
-
-class SilhouetteEdges:
-    """What ``Scene.silhouette_edge`` returns: the int64 [Es,2] tensor ``Edges[flags]`` of the reference (DiffRender.py:445-457), materialised
-    only when somebody looks at it.  The reference's loop hands it straight to ``primary_visibility`` (optim.py:76-77), which here reads
-    the per-edge flags on the device instead -- so that the boolean-mask indexing, a device->host synchronisation per silhouette view, never
-    happens.  Anything else (indexing, ``len``, ``.shape``, torch functions, attribute access) sees the materialised tensor."""
-
-    def __init__(self, edges, flags):
-        self._edges, self._flags, self._t = edges, flags, None
-
-    def tensor(self):
-        if self._t is None:
-            self._t = self._edges[self._flags.view(torch.bool)]
-        return self._t
-
-    def __getattr__(self, name):                     # (only reached for names this object does not define itself)
-        if name.startswith("_"):                     # (its own fields, before __init__ has run -- copy / pickle probe for them: no recursion)
-            raise AttributeError(name)
-        return getattr(self.tensor(), name)
-
-    def __getitem__(self, k):
-        return self.tensor()[k]
-
-    def __len__(self):
-        return len(self.tensor())
-
-    def __iter__(self):
-        return iter(self.tensor())
-
-    def __repr__(self):
-        return f"SilhouetteEdges({self.tensor()!r})"
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        un = lambda a: a.tensor() if isinstance(a, SilhouetteEdges) else a
-        args = tuple(un(a) if not isinstance(a, (list, tuple)) else type(a)(un(b) for b in a) for a in args)
-        kwargs = {k: un(v) for k, v in (kwargs or {}).items()}
-        return func(*args, **kwargs)
-
-
+# LAZY_VISIBILITY: primary_visibility returns stand-ins for (index, output) -- see SampleSet.  They behave as the reference's tensors for
+# indexing (incl. assignment), len / shape / dtype / any attribute, operators, torch functions, isinstance(x, torch.Tensor) and
+# torch.is_tensor(x); what they cannot do is pass a C++-level tensor check that does not go through __torch_function__ (torch.compile /
+# torch.jit tracing of the caller's loss, a custom C++ op taking the pair): such callers set LAZY_VISIBILITY = False.
 LAZY_VISIBILITY = os.environ.get("DRT_LAZY_VISIBILITY", "1") != "0"
-
-
-class SampleSet:
-    """The silhouette samples of one ``primary_visibility`` call, left where the kernel wrote them: for ALL E unique edges an index row,
-    f = hit(+) - hit(-) and a `keep` flag (|f| > 1e-5 and inside the view: DiffRender.py:244, 478).  The reference returns the compacted
-    (index [M,2], output [M]); that compaction is ``materialise()`` -- taken by anything that looks at the pair as tensors.  The one
-    expression the reference's loop applies to the pair (optim.py:78) is recognised step by step by the lazy objects below and evaluated by
-    ``term()`` over the uncompacted rows: same samples, same terms, a float64 sum in another order."""
-
-    def __init__(self, scene, vertices, sil, camera_M, origin, detach_depth, res_x, res_y):
-        self.scene, self.vertices, self.sil, self.camera_M, self.origin = scene, vertices, sil, camera_M, origin
-        self.detach_depth, self.res_x, self.res_y = detach_depth, res_x, res_y
-        self.v = _f64c(vertices.detach(), "vertices")
-        edges, flags = sil
-        self.edges = edges.contiguous()
-        assert self.edges.dtype == torch.long and self.edges.dim() == 2 and self.edges.shape[1] == 2
-        self.cam = pack_camera(camera_M)
-        o = _f64c(origin.detach(), "origin")
-        n = self.edges.shape[0]
-        dev = self.v.device
-        w8 = torch.empty(3 * n, dtype=torch.long, device=dev)           # (two allocations instead of four: index | d term / d output ; f | keep)
-        w1 = torch.empty(5 * n, dtype=torch.uint8, device=dev)
-        self.index, self.dterm = w8[:2 * n].view(n, 2), w8[2 * n:].view(torch.float64)
-        self.f, self.keep = w1[:4 * n].view(torch.float32), w1[4 * n:]
-        with _on(dev):
-            _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, self.v.data_ptr(), self.edges.data_ptr(), n, self.cam.data_ptr(),
-                                                          o.data_ptr(), self.index.data_ptr(), self.f.data_ptr(), self.keep.data_ptr(), res_x, res_y,
-                                                          _lib.ptr(flags), _stream()))
-        self._pair = None
-        _stats["visibility_lazy"] += 1
-
-    def materialise(self):
-        """(index int64 [M,2], output float32 [M]) as the reference returns them, differentiable w.r.t. the vertices."""
-        if self._pair is None:
-            _stats["visibility_materialised"] += 1
-            self._pair = _EdgeSample.apply(self.vertices, self.sil, self.camera_M, self.origin, self.scene, self.detach_depth, self.res_x, self.res_y,
-                                           (self.index, self.f, self.keep))
-        return self._pair
-
-    def term(self, image):
-        """sum |image[y, x] - output| over the samples (optim.py:78), a scalar differentiable w.r.t. the vertices."""
-        _stats["visibility_term_in_place"] += 1
-        return _VhTermLazy.apply(self.vertices, self, image)
-
-
-class _LazyTensor:
-    """A stand-in that behaves as the tensor ``self.tensor()`` for everything it does not recognise."""
-
-    def __getattr__(self, name):
-        if name.startswith("_"):
-            raise AttributeError(name)
-        return getattr(self.tensor(), name)
-
-    def __getitem__(self, k):
-        return self.tensor()[k]
-
-    def __len__(self):
-        return len(self.tensor())
-
-    def __iter__(self):
-        return iter(self.tensor())
-
-    def __repr__(self):
-        return f"{type(self).__name__}({self.tensor()!r})"
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], tuple) and len(args[1]) == 2:
-            # image[index[:, 1], index[:, 0]]  (optim.py:78)
-            img, (iy, ix) = args
-            if (isinstance(iy, LazyColumn) and isinstance(ix, LazyColumn) and iy._ss is ix._ss and (iy._col, ix._col) == (1, 0) and isinstance(img, torch.Tensor)
-                    and img.dim() == 2 and img.shape == (iy._ss.res_y, iy._ss.res_x) and img.dtype == torch.float64 and img.is_cuda and img.is_contiguous()
-                    and not img.requires_grad and iy._ss._pair is None):
-                return LazyGather(iy._ss, img)
-        un = _unlazy
-        return func(*un(args), **{k: un(v) for k, v in (kwargs or {}).items()})
-
-
-def _delegate(name):
-    def op(self, *args, **kwargs):
-        return getattr(self.tensor(), name)(*_unlazy(args), **{k: _unlazy(v) for k, v in kwargs.items()})
-    op.__name__ = name
-    return op
-
-
-# operators are looked up on the TYPE, not through __getattr__: every one a tensor has goes to the materialised tensor
-for _name in ("add radd sub rsub mul rmul truediv rtruediv floordiv rfloordiv mod rmod pow rpow matmul rmatmul neg pos abs invert and rand or ror xor rxor "
-              "lshift rshift eq ne lt le gt ge bool float int index contains").split():
-    if not hasattr(_LazyTensor, f"__{_name}__") or _name in ("eq", "ne", "lt", "le", "gt", "ge"):
-        setattr(_LazyTensor, f"__{_name}__", _delegate(f"__{_name}__"))
-_LazyTensor.__hash__ = lambda self: id(self)
-
-
-def _unlazy(a):
-    if isinstance(a, _LazyTensor):
-        return a.tensor()
-    if isinstance(a, (list, tuple)):
-        return type(a)(_unlazy(b) for b in a)
-    return a
-
-
-class LazyIndex(_LazyTensor):
-    def __init__(self, ss):
-        self._ss = ss
-
-    def tensor(self):
-        return self._ss.materialise()[0]
-
-    def __getitem__(self, k):
-        if (isinstance(k, tuple) and len(k) == 2 and isinstance(k[0], slice) and k[0] == slice(None) and type(k[1]) is int and k[1] in (0, 1)
-                and self._ss._pair is None):
-            return LazyColumn(self._ss, k[1])
-        return self.tensor()[k]
-
-
-class LazyColumn(_LazyTensor):
-    def __init__(self, ss, col):
-        self._ss, self._col = ss, col
-
-    def tensor(self):
-        return self._ss.materialise()[0][:, self._col]
-
-
-class LazyOutput(_LazyTensor):
-    def __init__(self, ss):
-        self._ss = ss
-
-    def tensor(self):
-        return self._ss.materialise()[1]
-
-
-class LazyGather(_LazyTensor):
-    """image[index[:, 1], index[:, 0]]"""
-
-    def __init__(self, ss, image):
-        self._ss, self._image = ss, image
-
-    def tensor(self):
-        idx = self._ss.materialise()[0]
-        return self._image[idx[:, 1], idx[:, 0]]
-
-    def __sub__(self, other):
-        if isinstance(other, LazyOutput) and other._ss is self._ss and self._ss._pair is None:
-            return LazyDiff(self._ss, self._image, 0)
-        return self.tensor() - _unlazy(other)
-
-
-class LazyDiff(_LazyTensor):
-    """image[...] - output (stage 0), its .abs() (stage 1); .sum() of stage 1 is SampleSet.term."""
-
-    def __init__(self, ss, image, stage):
-        self._ss, self._image, self._stage = ss, image, stage
-
-    def tensor(self):
-        idx, out = self._ss.materialise()
-        d = self._image[idx[:, 1], idx[:, 0]] - out
-        return d.abs() if self._stage else d
-
-    def abs(self):
-        if self._stage == 0 and self._ss._pair is None:
-            return LazyDiff(self._ss, self._image, 1)
-        return self.tensor().abs()
-
-    def sum(self, *args, **kwargs):
-        if self._stage == 1 and not args and not kwargs and self._ss._pair is None:
-            return self._ss.term(self._image)
-        return self.tensor().sum(*args, **kwargs)
-
-
-class _VhTermLazy(torch.autograd.Function):
-    """sum over the kept samples of |image[y, x] - 0.5| as a function of the vertices (SampleSet.term)."""
-
-    @staticmethod
-    def forward(ctx, vertices, ss, image):
-        n = ss.edges.shape[0]
-        dev = ss.v.device
-        loss = det.scalar(dev)
-        dterm = ss.dterm
-        with _on(dev):
-            _lib.check(_lib.lib().drt_vh_term(ss.index.data_ptr(), ss.keep.data_ptr(), n, image.data_ptr(), ss.res_x, ss.res_y,
-                                              loss.data_ptr(), dterm.data_ptr(), _stream()))
-        ctx.ss = ss
-        ctx.save_for_backward(dterm)
-        return det.value(loss)
-
-    @staticmethod
-    def backward(ctx, g_loss):
-        (dterm,) = ctx.saved_tensors
-        ss = ctx.ss
-        grad_v = det.acc(ss.v)
-        # (the reference's `output` is float32: the incoming gradient reaches primary_edge_sample.backward rounded to float32, DiffRender.py:251, 263-267)
-        g = g_loss if (g_loss.dtype == torch.float64 and g_loss.is_cuda and g_loss.numel() == 1) else g_loss.to(device=ss.v.device, dtype=torch.float64).reshape(1)
-        with _on(ss.v.device):
-            _lib.check(_lib.lib().drt_edge_sample_backward_term(ss.v.data_ptr(), ss.edges.data_ptr(), ss.edges.shape[0], ss.cam.data_ptr(), ss.f.data_ptr(),
-                                                                dterm.data_ptr(), g.data_ptr(), int(ss.detach_depth), grad_v.data_ptr(), _stream()))
-        return det.value(grad_v, ss.v), None, None
-
-
-class _Dihedral(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, vertices, E2F):
-        v = _f64c(vertices.detach(), "vertices")
-        e2f = E2F.contiguous()
-        assert e2f.dtype == torch.long and e2f.shape[1:] == (2, 3)
-        n = e2f.shape[0]
-        out = torch.empty(n, dtype=torch.float64, device=v.device)
-        with _on(v.device):
-            _lib.check(_lib.lib().drt_dihedral_forward(v.data_ptr(), e2f.data_ptr(), n, out.data_ptr(), _stream()))
-        ctx.save_for_backward(v, e2f)
-        return out
-
-    @staticmethod
-    def backward(ctx, g_cos):
-        v, e2f = ctx.saved_tensors
-        grad_v = det.acc(v)
-        g = _f64c(g_cos, "grad")
-        with _on(v.device):
-            _lib.check(_lib.lib().drt_dihedral_backward(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], g.data_ptr(), grad_v.data_ptr(), _stream()))
-        return det.value(grad_v, v), None
-
-
-class _SmLossFused(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, vertices, E2F):
-        v = _f64c(vertices.detach(), "vertices")
-        e2f = E2F.contiguous()
-        loss = det.scalar(v.device)
-        grad_v = det.acc(v)
-        with _on(v.device):
-            _lib.check(_lib.lib().drt_sm_loss_fused(v.data_ptr(), e2f.data_ptr(), e2f.shape[0], loss.data_ptr(), grad_v.data_ptr(), _stream()))
-        ctx.save_for_backward(det.value(grad_v, v))
-        return det.value(loss)
-
-    @staticmethod
-    def backward(ctx, g_loss):
-        (grad_v,) = ctx.saved_tensors
-        return grad_v * g_loss, None
-
-
-class _EdgeSample(torch.autograd.Function):
-    """primary_visibility's projection + primary_edge_sample (reference DiffRender.py:189-267, 464-475)
-    as one function of the vertices."""
-
-    @staticmethod
-    def forward(ctx, vertices, sil_edges, camera_M, origin, scene, detach_depth, res_x, res_y, computed=None):
-        v = _f64c(vertices.detach(), "vertices")
-        flags = None
-        if isinstance(sil_edges, tuple):
-            # straight from silhouette_edge: every unique edge with its flag, no compaction (and no host round trip) in between
-            edges, flags = sil_edges[0].contiguous(), sil_edges[1]
-        else:
-            edges = sil_edges.contiguous()
-        assert edges.dtype == torch.long and edges.dim() == 2 and edges.shape[1] == 2
-        cam = pack_camera(camera_M)
-        o = _f64c(origin.detach(), "origin")
-        n = edges.shape[0]
-        if computed is not None:           # (a SampleSet that is being materialised: the kernel ran when primary_visibility was called)
-            index, f, keep = computed
-        else:
-            index = torch.empty((n, 2), dtype=torch.long, device=v.device)
-            f = torch.empty(n, dtype=torch.float32, device=v.device)           # (the kernel writes f and keep of every row, 0 for unflagged edges)
-            keep = torch.empty(n, dtype=torch.uint8, device=v.device)
-            with _on(v.device):
-                _lib.check(_lib.lib().drt_edge_sample_forward(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), n, cam.data_ptr(),
-                                                              o.data_ptr(), index.data_ptr(), f.data_ptr(), keep.data_ptr(), int(res_x), int(res_y),
-                                                              _lib.ptr(flags), _stream()))
-        # |f| > 1e-5 (DiffRender.py:244) and inside the view (DiffRender.py:478), decided by the kernel: ONE boolean index, one host sync.
-        # (An ordered compaction by one block of our own in place of the library's three-launch select: 58 us against 34 -- not kept.)
-        sel = torch.nonzero(keep).squeeze(1)             # (the host sync; the row numbers also serve the backward, which then needs none)
-        index = index.index_select(0, sel)
-        output = torch.full((sel.shape[0],), 0.5, device=v.device)   # float32, like the reference (DiffRender.py:251)
-        ctx.mark_non_differentiable(index)
-        ctx.save_for_backward(v, edges, cam, f, sel)
-        ctx.detach_depth = detach_depth
-        return index, output
-
-    @staticmethod
-    def backward(ctx, grad_index, grad_output):
-        v, edges, cam, f, sel = ctx.saved_tensors
-        grad_v = det.acc(v)
-        g = grad_output if grad_output.dtype == torch.float32 and grad_output.is_contiguous() else grad_output.to(torch.float32).contiguous()
-        with _on(v.device):
-            # (the kept rows and their float32 gradients as they are: no zero-filled [Es] coefficient vector, cast and scatter per view)
-            _lib.check(_lib.lib().drt_edge_sample_backward_rows(v.data_ptr(), edges.data_ptr(), edges.shape[0], cam.data_ptr(), f.data_ptr(),
-                                                                sel.data_ptr(), sel.shape[0], g.data_ptr(), int(ctx.detach_depth),
-                                                                grad_v.data_ptr(), _stream()))
-        return det.value(grad_v, v), None, None, None, None, None, None, None, None, None
-
-
-class _VhLossFused(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, vertices, scene, res_x, res_y, *flat):
-        v = _f64c(vertices.detach(), "vertices")
-        loss = det.scalar(v.device)
-        grad_v = det.acc(v)
-        n = len(flat) // 3
-        cams, orgs, softs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
-        keep = []
-        for k in range(n):
-            o = _f64c(flat[3 * k + 1].detach(), "origin")
-            sm = _f64c(flat[3 * k + 2], "soft_mask")
-            assert sm.numel() == res_x * res_y and o.numel() == 3 and flat[3 * k].numel() == 50
-            keep += [o, sm]
-            cams[k], orgs[k], softs[k] = flat[3 * k].data_ptr(), o.data_ptr(), sm.data_ptr()
-        edges, e2f = scene.Edges, scene.E2F
-        with _on(v.device):
-            _lib.check(_lib.lib().drt_vh_loss_fused(scene.optix_mesh._h, v.data_ptr(), edges.data_ptr(), e2f.data_ptr(), e2f.shape[0], n,
-                                                    cams, orgs, softs, res_x, res_y, 1, loss.data_ptr(), grad_v.data_ptr(), _stream()))
-        ctx.save_for_backward(det.value(grad_v, v))
-        ctx.n_in = len(flat)
-        return det.value(loss)
-
-    @staticmethod
-    def backward(ctx, g_loss):
-        (grad_v,) = ctx.saved_tensors
-        # The reference's silhouette samples are a float32 tensor (`output`, torch's default dtype, DiffRender.py:251): autograd casts the
-        # incoming d loss / d output to float32 before primary_edge_sample.backward multiplies it in (DiffRender.py:263-267).  The drop-in
-        # pair does the same by construction; here the scalar is rounded the same way (tests/test_gpu_trajectory.py).
-        return (grad_v * g_loss.to(torch.float32).to(torch.float64), None, None, None) + (None,) * ctx.n_in

@@ -68,8 +68,13 @@ class Loss_calculator:
                 _, _, soft_mask, origin, _, camera_M = self.data.get_view(next(self.silh_view))
                 views.append((camera_M, origin[0], soft_mask))
             return self.scene.vh_loss_fused_views(views)
-        terms = [self._silhouette_term(next(self.silh_view)) for _ in range(self.N_SILHOUETTE_VIEWS)]
-        return torch.stack(terms).sum()
+        # accumulated like the reference does (optim.py:71-78: `vh_loss = 0; vh_loss += term`): with the lazy pair of primary_visibility the
+        # terms are not evaluated one by one -- the sum is ONE fused launch over the eight views, enqueued here (Render.force), i.e. on the
+        # stream this method is called under
+        total = 0
+        for _ in range(self.N_SILHOUETTE_VIEWS):
+            total += self._silhouette_term(next(self.silh_view))
+        return Render.force(total)
 
     def sm_loss(self):
         if self.fused:
@@ -78,7 +83,11 @@ class Loss_calculator:
         return (-torch.log(1 + cos_dihedral)).sum()
 
     def ray_loss(self):
-        target, valid, _, origin, ray_dir, _ = self.data.get_view(next(self.ray_view))
+        view_id = next(self.ray_view)
+        target, valid, _, origin, ray_dir, _ = self.data.get_view(view_id)
+        bind = getattr(self.data, "get_binding", None)       # a capture whose views are resident constants offers a handle per view (RayBinding)
+        if bind is not None:
+            origin, ray_dir = bind(self.scene, view_id), None
         if self.fused:
             return self.scene.ray_loss_fused(origin, ray_dir, target, valid)
         exit_o, exit_d, exit_mask = self.scene.render_transparent(origin, ray_dir)
@@ -370,7 +379,11 @@ def local_loss_backward(scene, local_views, init_vertices, parameter, ray_w, fus
     vertices = init_vertices + parameter
     scene.update_verticex(vertices)
     parts = []
-    for target, valid, origin, ray_dir in local_views:
+    for view in local_views:
+        # (target, valid, origin, ray_dir) -- the tensors of Data.get_view -- or (target, valid, handle) with handle = scene.bind_rays(...):
+        # the explicit form of "these rays are constants" (diffrender.RayBinding)
+        target, valid, origin = view[0], view[1], view[2]
+        ray_dir = view[3] if len(view) > 3 else None
         if fused:
             parts.append(scene.ray_loss_fused(origin, ray_dir, target, valid))
         else:

@@ -199,3 +199,59 @@ def test_loss_started_on_the_first_sub_batch_equals_the_loss_behind_the_join(tmp
     np.testing.assert_allclose(out["split"]["losses"], out["plain"]["losses"], rtol=1e-12)
     a, b = np.array(out["split"]["param"]), np.array(out["plain"]["param"])
     assert np.abs(a).max() > 1e-3 and np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
+
+
+def test_an_explicit_ray_binding_recycles_by_contract_without_the_private_torch_api(setup, monkeypatch):
+    """scene.bind_rays(origin, ray_dir) (diffrender.RayBinding, round 6): the handle owns its outputs and the verdict of its rays, so the
+    fast path -- trusted grids, rows of the previous call zeroed instead of a dense fill -- needs neither torch._C._storage_Use_Count nor the
+    identity heuristics.  Same tensors as fresh outputs, call after call, with moving vertices; loss and gradient equal the plain route's."""
+    Render, mesh, o, d = setup
+    Vs = _moving(mesh, 6)
+    ref = _reference(Render, mesh, Vs, o, d)
+    monkeypatch.delattr(torch._C, "_storage_Use_Count")
+    Render.RECYCLE_OUTPUTS = False                  # (what a torch without the API gives: the module-level switch goes off at import)
+    Render.cache_report(reset=True)
+    scene = Render.Scene(mesh, 0)
+    rng = np.random.default_rng(5)
+    sp = torch.tensor(rng.standard_normal((o.shape[0], 3)) * 40.0 + np.array([0.0, 0.0, 150.0]), device="cuda")
+    valid = torch.tensor(rng.random(o.shape[0]) > 0.1, device="cuda")
+    handle = scene.bind_rays(o, d, sp, valid)
+    ptrs, losses, grads = [], [], []
+    for k, V in enumerate(Vs):
+        Vg = V.clone().requires_grad_(True)
+        scene.update_verticex(Vg)
+        oo, od, mk = scene.render_transparent(handle)
+        ptrs.append(oo.data_ptr())
+        assert torch.equal(mk, ref[k][2]) and torch.equal(oo, ref[k][0]) and torch.equal(od, ref[k][1]), k
+        loss = Render.ray_loss(oo, od, mk, sp, valid)
+        loss.backward()
+        losses.append(float(loss)); grads.append(Vg.grad.clone())
+    rep = Render.cache_report()
+    assert len(set(ptrs)) == 1 and rep.get("recycle_bound", 0) == 6 and rep.get("recycle_take", 0) == 0
+    assert rep.get("grid_establish", 0) == 1 and rep.get("grid_trust", 0) == 5
+    # the plain route (fresh outputs, identity heuristics) on a second scene: same loss and gradient
+    scene2 = Render.Scene(mesh, 0)
+    for k, V in enumerate(Vs):
+        Vg = V.clone().requires_grad_(True)
+        scene2.update_verticex(Vg)
+        oo, od, mk = scene2.render_transparent(o, d)
+        loss = Render.ray_loss(oo, od, mk, sp, valid)
+        loss.backward()
+        assert float(loss) == pytest.approx(losses[k], rel=1e-12)
+        assert float((Vg.grad - grads[k]).abs().max()) <= 1e-12 * float(grads[k].abs().max())
+
+
+def test_backward_through_recycled_outputs_of_a_binding_is_refused(setup):
+    Render, mesh, o, d = setup
+    scene = Render.Scene(mesh, 0)
+    handle = scene.bind_rays(o, d)
+    V = torch.tensor(mesh.vertices, dtype=torch.float64, device="cuda", requires_grad=True)
+    scene.update_verticex(V)
+    oo, od, mk = scene.render_transparent(handle)
+    stale = (od * od).sum()                       # a loss that needs the dense gradient path (not ray_loss's stash)
+    oo2, od2, mk2 = scene.render_transparent(handle)
+    assert oo2.data_ptr() == oo.data_ptr()
+    with pytest.raises(RuntimeError, match="recycled by a later call on the same RayBinding"):
+        stale.backward()
+    (od2 * od2).sum().backward()
+    assert float(V.grad.abs().max()) > 0
