@@ -70,7 +70,7 @@ def test_bench_as_a_whole_step_graph_recycles_its_outputs():
     (config.outputs_recycled)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["DRT_RECYCLE_MIN_RAYS"] = "0"
-    args = ["--steps", "3", "--warmup", "3", "--res", "256", "--views", "8", "--no-cpu-baseline", "--no-extras", "--repeats", "2"]
+    args = ["--steps", "3", "--warmup", "3", "--res", "256", "--views", "8", "--no-cpu-baseline", "--no-extras", "--repeats", "2", "--bind", "0"]      # (the drop-in signature: a pooled set becomes the graph's; the default, a RayBinding, brings its own)
     eager = _run([sys.executable, "bench.py", "--gpus", "1", "--graph", "0"] + args, env)
     graph = _run([sys.executable, "bench.py", "--gpus", "1", "--graph", "1"] + args, env)
     assert eager["config"]["hip_graph"] is False and eager["config"]["outputs_recycled"] is True
@@ -80,3 +80,23 @@ def test_bench_as_a_whole_step_graph_recycles_its_outputs():
     a, b = eager["config"]["final_loss"], graph["config"]["final_loss"]
     assert 0 < b < a, (a, b)          # (more steps taken: further down the same descent)
     assert graph["repeats"]["n"] == 2 and len(graph["repeats"]["ms_per_step"]) == 2
+
+
+def test_eight_ranks_of_nine_views_the_drivers_8_gpu_line_on_one_gpu():
+    """BASELINE.json config 4 as the driver launches it -- `--nproc-per-node 8 ... bench.py --gpus 8`, 72 views = 9 per rank -- with the eight
+    ranks sharing this box's one GPU over gloo (a functional check of the N = 8 path: eight scenes resident at once, the all-reduce of
+    grad[V,3] across eight ranks, rank 0's JSON line; no timing is read off it).  Reduced image size, the full mesh."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["DRT_DIST_BACKEND"] = "gloo"
+    args = ["--steps", "2", "--warmup", "1", "--res", "256", "--views", "72", "--no-cpu-baseline", "--no-extras", "--repeats", "2"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + args, env)
+    eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "8"] + args, env)
+    assert eight["n_gpus"] == 8 and eight["config"]["views_per_gpu"] == 9 and eight["scaling"] == "strong"
+    mg = eight["multi_gpu"]
+    assert mg["world_size_seen_by_torch_distributed"] == 8 and mg["views_per_rank"] == [9] * 8 and len(mg["allreduce_ms_per_rank"]) == 8
+    assert mg["allreduce_bytes"] == 25126 * 3 * 8
+    a, b = one["config"]["final_loss"], eight["config"]["final_loss"]
+    assert a > 0 and abs(a - b) <= 1e-12 * abs(a), (a, b)
+    assert eight["value"] > 0 and eight["config"]["workload"] == one["config"]["workload"]
