@@ -83,7 +83,7 @@ def _pmc(mode, workload):
         now = _build.source_hash()
         prov.update(git_head=rec.get("git_head"), source_sha256=rec.get("source_sha256"), sources_now_sha256=now,
                     stale=rec.get("source_sha256") != now)
-        return (rec.get(mode, {}) if rec.get("workload") == workload else {}), prov
+        return (rec.get(mode, {}) if rec.get("workloads", {}).get(mode, rec.get("workload")) == workload else {}), prov
     except Exception:
         return {}, prov
 
@@ -93,6 +93,16 @@ def _pmc(mode, workload):
 # SQ_INSTS_VALU that does not depend on a committed counter file -- reported next to the PMC figure, and used instead of it when that
 # file was collected on other kernel sources.
 VALU_PER_INNER_STEP, VALU_PER_LEAF_STEP = 103, 72
+
+
+def projection_pass(pmc, fresh, launches_per_step, alg_bytes_per_step):
+    """The projection pass against its algorithmic bytes (48 B per (image, triangle) + 40 B per written key): HBM traffic of its kernels from
+    the PMC passes (profiles/pmc.json, same kernel sources), per step = stage launches x (2 k_raster + 2 k_raster_big launches each)."""
+    out = {"alg_bytes_per_step": int(alg_bytes_per_step), "traffic_bytes_per_step": None, "ratio": None}
+    if pmc and fresh and all(k in pmc and "hbm_bytes_per_launch" in pmc[k] for k in ("k_raster", "k_raster_big")):
+        t = 2.0 * launches_per_step * (pmc["k_raster"]["hbm_bytes_per_launch"] + pmc["k_raster_big"]["hbm_bytes_per_launch"])
+        out.update(traffic_bytes_per_step=int(t), ratio=round(t / max(1.0, alg_bytes_per_step), 2))
+    return out
 
 
 def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None, live=None, wave_steps=None, recycled=False):
@@ -226,6 +236,7 @@ def roofline(prof, args, P, n_local_views, V, F, elapsed, world, prof_alone=None
                 "traversal": {k: issue_entry(k) for k in ("k_trace<closest>", "k_trace<any>") if k in by_kernel},
                 "stages": stages, "stages_alone_avg_launch_ms": {k: v["avg_launch_ms"] for k, v in alone.items()} if alone else None,
                 "whole_step_alg_GBps_per_gpu": round(step_alg / (elapsed / args.steps) / 1e9 / world, 1),
+                "projection_pass": projection_pass(pmc, pmc_fresh, stages["raster"]["launches"] / args.steps, alg["raster"] / args.steps) if "raster" in stages else None,
                 "live_stages": list(live) if live else None,
                 "note": "the closest-hit traversal of the refracted rays (stage trace2 = every launch of the dominant kernel) is timed by hipEvent pairs on its launch streams INSIDE the timed region (N = 1); the other stages are "
                         "timed in an immediate repeat of the same steps with every stage's events on; sub-batches run on two internal streams, so stage "
@@ -312,7 +323,7 @@ def cpu_baseline(mesh, center, extent):
     return out
 
 
-def regime_roofline(scene, step_fn, kk, n_rays_per_step, verify_every_ray):
+def regime_roofline(scene, step_fn, kk, n_rays_per_step, verify_every_ray, pmc_mode=None, pmc_workload=None, n_faces=0, n_views=0):
     """A regime's own roofline row (the `establish_mode` / `tight_framing` keys of the line): `kk` untimed steps with every stage's hipEvent
     pairs on, then one step in statistics mode.  The closest-hit traversal is priced like the headline's (VALU issue; wave-instructions from
     the wave-steps counted live x the static instruction counts of a wave-step, since profiles/pmc.json holds the headline workload's
@@ -364,8 +375,27 @@ def regime_roofline(scene, step_fn, kk, n_rays_per_step, verify_every_ray):
         if alone.get("cull"):
             rows["k_cull"]["alone"] = {"ms_per_step": round(alone["cull"], 4), "achieved": round(b / (alone["cull"] * 1e-3) / 1e9, 1),
                                        "frac": round(b / (alone["cull"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    proj = None
+    if pmc_mode:
+        # this regime's own counters (profiles/pmc.json[pmc_mode], collected by tools/final_runs.sh on the same kernel sources): HBM traffic of
+        # the traversal launch and of the projection pass, and the closest-hit kernel priced with its own SQ_INSTS_VALU
+        pmc, prov = _pmc(pmc_mode, pmc_workload)
+        fresh = bool(pmc) and not prov["stale"]
+        rec = max((pmc[q] for q in PMC_NAMES["k_trace<closest>"] if q in pmc), key=lambda r: r.get("launches", 0), default=None) if fresh else None
+        if rec and "k_trace<closest>" in rows:
+            r = rows["k_trace<closest>"]
+            r["traffic"] = rec.get("hbm_bytes_per_launch")
+            if rec.get("SQ_INSTS_VALU"):
+                t = r["avg_launch_ms"] * 1e-3
+                r.update(achieved=round(rec["SQ_INSTS_VALU"] / t / 1e9, 1), frac=round(rec["SQ_INSTS_VALU"] / t / VALU_PEAK, 4), valu_instr_per_launch=int(rec["SQ_INSTS_VALU"]),
+                         frac_source=f"rocprofv3 SQ_INSTS_VALU (profiles/pmc.json[{pmc_mode}], same kernel sources)")
+                if rec.get("SQ_THREAD_CYCLES_VALU") and rec.get("SQ_ACTIVE_INST_VALU"):
+                    r["valu_lanes_useful"] = round(rec["SQ_THREAD_CYCLES_VALU"] / (64 * rec["SQ_ACTIVE_INST_VALU"]), 3)
+        if "raster" in stages:
+            h0 = pr["shade1"][2] / kk
+            proj = projection_pass(pmc, fresh, stages["raster"]["launches_per_step"], 48.0 * n_faces * n_views + 40.0 * h0)
     dom = max(rows, key=lambda k: rows[k]["ms_per_step"]) if rows else None
-    return {"roofline": dict(rows[dom], others={k: v for k, v in rows.items() if k != dom}) if dom else None,
+    return {"roofline": dict(rows[dom], others={k: v for k, v in rows.items() if k != dom}) if dom else None, "projection_pass": proj,
             "stages_ms_per_step": {k: v["ms_per_step"] for k, v in stages.items()},
             "stages_alone_ms_per_step": {k: round(v, 4) for k, v in alone.items()}}
 
@@ -743,7 +773,9 @@ def main():
             ddist.barrier(); torch.cuda.synchronize()
             tt = min(tt, ddist.allreduce_max_float(time.perf_counter() - t0, dev))
         hits_t = pt["shade1"][2]
-        tight_roof = regime_roofline(scene, tight_step, min(kt, 5), len(my_views) * P, False)
+        tight_roof = regime_roofline(scene, tight_step, min(kt, 5), len(my_views) * P, False, pmc_mode="tight",
+                                     pmc_workload=f"{args.mesh} res {args.res} views {len(my_views)} streams default, cameras at {os.environ.get('DRT_TIGHT_FACTOR', '1.1')} extents",
+                                     n_faces=n_faces, n_views=len(my_views))
         tight_extra = {"M_rays_per_s": round(args.views * P * kt / tt / 1e6, 3), "ms_per_step": round(1e3 * tt / kt, 3), "steps": kt, "repeats": "best of 2", **tight_roof,
                        "primary_hit_fraction": round(hits_t / (len(my_views) * P), 4), "M_paths_per_s": round(hits_t * world / (tt / kt) / 1e6, 1),
                        "exit_rays_per_step_per_gpu": int(pt["trace3"][2]),

@@ -14,7 +14,7 @@
 //
 // Layout: faces int64 [F,3] (what drt_edge_tables takes), vertices float64 [V,3]; vertex -> incident faces as a CSR pair
 // (vf_start int64 [V+1], vf_face int64 [3F]: face ids grouped by vertex, ascending -- built by the driver with a stable sort).
-#include "drt_scene.h"
+#include "drt_device.h"
 
 namespace {
 
@@ -127,14 +127,10 @@ __device__ bool faces_stay_valid(int64_t v, d3 pnew, int64_t ea, int64_t eb, con
 
 // one thread per candidate edge (length < min_len, listed by the driver): every check of drt_remesh.cpp::collapse_short_edges but the
 // surface distance, whose query points (the midpoint, then the centroids of the surviving faces) it writes to q[c][max_q][3]
-__global__ void k_rm_collapse_eval(const int64_t* __restrict__ cand, int64_t n_cand, const int64_t* __restrict__ E, const int64_t* __restrict__ F,
-                                   const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start,
-                                   const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
-                                   uint8_t* __restrict__ ok, int32_t* __restrict__ n_query, double* __restrict__ q) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= n_cand) return;
-    ok[c] = 0; n_query[c] = 0;
-    const int64_t e = cand[c], a = E[2 * e], b = E[2 * e + 1];
+__device__ void collapse_eval_one(int64_t c, int64_t a, int64_t b, const int64_t* __restrict__ F,
+                                  const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start,
+                                  const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
+                                  uint8_t* __restrict__ ok, int32_t* __restrict__ n_query, double* __restrict__ q) {
     const d3 pa = ldv(V, a), pb = ldv(V, b);
     if (!(len3(pa - pb) < min_len)) return;
     Ring ra, rb;
@@ -156,6 +152,58 @@ __global__ void k_rm_collapse_eval(const int64_t* __restrict__ cand, int64_t n_c
     if (!faces_stay_valid(b, m, a, b, F, V, vn, vf_start, vf_face, max_len, qc, nq, max_q)) return;
     n_query[c] = nq;
     ok[c] = 1;
+}
+__global__ void k_rm_collapse_eval(const int64_t* __restrict__ cand, int64_t n_cand, const int64_t* __restrict__ E, const int64_t* __restrict__ F,
+                                   const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start,
+                                   const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
+                                   uint8_t* __restrict__ ok, int32_t* __restrict__ n_query, double* __restrict__ q) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    ok[c] = 0; n_query[c] = 0;
+    const int64_t e = cand[c];
+    collapse_eval_one(c, E[2 * e], E[2 * e + 1], F, V, vn, vf_start, vf_face, min_len, max_len, max_q, ok, n_query, q);
+}
+// The same over EVERY directed-edge slot c = 3 f + k of the face array as it stands (round 6: no candidate list, so no stream compaction and
+// no host round trip per round).  Every edge of a closed oriented mesh is the directed edge lo -> hi of exactly one face corner: slots with
+// F[c] < F[next] are the unique edges, the others -- and the slots of faces an earlier round killed (indices -1) -- report ok = 0.  Also
+// leaves the round's snapshot of the slot's edge (the claim / apply passes rewrite F) and its length (the priority key).
+__global__ void k_rm_collapse_eval_all(const int64_t* __restrict__ F, int64_t n_faces, const double* __restrict__ V, const double* __restrict__ vn,
+                                       const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
+                                       int64_t* __restrict__ E_snap, double* __restrict__ length, uint8_t* __restrict__ ok, int32_t* __restrict__ n_query,
+                                       double* __restrict__ q) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= 3 * n_faces) return;
+    ok[c] = 0; n_query[c] = 0;
+    const int64_t f = c / 3;
+    const int k = (int)(c - 3 * f);
+    const int64_t a = F[c], b = F[3 * f + (k + 1) % 3];
+    E_snap[2 * c] = a; E_snap[2 * c + 1] = b;
+    length[c] = 0.0;
+    if (a < 0 || !(a < b)) return;
+    length[c] = len3(ldv(V, a) - ldv(V, b));
+    collapse_eval_one(c, a, b, F, V, vn, vf_start, vf_face, min_len, max_len, max_q, ok, n_query, q);
+}
+// CheckSurfDist for the candidates that passed: item i has n_query[i] (or one) query points in q[i][max_q][3]; a point farther than max_dist
+// from the INPUT surface (closest point on the scene's tree, the query of drt_closest_point) takes the item's `ok` back.
+__global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter(TraceCtx c, const int32_t* __restrict__ faces, const float* __restrict__ verts,
+                                                                    uint8_t* ok, const int32_t* __restrict__ n_query, const double* __restrict__ q,
+                                                                    int64_t n_items, int max_q, double max_dist) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    const int64_t n = n_items * max_q;
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        const int64_t item = i / max_q;
+        const int k = (int)(i - item * max_q);
+        if (!ok[item] || k >= (n_query ? n_query[item] : 1)) continue;
+        const Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(q, i), st);
+        if (!(sqrt(r.dist2) <= max_dist)) ok[item] = 0;
+    }
+}
+// the faces a round's collapses killed leave the face array in place: their indices become -1 (the next round's tables skip them; one
+// compaction at the end of the step instead of one per round)
+__global__ void k_rm_kill_faces(int64_t* __restrict__ F, const uint8_t* __restrict__ f_alive, int64_t n_faces) {
+    const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (f < n_faces && !f_alive[f]) { F[3 * f] = -1; F[3 * f + 1] = -1; F[3 * f + 2] = -1; }
 }
 
 // Priority of a collapse: the shorter edges first (eight length classes below min_len, as the host version's sweep goes by length), a
@@ -179,7 +227,7 @@ __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_
                                     uint8_t* __restrict__ v_alive, uint8_t* dirty, int32_t* n_done) {
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= n_cand || !ok[c]) return;
-    const int64_t e = cand[c], a = E[2 * e], b = E[2 * e + 1];
+    const int64_t e = cand ? cand[c] : c, a = E[2 * e], b = E[2 * e + 1];          // (no list: every directed-edge slot is a candidate slot)
     const unsigned long long key = collapse_key(length[e], min_len, e, seed);      // (from the lengths of the round's start: V changes under APPLY)
     // Sub-rounds (several claim / apply pairs on ONE evaluation and ONE set of tables): a collapse that went ahead marks everything it
     // read or wrote `dirty`; a candidate takes part in a later sub-round only while its two vertices and both rings are clean -- then no
@@ -393,11 +441,45 @@ int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d
     return DRT_OK;
 }
 
+int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
+                             const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
+                             uint8_t* d_ok, int32_t* d_n_query, double* d_query, void* stream) {
+    if (n_faces <= 0) return DRT_OK;
+    if (!d_faces || !d_verts || !d_vn || !d_vf_start || !d_vf_face || !d_edge_snap || !d_length || !d_ok || !d_n_query || !d_query || max_q < 1)
+        return fail(DRT_E_INVALID, "bad argument");
+    k_rm_collapse_eval_all<<<blocks_for(3 * n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, n_faces, d_verts, d_vn, d_vf_start, d_vf_face, min_len, max_len, max_q,
+                                                                                   d_edge_snap, d_length, d_ok, d_n_query, d_query);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_query, const double* d_query, int64_t n_items, int max_q, double max_dist,
+                          void* stream) {
+    CHECK_BUILT(s);
+    if (n_items <= 0) return DRT_OK;
+    if (!d_ok || !d_query || max_q < 1) return fail(DRT_E_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = wait_build(s, st); if (rc) return rc; }
+    { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
+    k_rm_surface_filter<<<grid_for(n_items * max_q, kTraceBlock, s->grid_trace), kTraceBlock, 0, st>>>(trace_ctx(s), s->faces, s->verts, d_ok, d_n_query, d_query,
+                                                                                                        n_items, max_q, max_dist);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_kill_faces(int64_t* d_faces, const uint8_t* d_f_alive, int64_t n_faces, void* stream) {
+    if (n_faces <= 0) return DRT_OK;
+    if (!d_faces || !d_f_alive) return fail(DRT_E_INVALID, "null pointer argument");
+    k_rm_kill_faces<<<blocks_for(n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, d_f_alive, n_faces);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
                           const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, const double* d_length,
                           uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream) {
     if (n_cand <= 0) return DRT_OK;
-    if (!d_cand || !d_ok || !d_edges || !d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_length || !d_lock || !d_f_alive || !d_v_alive || !d_dirty ||
+    if (!d_ok || !d_edges || !d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_length || !d_lock || !d_f_alive || !d_v_alive || !d_dirty ||
         !d_n_done || n_verts <= 0 || sub_rounds < 1)
         return fail(DRT_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;

@@ -109,65 +109,71 @@ class _Work:
         return n_split
 
     # ---- 2. collapse
+    def _filter_by_surface(self, ok, nq, q, n_items, max_q):
+        """CheckSurfDist on the device (drt_rm_surface_filter): candidates whose query points leave the input surface lose their `ok`."""
+        if self.surface is None or not np.isfinite(self.max_dist) or n_items == 0:
+            return
+        _check(_lib.lib().drt_rm_surface_filter(self.surface._h, ok.data_ptr(), _lib.ptr(nq), q.data_ptr(), n_items, max_q, float(self.max_dist), _stream()))
+
     def collapse_short_edges(self, min_len, max_len):
+        """Rounds of evaluate (every directed-edge slot of the face array at once) -> surface filter -> claim / apply.  Round 6: no candidate
+        list, no per-round compaction of the face array (killed faces stay in place with indices -1 until the step is through) and ONE host
+        round trip per round -- the number of collapses it applied, which ends the step -- instead of seven; about a third of the launches."""
         lib = _lib.lib()
-        done = 0
-        v_alive = torch.ones(self.V.shape[0], dtype=torch.uint8, device=self.dev)
-        first = 0
+        done = first = 0
+        nf = self.F.shape[0]
+        dev = self.dev
+        v_alive = torch.ones(self.V.shape[0], dtype=torch.uint8, device=dev)
+        # per-slot workspaces of the step (3 F slots; the face array keeps its size until the compaction at the end)
+        E_snap = torch.empty((3 * nf, 2), dtype=torch.long, device=dev)
+        length = torch.empty(3 * nf, dtype=torch.float64, device=dev)
+        ok = torch.empty(3 * nf, dtype=torch.uint8, device=dev)
+        nq = torch.empty(3 * nf, dtype=torch.int32, device=dev)
+        q = torch.empty((3 * nf, MAX_Q, 3), dtype=torch.float64, device=dev)
+        nv = self.V.shape[0]
+        lock = torch.empty(nv, dtype=torch.int64, device=dev)                           # (workspaces: preset by the call)
+        dirty = torch.empty(nv, dtype=torch.uint8, device=dev)
+        f_alive = torch.empty(nf, dtype=torch.uint8, device=dev)
+        n_done = torch.zeros(1, dtype=torch.int32, device=dev)
         for rnd in range(MAX_ROUNDS + 1):
             if rnd == MAX_ROUNDS:
                 self.stats["collapse_unfinished"] += 1            # candidates were still being applied when the rounds ran out
                 break
             self.stats["collapse_rounds"] += 1
-            # candidates straight from the faces: every edge of a closed oriented mesh is the directed edge (lo -> hi) of exactly one face
-            # corner, so the rows 3 f + k with F[f, k] < F[f, k + 1] ARE the unique edges -- no sorted edge table per round (0.6 ms of a
-            # 1.4 ms round at 80 k faces; the flips, which search the table, still build it)
-            E = self.F[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2).contiguous()
-            length = (self.V[E[:, 0]] - self.V[E[:, 1]]).norm(dim=1).contiguous()
-            cand = torch.nonzero((length < min_len) & (E[:, 0] < E[:, 1])).squeeze(1).contiguous()
-            if len(cand) == 0:
-                break
-            vf_start, vf_face = self.csr()
+            vf_start, vf_face = self.csr()                        # (killed faces hold -1: sorted to the front, outside every vertex's run)
             vn = self.vertex_normals(vf_start, vf_face)
-            ok = torch.zeros(len(cand), dtype=torch.uint8, device=self.dev)
-            nq = torch.zeros(len(cand), dtype=torch.int32, device=self.dev)
-            q = torch.empty((len(cand), MAX_Q, 3), dtype=torch.float64, device=self.dev)
-            _check(lib.drt_rm_collapse_eval(cand.data_ptr(), len(cand), E.data_ptr(), self.F.data_ptr(), self.V.data_ptr(), vn.data_ptr(),
-                                            vf_start.data_ptr(), vf_face.data_ptr(), float(min_len), float(max_len), MAX_Q,
-                                            ok.data_ptr(), nq.data_ptr(), q.data_ptr(), _stream()))
+            _check(lib.drt_rm_collapse_eval_all(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
+                                                float(min_len), float(max_len), MAX_Q, E_snap.data_ptr(), length.data_ptr(), ok.data_ptr(),
+                                                nq.data_ptr(), q.data_ptr(), _stream()))
             # CheckSurfDist: the midpoint and the centroid of every face that survives must stay near the input surface
-            used = torch.arange(MAX_Q, device=self.dev).unsqueeze(0) < nq.unsqueeze(1)
-            used &= ok.bool().unsqueeze(1)
-            pts = q[used]
-            near = self.near_surface(pts)
-            far_rows = torch.nonzero(used)[:, 0][~near]
-            ok[far_rows] = 0
-            if int(ok.sum()) == 0:
-                break
-            nv = self.V.shape[0]
-            lock = torch.empty(nv, dtype=torch.int64, device=self.dev)                           # (workspaces: preset by the call)
-            dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
-            f_alive = torch.ones(self.F.shape[0], dtype=torch.uint8, device=self.dev)
-            n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
-            _check(lib.drt_rm_collapse_apply(cand.data_ptr(), len(cand), ok.data_ptr(), E.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
+            self._filter_by_surface(ok, nq, q, 3 * nf, MAX_Q)
+            f_alive.fill_(1)
+            n_done.zero_()
+            _check(lib.drt_rm_collapse_apply(None, 3 * nf, ok.data_ptr(), E_snap.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
                                              vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, length.data_ptr(),
                                              lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), dirty.data_ptr(), SUB_ROUNDS, n_done.data_ptr(), _stream()))
-            n = int(n_done.item())
+            _check(lib.drt_rm_kill_faces(self.F.data_ptr(), f_alive.data_ptr(), nf, _stream()))
+            n = int(n_done.item())                                # the round's one host round trip
             if DEBUG:
-                print(f"  collapse round: {len(cand)} short edges, {int(ok.sum())} pass, {n} applied")
+                print(f"  collapse round: {int(ok.sum())} pass, {n} applied")
             if n == 0:
                 break
             done += n
-            self.F = self.F[f_alive.bool()].contiguous()
             first = first or n
             if n < max(4, first // TAIL_CUT):     # the tail of a step: a handful of candidates per round, each round a rebuild of the tables;
                 break                             # what is left is picked up by the next of the call's iterations (or the next pass)
+        if done:
+            self.F = self.F[self.F[:, 0] >= 0].contiguous()
         return done
 
     # ---- 3. flip
     def flip_edges(self, max_len):
         lib = _lib.lib()
         done = first = 0
+        nv = self.V.shape[0]
+        lock = torch.empty(nv, dtype=torch.int32, device=self.dev)
+        dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
+        n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
         for rnd in range(MAX_ROUNDS + 1):
             if rnd == MAX_ROUNDS:
                 self.stats["flip_unfinished"] += 1
@@ -177,25 +183,16 @@ class _Work:
             vf_start, vf_face = self.csr()
             vn = self.vertex_normals(vf_start, vf_face)
             n_e = E.shape[0]
-            ok = torch.zeros(n_e, dtype=torch.uint8, device=self.dev)
+            ok = torch.empty(n_e, dtype=torch.uint8, device=self.dev)
             quad = torch.empty((n_e, 6), dtype=torch.long, device=self.dev)
-            q = torch.zeros((n_e, 3), dtype=torch.float64, device=self.dev)
+            q = torch.empty((n_e, 3), dtype=torch.float64, device=self.dev)
             _check(lib.drt_rm_flip_eval(E.data_ptr(), n_e, edge_rows.contiguous().data_ptr(), self.F.data_ptr(), self.V.data_ptr(), vn.data_ptr(),
                                         vf_start.data_ptr(), float(max_len), ok.data_ptr(), quad.data_ptr(), q.data_ptr(), _stream()))
-            idx = torch.nonzero(ok).squeeze(1)
-            if len(idx) == 0:
-                break
-            near = self.near_surface(q[idx])
-            ok[idx[~near]] = 0
-            if int(ok.sum()) == 0:
-                break
-            nv = self.V.shape[0]
-            lock = torch.empty(nv, dtype=torch.int32, device=self.dev)
-            dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
-            n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self._filter_by_surface(ok, None, q, n_e, 1)          # the midpoint of the new edge
+            n_done.zero_()
             _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), nv, lock.data_ptr(), dirty.data_ptr(), SUB_ROUNDS,
                                          n_done.data_ptr(), _stream()))
-            n = int(n_done.item())
+            n = int(n_done.item())                                # the round's one host round trip
             if DEBUG:
                 print(f"  flip round: {int(ok.sum())} pass, {n} applied")
             if n == 0:

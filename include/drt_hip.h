@@ -366,6 +366,19 @@ int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
                           const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, const double* d_length,
                           uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream);
+/* Round 6: the same evaluation over EVERY directed-edge slot c = 3 f + k of d_faces (no candidate list: no stream compaction, no host round
+ * trip per round).  Slots that are not the lo -> hi representative of their edge, not short, or belong to a face an earlier round killed
+ * (indices -1, drt_rm_kill_faces) report ok = 0.  Outputs sized [3 n_faces]: d_edge_snap int64 [.,2] (the slot's edge at the start of the
+ * round: what drt_rm_collapse_apply takes as d_edges with d_cand = NULL), d_length, d_ok, d_n_query, d_query [., max_q, 3].
+ * drt_rm_surface_filter: CheckSurfDist on the device -- item i keeps d_ok[i] only if all of its d_n_query[i] (NULL: one) points
+ * d_query[i][k] lie within max_dist of the surface held by scene `s` (the closest-point query of drt_closest_point).
+ * drt_rm_kill_faces: faces with d_f_alive[f] == 0 get the indices -1 in place. */
+int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
+                             const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
+                             uint8_t* d_ok, int32_t* d_n_query, double* d_query, void* stream);
+int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_query, const double* d_query, int64_t n_items, int max_q,
+                          double max_dist, void* stream);
+int drt_rm_kill_faces(int64_t* d_faces, const uint8_t* d_f_alive, int64_t n_faces, void* stream);
 int drt_rm_flip_eval(const int64_t* d_edges, int64_t n_edges, const int64_t* d_edge_rows, const int64_t* d_faces, const double* d_verts, const double* d_vn,
                      const int64_t* d_vf_start, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream);
 int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, uint32_t* d_lock, uint8_t* d_dirty,

@@ -2,8 +2,9 @@
 # The measurement batch whose outputs go to profiles/ at the end of a round (run on the GPU box through gpurun).
 # usage: bash tools/final_runs.sh <prefix>      e.g. r02
 set -u
-P=${1:-r05}
+P=${1:-r06}
 O=gpurun_out/final_$P; mkdir -p $O
+export DRT_BENCH_REPEATS=5      # (the many small runs of this batch: five repeats of the timed region each; the bench lines at the end run the sustained default)
 {
   for cfg in "--mesh hand --res 512 --views 72" "--mesh mouse --res 1024 --views 72" "--mesh horse --res 1024 --views 72" "--mesh monkey --res 1024 --views 72" "--mesh monkey --res 1024 --views 144"; do
     python bench.py $cfg --no-cpu-baseline --no-extras --steps 10 --warmup 3 2>/dev/null | python -c "
@@ -39,7 +40,19 @@ for r in gpu host; do REMESH=$r python tools/recon_trend.py 2>&1 | grep -v amdgp
 python -m drt_amd.reconstruct --name monkey --views 144 --res 1024 2>&1 | grep -v amdgpu > $O/recon_monkey_144views.txt
 # the launch line of the driver's multi-GPU runs, two ranks on this box's one GPU (gloo instead of RCCL): functional check of bench.py's N > 1 path
 DRT_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
+# the driver's N = 8 line (BASELINE config 4: 9 views per rank), eight ranks on this one GPU over gloo, full size: functional check, memory of eight scenes
+DRT_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 8 --steps 3 --warmup 2 --repeats 2 --no-cpu-baseline --no-extras > $O/bench_8rank_gloo.json 2> $O/bench_8rank_gloo.err
 python tools/iter_bench.py > $O/iter_bench.txt 2>&1
+{
+  # explicit ray binding (default) vs the drop-in signature's identity heuristics; deterministic accumulation mode (drt_deterministic)
+  for a in "--bind 1" "--bind 0"; do
+    for e in "DRT_DETERMINISTIC=0" "DRT_DETERMINISTIC=1"; do
+      echo "bench.py $a :: $e :: $(env $e python bench.py $a --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], 'ms/step', d['repeats']['ms_per_step'], 'backward', d['roofline']['stages']['backward']['ms_per_step'])")"
+    done
+  done
+  echo "bench.py --distance-factor 1.1 :: DRT_DETERMINISTIC=1 :: $(DRT_DETERMINISTIC=1 python bench.py --distance-factor 1.1 --no-cpu-baseline --no-extras --steps 10 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], 'ms/step')")"
+  DRT_DETERMINISTIC=1 python tools/iter_bench.py 2>&1 | grep -v amdgpu | grep "ms/iteration" | sed 's/^/DRT_DETERMINISTIC=1 iter_bench: /'
+} > $O/bind_det.txt 2>&1
 bash tools/profile.sh $P > $O/profile.log 2>&1
 PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 DRT_PREFILL_NEXT=0 bash tools/profile.sh ${P}_serial > $O/profile_serial.log 2>&1
 # the regime real captures live in: the object fills the image (camera at 1.1 extents)
@@ -47,9 +60,12 @@ bash tools/profile.sh ${P}_tight --distance-factor 1.1 > $O/profile_tight.log 2>
 PROFILE_SKIP_PMC=1 DRT_STREAMS=1 DRT_FILL_OVERLAP=0 DRT_PREFILL_NEXT=0 bash tools/profile.sh ${P}_tight_serial --distance-factor 1.1 > $O/profile_tight_serial.log 2>&1
 bash tools/step_timeline.sh $O/step_timeline_tight.txt --distance-factor 1.1 > /dev/null 2>&1
 # the bench lines LAST, with this build's own counters: bench.py prices k_trace's live launch time against SQ_INSTS_VALU of profiles/pmc.json
-python tools/make_pmc_json.py gpurun_out/$P profiles/pmc.json dropin > /dev/null && cp profiles/pmc.json $O/pmc.json
+python tools/make_pmc_json.py gpurun_out/$P profiles/pmc.json dropin > /dev/null
+PMC_WORKLOAD="horse res 1024 views 72 streams default, cameras at 1.1 extents" python tools/make_pmc_json.py gpurun_out/${P}_tight profiles/pmc.json tight > /dev/null
+cp profiles/pmc.json $O/pmc.json
 # (measured twice: right after the counter passes above the same box runs the step 3 % slower -- 2.40 vs 2.33 ms -- than in a call of its own; let it settle)
 sleep 30
+unset DRT_BENCH_REPEATS          # the bench lines: sustained mode (>= 3 s of timed steps, median of the repeats after the first second)
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --mode fused --no-cpu-baseline > $O/bench_fused.json 2> /dev/null
 tail -n 3 $O/configs.txt $O/scaling_proxy.txt $O/iter_bench.txt; python tools/benchsum.py $O/bench.json | head -3

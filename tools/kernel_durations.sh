@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-launch durations of the kernels whose name matches a pattern, in launch order, under rocprofv3 --kernel-trace.
 # usage (via gpurun): bash tools/kernel_durations.sh <name-regex> <n_last> <command ...>
-export DRT_BENCH_REPEATS=${DRT_BENCH_REPEATS:-1}      # (bench.py without --repeats runs a >= 3 s sustained measurement: not what this script is after)
+export DRT_BENCH_REPEATS=1      # (one timed region per profiled run, whatever the caller exported)
 export TMPDIR=/tmp
 pat=$1; n=$2; shift 2
 rm -rf /tmp/rp_kd

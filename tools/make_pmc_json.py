@@ -44,7 +44,10 @@ try:
     res["git_head"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
 except Exception:
     res["git_head"] = None
-res["workload"] = os.environ.get("PMC_WORKLOAD", "horse res 1024 views 72 streams default")
+wl = os.environ.get("PMC_WORKLOAD", "horse res 1024 views 72 streams default")
+res.setdefault("workloads", {})[mode] = wl          # (per mode: "tight" = the same step with the cameras at 1.1 extents)
+if mode in ("dropin", "fused") or "workload" not in res:
+    res["workload"] = wl
 res["note"] = ("per-launch means from separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-extras --random-targets` "
                "(tools/profile.sh); SQ_* cycle counters are quad-cycles; FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte requests as 64, "
                "MI355X_MICROARCH.md) + WRITE_SIZE x 1024")

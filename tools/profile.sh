@@ -3,7 +3,7 @@
 # (PMC passes: one warm-up step -- it ESTABLISHES the grid verdict -- and two steady-state steps; per-kernel means.)
 # Big raw outputs stay in /tmp; only summaries land in gpurun_out/<tag>/.
 # usage: tools/profile.sh <tag> [bench args...]
-export DRT_BENCH_REPEATS=${DRT_BENCH_REPEATS:-1}      # (bench.py without --repeats runs a >= 3 s sustained measurement: not what this script is after)
+export DRT_BENCH_REPEATS=1      # (one timed region per profiled run, whatever the caller exported)
 set -u
 TAG=${1:-prof}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}

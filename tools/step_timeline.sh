@@ -2,7 +2,7 @@
 # Gantt of ONE step of bench.py (the second-to-last one of the timed region) under rocprofv3 --kernel-trace: every dispatch with its
 # start offset from the step's k_cast_verts, duration and hardware queue, in start order, plus the idle gaps of the chip.
 # usage (via gpurun): bash tools/step_timeline.sh <out.txt> [bench args...]
-export DRT_BENCH_REPEATS=${DRT_BENCH_REPEATS:-1}      # (bench.py without --repeats runs a >= 3 s sustained measurement: not what this script is after)
+export DRT_BENCH_REPEATS=1      # (one timed region per profiled run, whatever the caller exported)
 export TMPDIR=/tmp
 out=$1; shift
 rm -rf /tmp/rp_st

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel timeline (start offset, duration) of the last kernels of a python script under rocprofv3 --kernel-trace.
 # usage (via gpurun): bash tools/timeline.sh <script.py> [n_last]
-export DRT_BENCH_REPEATS=${DRT_BENCH_REPEATS:-1}      # (bench.py without --repeats runs a >= 3 s sustained measurement: not what this script is after)
+export DRT_BENCH_REPEATS=1      # (one timed region per profiled run, whatever the caller exported)
 export TMPDIR=/tmp
 rm -rf /tmp/rp_tl
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_tl -o t -- python $1 > /tmp/rp_tl.log 2>&1
