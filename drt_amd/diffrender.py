@@ -671,13 +671,15 @@ def ray_loss(out_ori, out_dir, mask, screen_pixel, valid):
     return _RayLoss.apply(out_ori, out_dir, mask, screen_pixel, valid, link)
 
 
-def edge_tables(F, V, want_rows=False):
+def edge_tables(F, V, want_rows=False, check=True):
     """Edges [E,2], E2F [E,2,3], mean_len (reference DiffRender.py:338-355) on the device of ``F`` / ``V`` -- the reference
     goes through trimesh's host-side ``group_rows`` / ``edges_face``.  One stable radix sort of the 3F directed-edge keys
     in libdrt_hip (``drt_edge_tables``).  Order as pinned in mesh_io.group_rows_pairs: edges ascend by (min vertex, max
     vertex); the first face of a pair is the one with the lower directed-edge row.  Asserts watertightness
     (DiffRender.py:305); that check and ``mean_len`` come back in ONE small device->host copy (a topology change is not
-    on the per-iteration path).  ``want_rows``: also the int32 [3F] directed-edge -> unique-edge map."""
+    on the per-iteration path).  ``want_rows``: also the int32 [3F] directed-edge -> unique-edge map.  ``check=False``: no read-back at all
+    (``mean_len`` is then None, watertightness is the caller's business: the device remesher's rounds, which keep the mesh closed by
+    construction and install the result through ``Scene._set_topology``, which checks)."""
     if not F.is_cuda:
         raise RuntimeError("edge_tables needs GPU tensors (there is no CPU path in the product)")
     Fc = F.to(torch.long).contiguous()
@@ -694,6 +696,8 @@ def edge_tables(F, V, want_rows=False):
         ws = torch.empty(int(_lib.lib().drt_edge_tables_workspace(n_f)), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib().drt_edge_tables(Fc.data_ptr(), n_f, Vc.data_ptr(), n_v, ws.data_ptr(), Edges.data_ptr(), E2F.data_ptr(),
                                               rows.data_ptr(), out.data_ptr(), out[1:].data_ptr(), _stream()))
+    if not check:
+        return (Edges, E2F, None, rows) if want_rows else (Edges, E2F, None)
     host = out.cpu()
     status = int(host[1:].view(torch.int32)[0])
     if status & 2:

@@ -39,6 +39,7 @@ MAX_ROUNDS = 96            # evaluate / claim / apply rounds per step (a round a
 SUB_ROUNDS = int(__import__("os").environ.get("DRT_REMESH_SUB_ROUNDS", 3))     # claim / apply pairs per evaluation (one set of edge tables, vertex -> face lists and surface queries
                            # serves several independent sets: candidates whose neighbourhood an earlier pair of the round touched sit out until the next evaluation)
 TAIL_CUT = int(__import__("os").environ.get("DRT_REMESH_TAIL_CUT", 32))       # a step ends when a round applies less than 1 / TAIL_CUT of what its first round applied
+KEEP_VERDICTS = __import__("os").environ.get("DRT_REMESH_KEEP_VERDICTS", "1") != "0"      # collapse rounds evaluate only what the previous round changed (see k_rm_collapse_eval_all)
 DEBUG = False
 
 
@@ -60,7 +61,7 @@ class _Work:
     # ---- derived tables
     def edges(self):
         """Edges [E,2] ascending by (lo, hi), row2edge int32 [3F], edge_rows int64 [E,2] (the two directed-edge rows of every edge)."""
-        E, _, _, rows = diffrender.edge_tables(self.F, self.V, want_rows=True)
+        E, _, _, rows = diffrender.edge_tables(self.F, self.V, want_rows=True, check=False)      # (no read-back: every step here keeps the mesh closed)
         order = torch.argsort(rows, stable=True)                # rows grouped by edge id: two per edge (watertight: asserted above)
         return E, rows, order.view(-1, 2)
 
@@ -90,19 +91,24 @@ class _Work:
         E, rows, _ = self.edges()
         lo, hi = self.V[E[:, 0]], self.V[E[:, 1]]
         long_ = (lo - hi).norm(dim=1) > max_len
-        n_split = int(long_.sum())
-        if n_split == 0:
-            return 0
-        nv = self.V.shape[0]
-        mid_of_edge = torch.full((E.shape[0],), -1, dtype=torch.long, device=self.dev)
-        mid_of_edge[long_] = nv + torch.arange(n_split, device=self.dev)
-        self.V = torch.cat([self.V, (lo[long_] + hi[long_]) * 0.5]).contiguous()          # (V[lo] + V[hi]) * 0.5: the host version's bits
-        nf = self.F.shape[0]
+        nv, nf = self.V.shape[0], self.F.shape[0]
+        # the new vertex of every long edge, numbered in edge order; face counts; ONE host round trip for both totals (the sizes of the new arrays)
+        rank = torch.cumsum(long_, 0)
+        mid_of_edge = torch.where(long_, nv + rank - 1, torch.full_like(rank, -1))
         count = torch.empty(nf, dtype=torch.long, device=self.dev)
         lib = _lib.lib()
         _check(lib.drt_rm_split_faces(self.F.data_ptr(), nf, rows.data_ptr(), mid_of_edge.data_ptr(), None, count.data_ptr(), None, None, _stream()))
-        offset = torch.cumsum(count, 0) - count
-        out = torch.empty((int(count.sum()), 3), dtype=torch.long, device=self.dev)
+        offset = torch.cumsum(count, 0)
+        n_split, n_out = (int(x) for x in torch.stack([rank[-1], offset[-1]]).tolist())
+        if n_split == 0:
+            return 0
+        offset = offset - count
+        # midpoints written by destination row (no stream compaction): short edges all go to one scratch row behind the new vertices
+        newV = torch.empty((nv + n_split + 1, 3), dtype=torch.float64, device=self.dev)
+        newV[:nv] = self.V
+        newV.index_copy_(0, torch.where(long_, mid_of_edge, torch.full_like(rank, nv + n_split)), (lo + hi) * 0.5)     # (V[lo] + V[hi]) * 0.5: the host version's bits
+        self.V = newV[:nv + n_split]
+        out = torch.empty((n_out, 3), dtype=torch.long, device=self.dev)
         _check(lib.drt_rm_split_faces(self.F.data_ptr(), nf, rows.data_ptr(), mid_of_edge.data_ptr(), self.V.data_ptr(), None, offset.data_ptr(),
                                       out.data_ptr(), _stream()))
         self.F = out
@@ -130,11 +136,19 @@ class _Work:
         ok = torch.empty(3 * nf, dtype=torch.uint8, device=dev)
         nq = torch.empty(3 * nf, dtype=torch.int32, device=dev)
         q = torch.empty((3 * nf, MAX_Q, 3), dtype=torch.float64, device=dev)
+        check_dist = self.surface is not None and np.isfinite(self.max_dist)
+        ql_cap = 3 * nf * 4                                      # query points of a round (a candidate that does not fit waits for the next one)
+        ql_item = torch.empty(ql_cap, dtype=torch.int32, device=dev) if check_dist else None
+        ql_point = torch.empty((ql_cap, 3), dtype=torch.float64, device=dev) if check_dist else None
+        ql_count = torch.zeros(1, dtype=torch.int32, device=dev) if check_dist else None
         nv = self.V.shape[0]
         lock = torch.empty(nv, dtype=torch.int64, device=dev)                           # (workspaces: preset by the call)
         dirty = torch.empty(nv, dtype=torch.uint8, device=dev)
         f_alive = torch.empty(nf, dtype=torch.uint8, device=dev)
         n_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        # verdicts carried from round to round (KEEP_VERDICTS): the round a slot was last evaluated in, the round a vertex's neighbourhood last changed in
+        eval_round = torch.full((3 * nf,), -1, dtype=torch.int32, device=dev) if KEEP_VERDICTS else None
+        touched = torch.full((nv,), -1, dtype=torch.int32, device=dev) if KEEP_VERDICTS else None
         for rnd in range(MAX_ROUNDS + 1):
             if rnd == MAX_ROUNDS:
                 self.stats["collapse_unfinished"] += 1            # candidates were still being applied when the rounds ran out
@@ -144,14 +158,19 @@ class _Work:
             vn = self.vertex_normals(vf_start, vf_face)
             _check(lib.drt_rm_collapse_eval_all(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
                                                 float(min_len), float(max_len), MAX_Q, E_snap.data_ptr(), length.data_ptr(), ok.data_ptr(),
-                                                nq.data_ptr(), q.data_ptr(), _stream()))
+                                                nq.data_ptr(), q.data_ptr(), _lib.ptr(ql_item), _lib.ptr(ql_point), _lib.ptr(ql_count), ql_cap,
+                                                rnd, _lib.ptr(eval_round), _lib.ptr(touched), _stream()))
             # CheckSurfDist: the midpoint and the centroid of every face that survives must stay near the input surface
-            self._filter_by_surface(ok, nq, q, 3 * nf, MAX_Q)
+            if check_dist:
+                _check(lib.drt_rm_surface_filter_list(self.surface._h, ok.data_ptr(), ql_item.data_ptr(), ql_point.data_ptr(), ql_count.data_ptr(), ql_cap,
+                                                      float(self.max_dist), _stream()))
             f_alive.fill_(1)
             n_done.zero_()
             _check(lib.drt_rm_collapse_apply(None, 3 * nf, ok.data_ptr(), E_snap.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
                                              vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, length.data_ptr(),
                                              lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), dirty.data_ptr(), SUB_ROUNDS, n_done.data_ptr(), _stream()))
+            if KEEP_VERDICTS:
+                _check(lib.drt_rm_mark_touched(dirty.data_ptr(), self.F.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(), nv, rnd, touched.data_ptr(), _stream()))
             _check(lib.drt_rm_kill_faces(self.F.data_ptr(), f_alive.data_ptr(), nf, _stream()))
             n = int(n_done.item())                                # the round's one host round trip
             if DEBUG:
