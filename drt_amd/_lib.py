@@ -70,8 +70,7 @@ SIGNATURES = {
     "drt_rm_split_faces": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "drt_rm_vertex_normals": (_c.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
     "drt_rm_collapse_eval": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _D, _D, _c.c_int, _P, _P, _P, _P]),
-    "drt_rm_collapse_eval_all": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _D, _D, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _c.c_int, _P, _P, _P]),
-    "drt_rm_mark_touched": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _P, _P]),
+    "drt_rm_collapse_eval_all": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _D, _D, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "drt_rm_surface_filter_list": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _D, _P]),
     "drt_rm_surface_filter": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _D, _P]),
     "drt_rm_kill_faces": (_c.c_int, [_P, _P, _I64, _P]),

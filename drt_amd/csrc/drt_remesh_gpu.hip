@@ -170,25 +170,16 @@ __global__ void k_rm_collapse_eval(const int64_t* __restrict__ cand, int64_t n_c
 __global__ void k_rm_collapse_eval_all(const int64_t* __restrict__ F, int64_t n_faces, const double* __restrict__ V, const double* __restrict__ vn,
                                        const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
                                        int64_t* __restrict__ E_snap, double* __restrict__ length, uint8_t* __restrict__ ok, int32_t* __restrict__ n_query,
-                                       double* __restrict__ q, int32_t* __restrict__ ql_item, double* __restrict__ ql_point, unsigned* ql_count, unsigned ql_cap,
-                                       int round, int32_t* __restrict__ eval_round, const int32_t* __restrict__ touched) {
+                                       double* __restrict__ q, int32_t* __restrict__ ql_item, double* __restrict__ ql_point, unsigned* ql_count, unsigned ql_cap) {
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= 3 * n_faces) return;
     const int64_t f = c / 3;
     const int k = (int)(c - 3 * f);
     const int64_t a = F[c], b = F[3 * f + (k + 1) % 3];
-    // The verdict of an earlier round STANDS while nothing it read has changed: slots are stable (killed faces stay in place), and
-    // k_rm_mark_touched stamps every vertex a round's collapses dirtied AND its neighbours with that round -- so "a and b untouched since
-    // the slot was evaluated" means both rings, every face around them, their valences and consensus normals are what the evaluation saw
-    // (the argument of the sub-rounds in k_rm_collapse_claim, carried across rounds).  Only the neighbourhoods a round changed are
-    // evaluated again, and only their query points go to the surface: a round applies a few per cent of the candidates.
-    if (eval_round && a >= 0 && a < b && eval_round[c] >= 0 && touched[a] < eval_round[c] && touched[b] < eval_round[c]) return;
     ok[c] = 0; n_query[c] = 0;
     E_snap[2 * c] = a; E_snap[2 * c + 1] = b;
     length[c] = 0.0;
-    if (eval_round) eval_round[c] = -1;
     if (a < 0 || !(a < b)) return;
-    if (eval_round) eval_round[c] = round;
     length[c] = len3(ldv(V, a) - ldv(V, b));
     collapse_eval_one(c, a, b, F, V, vn, vf_start, vf_face, min_len, max_len, max_q, ok, n_query, q);
     // the query points of a candidate that passed go to ONE compact list (drt_rm_surface_filter_list walks it with full wavefronts; a pass
@@ -196,7 +187,7 @@ __global__ void k_rm_collapse_eval_all(const int64_t* __restrict__ F, int64_t n_
     // candidate to the next round.
     if (ql_item && ok[c]) {
         const unsigned nq = (unsigned)n_query[c], base = atomicAdd(ql_count, nq);
-        if (base + nq > ql_cap) { ok[c] = 0; if (eval_round) eval_round[c] = -1; return; }       // (not a verdict: evaluated again next round)
+        if (base + nq > ql_cap) { ok[c] = 0; return; }
         const double* qc = q + 3 * (int64_t)max_q * c;
         for (unsigned k = 0; k < nq; ++k) {
             ql_item[base + k] = (int32_t)c;
@@ -232,18 +223,6 @@ __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter(TraceCtx c, c
         if (!ok[item] || k >= (n_query ? n_query[item] : 1)) continue;
         const Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(q, i), st);
         if (!(sqrt(r.dist2) <= max_dist)) ok[item] = 0;
-    }
-}
-// every vertex a round's collapses dirtied, and every neighbour of such a vertex, is stamped with the round (see k_rm_collapse_eval_all).
-// Rings from the round's vertex -> face lists and the face array as the applies left it (b -> a rewritten, killed faces still in place).
-__global__ void k_rm_mark_touched(const uint8_t* __restrict__ dirty, const int64_t* __restrict__ F, const int64_t* __restrict__ vf_start,
-                                  const int64_t* __restrict__ vf_face, int64_t n_verts, int round, int32_t* __restrict__ touched) {
-    const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (v >= n_verts || !dirty[v]) return;
-    touched[v] = round;
-    for (int64_t s = vf_start[v]; s < vf_start[v + 1]; ++s) {
-        const int64_t f = vf_face[s];
-        for (int k = 0; k < 3; ++k) { const int64_t u = F[3 * f + k]; if (u >= 0) touched[u] = round; }
     }
 }
 // the faces a round's collapses killed leave the face array in place: their indices become -1 (the next round's tables skip them; one
@@ -491,9 +470,8 @@ int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d
 int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
                              const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
                              uint8_t* d_ok, int32_t* d_n_query, double* d_query, int32_t* d_list_item, double* d_list_point, uint32_t* d_list_count,
-                             int64_t list_cap, int round, int32_t* d_eval_round, const int32_t* d_touched, void* stream) {
+                             int64_t list_cap, void* stream) {
     if (n_faces <= 0) return DRT_OK;
-    if ((d_eval_round == nullptr) != (d_touched == nullptr) || round < 0) return fail(DRT_E_INVALID, "d_eval_round and d_touched go together");
     if (!d_faces || !d_verts || !d_vn || !d_vf_start || !d_vf_face || !d_edge_snap || !d_length || !d_ok || !d_n_query || !d_query || max_q < 1)
         return fail(DRT_E_INVALID, "bad argument");
     if (d_list_item && (!d_list_point || !d_list_count || list_cap <= 0 || list_cap > UINT32_MAX / 2)) return fail(DRT_E_INVALID, "bad query list");
@@ -501,7 +479,7 @@ int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const doub
     if (d_list_item) HIP_TRY(hipMemsetAsync(d_list_count, 0, sizeof(uint32_t), st));
     k_rm_collapse_eval_all<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, n_faces, d_verts, d_vn, d_vf_start, d_vf_face, min_len, max_len, max_q,
                                                                    d_edge_snap, d_length, d_ok, d_n_query, d_query, d_list_item, d_list_point, d_list_count,
-                                                                   (unsigned)(d_list_item ? list_cap : 0), round, d_eval_round, d_touched);
+                                                                   (unsigned)(d_list_item ? list_cap : 0));
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -529,15 +507,6 @@ int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_quer
     { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
     k_rm_surface_filter<<<grid_for(n_items * max_q, kTraceBlock, s->grid_trace), kTraceBlock, 0, st>>>(trace_ctx(s), s->faces, s->verts, d_ok, d_n_query, d_query,
                                                                                                         n_items, max_q, max_dist);
-    HIP_TRY(hipGetLastError());
-    return DRT_OK;
-}
-
-int drt_rm_mark_touched(const uint8_t* d_dirty, const int64_t* d_faces, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, int round,
-                        int32_t* d_touched, void* stream) {
-    if (n_verts <= 0) return DRT_OK;
-    if (!d_dirty || !d_faces || !d_vf_start || !d_vf_face || !d_touched) return fail(DRT_E_INVALID, "null pointer argument");
-    k_rm_mark_touched<<<blocks_for(n_verts), 256, 0, (hipStream_t)stream>>>(d_dirty, d_faces, d_vf_start, d_vf_face, n_verts, round, d_touched);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

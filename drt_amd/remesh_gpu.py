@@ -39,7 +39,6 @@ MAX_ROUNDS = 96            # evaluate / claim / apply rounds per step (a round a
 SUB_ROUNDS = int(__import__("os").environ.get("DRT_REMESH_SUB_ROUNDS", 3))     # claim / apply pairs per evaluation (one set of edge tables, vertex -> face lists and surface queries
                            # serves several independent sets: candidates whose neighbourhood an earlier pair of the round touched sit out until the next evaluation)
 TAIL_CUT = int(__import__("os").environ.get("DRT_REMESH_TAIL_CUT", 32))       # a step ends when a round applies less than 1 / TAIL_CUT of what its first round applied
-KEEP_VERDICTS = __import__("os").environ.get("DRT_REMESH_KEEP_VERDICTS", "1") != "0"      # collapse rounds evaluate only what the previous round changed (see k_rm_collapse_eval_all)
 DEBUG = False
 
 
@@ -146,9 +145,6 @@ class _Work:
         dirty = torch.empty(nv, dtype=torch.uint8, device=dev)
         f_alive = torch.empty(nf, dtype=torch.uint8, device=dev)
         n_done = torch.zeros(1, dtype=torch.int32, device=dev)
-        # verdicts carried from round to round (KEEP_VERDICTS): the round a slot was last evaluated in, the round a vertex's neighbourhood last changed in
-        eval_round = torch.full((3 * nf,), -1, dtype=torch.int32, device=dev) if KEEP_VERDICTS else None
-        touched = torch.full((nv,), -1, dtype=torch.int32, device=dev) if KEEP_VERDICTS else None
         for rnd in range(MAX_ROUNDS + 1):
             if rnd == MAX_ROUNDS:
                 self.stats["collapse_unfinished"] += 1            # candidates were still being applied when the rounds ran out
@@ -158,8 +154,7 @@ class _Work:
             vn = self.vertex_normals(vf_start, vf_face)
             _check(lib.drt_rm_collapse_eval_all(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
                                                 float(min_len), float(max_len), MAX_Q, E_snap.data_ptr(), length.data_ptr(), ok.data_ptr(),
-                                                nq.data_ptr(), q.data_ptr(), _lib.ptr(ql_item), _lib.ptr(ql_point), _lib.ptr(ql_count), ql_cap,
-                                                rnd, _lib.ptr(eval_round), _lib.ptr(touched), _stream()))
+                                                nq.data_ptr(), q.data_ptr(), _lib.ptr(ql_item), _lib.ptr(ql_point), _lib.ptr(ql_count), ql_cap, _stream()))
             # CheckSurfDist: the midpoint and the centroid of every face that survives must stay near the input surface
             if check_dist:
                 _check(lib.drt_rm_surface_filter_list(self.surface._h, ok.data_ptr(), ql_item.data_ptr(), ql_point.data_ptr(), ql_count.data_ptr(), ql_cap,
@@ -169,8 +164,6 @@ class _Work:
             _check(lib.drt_rm_collapse_apply(None, 3 * nf, ok.data_ptr(), E_snap.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
                                              vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, length.data_ptr(),
                                              lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), dirty.data_ptr(), SUB_ROUNDS, n_done.data_ptr(), _stream()))
-            if KEEP_VERDICTS:
-                _check(lib.drt_rm_mark_touched(dirty.data_ptr(), self.F.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(), nv, rnd, touched.data_ptr(), _stream()))
             _check(lib.drt_rm_kill_faces(self.F.data_ptr(), f_alive.data_ptr(), nf, _stream()))
             n = int(n_done.item())                                # the round's one host round trip
             if DEBUG:

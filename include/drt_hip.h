@@ -376,12 +376,7 @@ int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* 
 int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
                              const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
                              uint8_t* d_ok, int32_t* d_n_query, double* d_query, int32_t* d_list_item, double* d_list_point, uint32_t* d_list_count,
-                             int64_t list_cap, int round, int32_t* d_eval_round, const int32_t* d_touched, void* stream);
-/* (round / d_eval_round int32 [3 n_faces] / d_touched int32 [n_verts], optional, both initialised to -1 by the caller: a slot whose two
- * vertices carry no stamp since the round it was evaluated in keeps that round's verdict -- d_ok, d_n_query untouched, nothing appended
- * to the list; drt_rm_mark_touched stamps the vertices a round's collapses dirtied, and their neighbours, with the round.) */
-int drt_rm_mark_touched(const uint8_t* d_dirty, const int64_t* d_faces, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, int round,
-                        int32_t* d_touched, void* stream);
+                             int64_t list_cap, void* stream);
 /* (d_list_item / d_list_point / d_list_count, optional: the query points of the candidates that passed, appended to ONE compact list of at
  * most list_cap entries -- item = slot, point [3] -- whose length stays on the device; a candidate that does not fit is left to the next
  * round.  drt_rm_surface_filter_list is drt_rm_surface_filter over that list.) */

@@ -98,25 +98,6 @@ def test_device_remesh_is_deterministic(hand):
     assert np.array_equal(a.vertices, b.vertices) and np.array_equal(a.faces, b.faces)
 
 
-@pytest.mark.parametrize("L", [6.0, 3.0])
-def test_verdicts_carried_across_collapse_rounds_change_nothing(hand, L):
-    """Round 6: a collapse round evaluates only the candidates whose neighbourhood the previous round changed and keeps the verdicts of the
-    others (k_rm_collapse_eval_all / k_rm_mark_touched).  A kept verdict is the verdict a fresh evaluation would give -- so the remeshed mesh
-    must be the SAME mesh, vertex for vertex and face for face, as with every candidate evaluated in every round."""
-    from drt_amd import remesh_gpu
-    old = remesh_gpu.KEEP_VERDICTS
-    try:
-        remesh_gpu.KEEP_VERDICTS = False
-        a, sa = _gpu_remesh(hand, L)
-        remesh_gpu.KEEP_VERDICTS = True
-        b, sb = _gpu_remesh(hand, L)
-    finally:
-        remesh_gpu.KEEP_VERDICTS = old
-    assert sa["collapsed"] > 100 and sa["collapse_rounds"] >= 3
-    assert sa == sb
-    assert np.array_equal(a.faces, b.faces) and np.array_equal(a.vertices, b.vertices)
-
-
 def test_device_split_alone_equals_the_host_split(hand):
     """The refine step has no order dependence: same vertices (the input's, then the midpoints of the long edges in ascending edge
     order vs. in face order) and, up to that renumbering, the same faces -- compared as a set of triangles over vertex POSITIONS."""
