@@ -187,7 +187,11 @@ __global__ void k_rm_collapse_eval_all(const int64_t* __restrict__ F, int64_t n_
     // candidate to the next round.
     if (ql_item && ok[c]) {
         const unsigned nq = (unsigned)n_query[c], base = atomicAdd(ql_count, nq);
-        if (base + nq > ql_cap) { ok[c] = 0; return; }
+        if (base + nq > ql_cap) {              // does not fit: left to the next round; what it reserved below the cap becomes skipped entries
+            ok[c] = 0;
+            for (unsigned j = base; j < ql_cap; ++j) ql_item[j] = -1;
+            return;
+        }
         const double* qc = q + 3 * (int64_t)max_q * c;
         for (unsigned k = 0; k < nq; ++k) {
             ql_item[base + k] = (int32_t)c;
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter_list(TraceCtx
     const unsigned n = min(*count, cap);
     for (unsigned i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
         const int32_t it = item[i];
-        if (!ok[it]) continue;
+        if (it < 0 || !ok[it]) continue;
         const Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(point, i), st);
         if (!(sqrt(r.dist2) <= max_dist)) ok[it] = 0;
     }

@@ -136,7 +136,7 @@ class _Work:
         nq = torch.empty(3 * nf, dtype=torch.int32, device=dev)
         q = torch.empty((3 * nf, MAX_Q, 3), dtype=torch.float64, device=dev)
         check_dist = self.surface is not None and np.isfinite(self.max_dist)
-        ql_cap = 3 * nf * 4                                      # query points of a round (a candidate that does not fit waits for the next one)
+        ql_cap = 3 * nf * 8                                      # query points of a round (a candidate that does not fit waits for the next one)
         ql_item = torch.empty(ql_cap, dtype=torch.int32, device=dev) if check_dist else None
         ql_point = torch.empty((ql_cap, 3), dtype=torch.float64, device=dev) if check_dist else None
         ql_count = torch.zeros(1, dtype=torch.int32, device=dev) if check_dist else None
