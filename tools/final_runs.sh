@@ -4,6 +4,7 @@
 set -u
 P=${1:-r06}
 O=gpurun_out/final_$P; mkdir -p $O
+python -m pytest tests -m gpu -q > $O/gputest.log 2>&1      # the whole GPU suite on this box, first
 export DRT_BENCH_REPEATS=5      # (the many small runs of this batch: five repeats of the timed region each; the bench lines at the end run the sustained default)
 {
   for cfg in "--mesh hand --res 512 --views 72" "--mesh mouse --res 1024 --views 72" "--mesh horse --res 1024 --views 72" "--mesh monkey --res 1024 --views 72" "--mesh monkey --res 1024 --views 144"; do
