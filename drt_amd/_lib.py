@@ -23,6 +23,9 @@ SIGNATURES = {
     "drt_version": (_c.c_int, []),
     "drt_deterministic": (_c.c_int, [_c.c_int]),
     "drt_fx_finalize": (_c.c_int, [_P, _I64, _P, _c.c_int, _P]),
+    "drt_fx_add": (_c.c_int, [_P, _P, _I64, _P]),
+    "drt_fx_to_limbs": (_c.c_int, [_P, _I64, _P, _P]),
+    "drt_fx_from_limbs": (_c.c_int, [_P, _I64, _P, _P]),
     "drt_create": (_c.c_int, [_c.c_int, _c.POINTER(_P)]),
     "drt_destroy": (None, [_P]),
     "drt_update_mesh": (_c.c_int, [_P, _P, _I64, _P, _I64, _P]),

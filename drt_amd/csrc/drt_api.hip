@@ -43,6 +43,44 @@ __global__ void __launch_bounds__(256) k_fx_finalize(const FxCell* __restrict__ 
     }
 }
 
+// dst += src, cell by cell (the sums of several calls, or of several ranks, before ONE conversion)
+__global__ void __launch_bounds__(256) k_fx_add(FxCell* __restrict__ dst, const FxCell* __restrict__ src, int64_t n) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const FxCell a = dst[i], b = src[i];
+        const Fx128 r = fx_add(Fx128{a.hi, a.lo}, Fx128{b.hi, b.lo});
+        dst[i] = FxCell{r.hi, r.lo, a.flags | b.flags};
+    }
+}
+// The exchange format of an all-reduce(SUM) over int64: a cell as four words whose plain per-word sums over up to 2^20 ranks cannot
+// overflow -- three limbs of 43 bits (the top one signed) and the three flags as counters in 20-bit digits.  value = l0 + l1 2^43 + l2 2^86.
+constexpr int kLimbBits = 43;
+__global__ void __launch_bounds__(256) k_fx_to_limbs(const FxCell* __restrict__ cells, int64_t n, int64_t* __restrict__ limbs) {
+    constexpr uint64_t kMask = (1ull << kLimbBits) - 1ull;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const FxCell c = cells[i];
+        const uint64_t hi = (uint64_t)c.hi;
+        limbs[4 * i + 0] = (int64_t)(c.lo & kMask);
+        limbs[4 * i + 1] = (int64_t)(((c.lo >> kLimbBits) | (hi << (64 - kLimbBits))) & kMask);
+        limbs[4 * i + 2] = c.hi >> (2 * kLimbBits - 64);                      // arithmetic shift: the sign lives here
+        limbs[4 * i + 3] = (int64_t)(((c.flags & kFxNaN) ? 1ull : 0ull) | ((c.flags & kFxPosInf) ? 1ull << 20 : 0ull) | ((c.flags & kFxNegInf) ? 1ull << 40 : 0ull));
+    }
+}
+__global__ void __launch_bounds__(256) k_fx_from_limbs(const int64_t* __restrict__ limbs, int64_t n, FxCell* __restrict__ cells) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        // (each limb is a signed 64-bit number now: sign-extend it to 128 bits, shift it into place, add)
+        auto wide = [](int64_t v, int shift) {
+            Fx128 r{v < 0 ? -1 : 0, (uint64_t)v};
+            if (shift >= 64) { r.hi = (int64_t)((uint64_t)v << (shift - 64)); r.lo = 0; }
+            else if (shift > 0) { r.hi = (int64_t)(((uint64_t)r.hi << shift) | ((uint64_t)v >> (64 - shift))); r.lo = (uint64_t)v << shift; }
+            return r;
+        };
+        const Fx128 r = fx_add(fx_add(wide(limbs[4 * i], 0), wide(limbs[4 * i + 1], kLimbBits)), wide(limbs[4 * i + 2], 2 * kLimbBits));
+        const uint64_t f = (uint64_t)limbs[4 * i + 3];
+        const uint64_t flags = ((f & 0xFFFFFull) ? kFxNaN : 0u) | (((f >> 20) & 0xFFFFFull) ? kFxPosInf : 0u) | (((f >> 40) & 0xFFFFFull) ? kFxNegInf : 0u);
+        cells[i] = FxCell{r.hi, r.lo, flags};
+    }
+}
+
 extern "C" {
 
 const char* drt_last_error(void) { return g_err; }
@@ -52,6 +90,30 @@ int drt_deterministic(int on) {
     const int was = det_mode() ? 1 : 0;
     if (on >= 0) g_det = on != 0;
     return was;
+}
+int drt_fx_add(void* d_dst_cells, const void* d_src_cells, int64_t n, void* stream) {
+    if (n < 0) return fail(DRT_E_INVALID, "negative size");
+    if (n == 0) return DRT_OK;
+    if (!d_dst_cells || !d_src_cells) return fail(DRT_E_INVALID, "null pointer argument");
+    k_fx_add<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(static_cast<FxCell*>(d_dst_cells), static_cast<const FxCell*>(d_src_cells), n);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+int drt_fx_to_limbs(const void* d_cells, int64_t n, int64_t* d_limbs, void* stream) {
+    if (n < 0) return fail(DRT_E_INVALID, "negative size");
+    if (n == 0) return DRT_OK;
+    if (!d_cells || !d_limbs) return fail(DRT_E_INVALID, "null pointer argument");
+    k_fx_to_limbs<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(static_cast<const FxCell*>(d_cells), n, d_limbs);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+int drt_fx_from_limbs(const int64_t* d_limbs, int64_t n, void* d_cells, void* stream) {
+    if (n < 0) return fail(DRT_E_INVALID, "negative size");
+    if (n == 0) return DRT_OK;
+    if (!d_cells || !d_limbs) return fail(DRT_E_INVALID, "null pointer argument");
+    k_fx_from_limbs<<<grid_for(n, 256, 1024), 256, 0, (hipStream_t)stream>>>(d_limbs, n, static_cast<FxCell*>(d_cells));
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
 }
 int drt_fx_finalize(const void* d_cells, int64_t n, double* d_out, int accumulate, void* stream) {
     if (n < 0) return fail(DRT_E_INVALID, "negative size");

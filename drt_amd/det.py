@@ -63,3 +63,44 @@ def value_into(a, out, stream=None):
     with _on(a.device):
         _lib.check(_lib.lib().drt_fx_finalize(a.data_ptr(), out.numel(), out.data_ptr(), 0, _stream() if stream is None else stream))
     return out
+
+
+# ---- the step's gradient as ONE exact sum over calls and ranks (drt_amd.optim.full_batch_step) -------------------------------------------
+# While a sink is armed, the backward passes of the refraction terms do not hand autograd a float64 gradient: they leave their
+# accumulator cells (and the scalar they would have been scaled by) here.  `collect` adds the cells of all calls (integers), all-reduces
+# them over the ranks as integers (drt_fx_to_limbs: per-word sums that cannot overflow), converts ONCE and scales -- every rank converts
+# the same integer, so N GPUs produce the bits one GPU produces.
+SINK = None
+
+
+def begin_sink():
+    global SINK
+    SINK = [] if on() else None
+    return SINK
+
+
+def end_sink():
+    global SINK
+    entries, SINK = SINK, None
+    return entries or []
+
+
+def collect(entries, like, allreduce, scale):
+    """float64 gradient shaped ``like`` = ``scale`` x the exact sum of the sink's entries [(cells, incoming gradient)] over calls and ranks,
+    all-reduced with ``allreduce(int64 tensor)`` (drt_amd.dist.allreduce_sum_).  ``scale``: the ONE incoming gradient every entry saw (the
+    seed of full_batch_step's backward pass; a sum node hands it to every term unchanged).  A rank without entries takes part with zeros."""
+    from .optix_mesh import _stream, _on
+    lib, n = _lib.lib(), like.numel()
+    total = entries[0][0] if entries else torch.zeros(n * _CELL_WORDS, dtype=torch.int64, device=like.device)
+    with _on(like.device):
+        if len(entries) > 1:
+            total = total.clone()
+            for cells, _ in entries[1:]:
+                _lib.check(lib.drt_fx_add(total.data_ptr(), cells.data_ptr(), n, _stream()))
+        limbs = torch.empty(n * 4, dtype=torch.int64, device=like.device)
+        _lib.check(lib.drt_fx_to_limbs(total.data_ptr(), n, limbs.data_ptr(), _stream()))
+        allreduce(limbs)
+        summed = torch.empty_like(total)
+        _lib.check(lib.drt_fx_from_limbs(limbs.data_ptr(), n, summed.data_ptr(), _stream()))
+    return value(summed, like) * scale
+

@@ -540,8 +540,11 @@ class _RenderTransparent(torch.autograd.Function):
                     rows.data_ptr(), n_rows.data_ptr(), sp.data_ptr(), scale.data_ptr(), grad_v.data_ptr(), _stream()))
         if grad_v is not None:
             grad_v = det.value(grad_v, v)          # (deterministic mode: the exact integer sums, rounded once)
-        for rows, stash, _, scale in pending:
+        for rows, stash, wide, scale in pending:
             if rows is None:
+                if det.SINK is not None and wide is not None:
+                    det.SINK.append((wide, scale))        # full_batch_step sums the cells of all calls and ranks exactly, then converts once
+                    continue
                 grad_v = torch.addcmul(grad_v, stash, scale) if grad_v is not None else stash * scale
         return grad_v, None, None, None, None, None, None, None, None
 
@@ -561,7 +564,7 @@ class _RayLoss(torch.autograd.Function):
         need = ctx.needs_input_grad[1]
         ctx.link = link if need else None
         g = torch.empty_like(od) if need and link is None else None      # dense d loss / d out_dir only without a link
-        ctx.stash = None
+        ctx.stash = ctx.stash_wide = None
         own = (link is not None and link.paths is not None and link.paths[0] is not None and link.mask is not None
                and link.mask() is mask and mask._version == 0)           # the forward's own mask, untouched: its list of set rows is exact
         eager = (own and need and EAGER_LOSS_GRAD and link.render is not None and link.out_ori is not None and link.out_ori() is out_ori
@@ -583,6 +586,7 @@ class _RayLoss(torch.autograd.Function):
                 _lib.check(fn(
                     scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), n, ior[0], ior[1], face1.data_ptr(), face2.data_ptr(),
                     sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(), link.paths[1].data_ptr(), loss.data_ptr(), ctx.stash.data_ptr(), _stream()))
+                ctx.stash_wide = ctx.stash if ctx.stash.dtype == torch.int64 else None      # (deterministic mode: the cells themselves, for det.SINK)
                 ctx.stash = det.value(ctx.stash, v)
             elif own:
                 _lib.check(_lib.lib().drt_ray_loss_listed(oo.data_ptr(), od.data_ptr(), sp.data_ptr(), va.data_ptr(), link.paths[0].data_ptr(),
@@ -604,7 +608,7 @@ class _RayLoss(torch.autograd.Function):
                 return None, None, None, None, None, None
             scale = g_loss.detach().to(torch.float64).reshape(1).contiguous()
             if ctx.stash is not None:
-                ctx.link.pending.append((None, ctx.stash, None, scale))
+                ctx.link.pending.append((None, ctx.stash, ctx.stash_wide, scale))
                 return None, ctx.link.token(ctx.n_rays, ctx.stash.device), None, None, None, None
             ctx.link.pending.append((rows, n_rows, sp, scale))
             return None, ctx.link.token(ctx.n_rays, rows.device), None, None, None, None
@@ -646,12 +650,16 @@ class _RenderRayLossFused(torch.autograd.Function):
             _lib.check(_lib.lib().drt_render_ray_loss_fused(
                 scene.optix_mesh._h, v.data_ptr(), o.data_ptr(), d.data_ptr(), sp.data_ptr(), va.data_ptr(), o.shape[0],
                 float(ior_int), float(ior_ext), loss.data_ptr(), grad_v.data_ptr(), None, *_tile_hint(o.shape[0]), grid[0], _lib.ptr(grid[1]), _stream()))
+        ctx.wide = grad_v if grad_v.dtype == torch.int64 else None
         ctx.save_for_backward(det.value(grad_v, v))
         return det.value(loss)
 
     @staticmethod
     def backward(ctx, g_loss):
         (grad_v,) = ctx.saved_tensors
+        if det.SINK is not None and ctx.wide is not None:
+            det.SINK.append((ctx.wide, g_loss))
+            return None, None, None, None, None, None, None, None, None
         return grad_v * g_loss, None, None, None, None, None, None, None, None
 
 

@@ -425,9 +425,25 @@ def full_batch_step(scene, local_views, init_vertices, parameter, opt, ray_w, fu
         raise RuntimeError("full_batch_step: `parameter` has a gradient hook; build it with setup_opt(..., hook=False) "
                            "(limit_hook is applied here, after the all-reduce)")
     opt.zero_grad(set_to_none=True)
-    loss = local_loss_backward(scene, local_views, init_vertices, parameter, ray_w, fused)
-    g = parameter.grad if parameter.grad is not None else torch.zeros_like(parameter)   # a rank with no views
-    ddist.allreduce_sum_(g)                 # the only exchange of the step
+    from . import det
+    sink = det.begin_sink()                 # deterministic mode: the refraction terms leave their exact accumulators here instead of float64 gradients
+    try:
+        loss = local_loss_backward(scene, local_views, init_vertices, parameter, ray_w, fused)
+    finally:
+        entries = det.end_sink()
+    if sink is not None:
+        # ONE exchange, exact: the 128-bit sums of every call of every rank are added as integers and converted once -- N GPUs, one GPU, any
+        # split of the views give the same bits (what autograd did not route through the sink, nothing in this step, is added as before)
+        g = det.collect(entries, parameter, ddist.allreduce_sum_, _seed(ray_w, parameter))
+        if not (fused or (Render.EAGER_LOSS_GRAD and Render.SPARSE_LOSS_GRAD)):
+            # (module switches that route ray_loss's gradient through autograd as float64 instead: the same on every rank, so every rank
+            # joins this second collective or none does)
+            g = g + ddist.allreduce_sum_(parameter.grad if parameter.grad is not None else torch.zeros_like(parameter))
+        elif parameter.grad is not None:
+            raise RuntimeError("full_batch_step (deterministic mode): a gradient reached `parameter` outside the exact sink")
+    else:
+        g = parameter.grad if parameter.grad is not None else torch.zeros_like(parameter)   # a rank with no views
+        ddist.allreduce_sum_(g)             # the only exchange of the step
     parameter.grad = g if getattr(opt, "applies_limit", False) else limit_hook(g)     # clamp after the sum over views, as on one GPU
     opt.step()
     return loss

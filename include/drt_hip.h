@@ -50,6 +50,13 @@ int drt_version(void);       /* 2: drt_deterministic / drt_fx_finalize */
 #define DRT_FX_BYTES_PER_VALUE 24
 int drt_deterministic(int on);
 int drt_fx_finalize(const void* d_cells, int64_t n, double* d_out, int accumulate, void* stream);
+/* Sums of sums, still exact: drt_fx_add adds n cells of d_src_cells into d_dst_cells (several calls of one step).  For the step's ONE
+ * all-reduce over ranks drt_fx_to_limbs rewrites n cells as int64 [n,4] -- three 43-bit limbs of the 128-bit sum,
+ * the top one signed, and the flags as counters -- whose plain per-word SUM over up to 2^20 ranks cannot overflow; drt_fx_from_limbs
+ * puts the reduced words back together.  All ranks then convert the SAME integer: N GPUs give the bits one GPU gives. */
+int drt_fx_add(void* d_dst_cells, const void* d_src_cells, int64_t n, void* stream);
+int drt_fx_to_limbs(const void* d_cells, int64_t n, int64_t* d_limbs, void* stream);
+int drt_fx_from_limbs(const int64_t* d_limbs, int64_t n, void* d_cells, void* stream);
 
 /* ---- lifetime: replaces optix_mesh::optix_mesh(cuda_device), optix_extend.cpp:8-12 ---- */
 int drt_create(int device, drt_scene_t** out);
