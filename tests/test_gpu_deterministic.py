@@ -85,7 +85,6 @@ def test_a_sum_split_over_two_ranks_is_within_one_rounding_of_its_parts(det_on):
     # truncation of sub-unit contributions (< 2^-80 each, a few thousand per vertex at most) is far below these bounds
     bound = (g_a.abs() + g_b.abs() + two.abs()) * 2.0 ** -53 + 1e-20
     assert bool(((two - g_all).abs() <= bound).all()), float(((two - g_all).abs() / bound).max())
-    assert float((two - g_all).abs().max()) > 0 or True
 
 
 @pytest.mark.parametrize("fused", [False, True])
