@@ -13,7 +13,7 @@
 // (tests/test_gpu_remesh.py), the host version being the checker.
 //
 // Layout: faces int64 [F,3] (what drt_edge_tables takes), vertices float64 [V,3]; vertex -> incident faces as a CSR pair
-// (vf_start int64 [V+1], vf_face int64 [3F]: face ids grouped by vertex, ascending -- built by the driver with a stable sort).
+// (vf_start int64 [V+1], vf_face int64 [3F]: face ids grouped by vertex, ascending -- drt_rm_vertex_faces: count, scan, fill, sort each run).
 #include "drt_device.h"
 
 namespace {
@@ -52,23 +52,57 @@ __device__ __forceinline__ void collect_ring(int64_t v, const int64_t* __restric
 }
 
 // ---- split -------------------------------------------------------------------------------------------------------------------
+// Long edges by directed-edge slot c = 3 f + k (the lo -> hi slot of an edge speaks for it, as in the collapse and the flip): no sorted edge
+// table.  k_rm_split_mark flags them; the caller's prefix sum of the flags numbers the new vertices; k_rm_split_assign hands every slot --
+// the owner and the slot across the edge, found in the vertex -> face list of the edge's far end -- the midpoint vertex of its edge or -1.
+__global__ void k_rm_split_mark(const int64_t* __restrict__ F, int64_t n_faces, const double* __restrict__ V, double max_len, uint8_t* __restrict__ flag) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= 3 * n_faces) return;
+    const int64_t f = c / 3;
+    const int64_t a = F[c], b = F[3 * f + (int)(c - 3 * f + 1) % 3];
+    flag[c] = a >= 0 && a < b && len3(ldv(V, a) - ldv(V, b)) > max_len;
+}
+__global__ void k_rm_split_assign(const int64_t* __restrict__ F, int64_t n_faces, const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face,
+                                  const uint8_t* __restrict__ flag, const int64_t* __restrict__ rank /* inclusive prefix sum of flag */, int64_t n_verts,
+                                  int64_t* __restrict__ mid_of_slot) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= 3 * n_faces) return;
+    const int64_t f = c / 3;
+    const int64_t a = F[c], b = F[3 * f + (int)(c - 3 * f + 1) % 3];
+    if (a < 0) { mid_of_slot[c] = -1; return; }
+    if (!(a < b)) return;                                      // (written by the owner of the edge)
+    const int64_t mid = flag[c] ? n_verts + rank[c] - 1 : -1;
+    mid_of_slot[c] = mid;
+    for (int64_t s = vf_start[b]; s < vf_start[b + 1]; ++s) {
+        const int64_t g = vf_face[s];
+        for (int k = 0; k < 3; ++k)
+            if (F[3 * g + k] == b && F[3 * g + (k + 1) % 3] == a) { mid_of_slot[3 * g + k] = mid; return; }
+    }
+}
+// the midpoints, written behind the old vertices: (V[lo] + V[hi]) * 0.5, the host version's bits
+__global__ void k_rm_split_midpoints(const int64_t* __restrict__ F, int64_t n_faces, const int64_t* __restrict__ mid_of_slot, double* __restrict__ V) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= 3 * n_faces) return;
+    const int64_t f = c / 3;
+    const int64_t a = F[c], b = F[3 * f + (int)(c - 3 * f + 1) % 3], m = mid_of_slot[c];
+    if (a >= 0 && a < b && m >= 0) store_d3(V, m, (ldv(V, a) + ldv(V, b)) * 0.5);
+}
 // per face: the midpoint vertex of each of its edges (-1: not split) -> number of faces it becomes
-__global__ void k_rm_split_count(const int32_t* __restrict__ row2edge, const int64_t* __restrict__ mid_of_edge, int64_t n_faces,
-                                 int64_t* __restrict__ count) {
+__global__ void k_rm_split_count(const int64_t* __restrict__ mid_of_slot, int64_t n_faces, int64_t* __restrict__ count) {
     const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (f >= n_faces) return;
     int n = 0;
-    for (int k = 0; k < 3; ++k) n += mid_of_edge[row2edge[3 * f + k]] >= 0;
+    for (int k = 0; k < 3; ++k) n += mid_of_slot[3 * f + k] >= 0;
     count[f] = n + 1;
 }
 // the patterns of drt_remesh.cpp::split_long_edges: 1 -> 2 faces, 2 -> 3 with the shorter diagonal, 3 -> 4
-__global__ void k_rm_split_faces(const int64_t* __restrict__ F, const int32_t* __restrict__ row2edge, const int64_t* __restrict__ mid_of_edge,
+__global__ void k_rm_split_faces(const int64_t* __restrict__ F, const int64_t* __restrict__ mid_of_slot,
                                  const double* __restrict__ V /* midpoints already appended */, int64_t n_faces,
                                  const int64_t* __restrict__ offset /* exclusive prefix sum of the counts */, int64_t* __restrict__ out) {
     const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (f >= n_faces) return;
     const int64_t v[3] = {F[3 * f], F[3 * f + 1], F[3 * f + 2]};
-    const int64_t m[3] = {mid_of_edge[row2edge[3 * f]], mid_of_edge[row2edge[3 * f + 1]], mid_of_edge[row2edge[3 * f + 2]]};
+    const int64_t m[3] = {mid_of_slot[3 * f], mid_of_slot[3 * f + 1], mid_of_slot[3 * f + 2]};
     const int n = (m[0] >= 0) + (m[1] >= 0) + (m[2] >= 0);
     int64_t* o = out + 3 * offset[f];
     auto put = [&](int t, int64_t a, int64_t b, int64_t c) { o[3 * t] = a; o[3 * t + 1] = b; o[3 * t + 2] = c; };
@@ -100,6 +134,71 @@ __global__ void k_rm_vertex_normals(const int64_t* __restrict__ F, const double*
     store_d3(vn, v, s);
 }
 
+// ---- vertex -> incident faces ---------------------------------------------------------------------------------------------------
+// Every evaluate / claim / apply round needs this table of the mesh as it stands; a stable sort of the 3 F corner indices (torch.argsort:
+// a merge sort of a dozen launches, plus a gather and a search) took 160 us a time, 35 times per remesh call.  Count, scan, fill with an
+// atomic cursor, then each vertex puts its handful of faces in ascending order: four small launches, and the same table bit for bit
+// (ascending runs are what make the vertex normals -- float64 sums in run order -- and so the whole remesh deterministic).
+__global__ void k_rm_vf_count(const int64_t* __restrict__ F, int64_t n_corners, int32_t* count) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n_corners) return;
+    const int64_t v = F[c];
+    if (v >= 0) atomicAdd(&count[v], 1);                       // (a killed face holds -1: in nobody's run)
+}
+// exclusive scan of count[0 .. n) -> start[0 .. n] by ONE workgroup (n = V is tens of thousands): tiles of 4096, four counts per thread
+// (coalesced), a shuffle scan inside each wavefront, the sixteen wavefront totals through LDS, the running total carried from tile to tile
+__global__ void __launch_bounds__(1024) k_rm_vf_scan(const int32_t* __restrict__ count, int64_t n, int64_t* __restrict__ start) {
+    __shared__ int64_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int64_t carry = 0;
+    for (int64_t base = 0; base < n; base += 4096) {
+        const int64_t i = base + 4 * t;
+        int32_t c[4];
+        for (int k = 0; k < 4; ++k) c[k] = i + k < n ? count[i + k] : 0;
+        const int64_t s = ((int64_t)c[0] + c[1]) + ((int64_t)c[2] + c[3]);
+        int64_t x = s;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t y = __shfl_up((long long)x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int64_t before = 0, total = 0;
+        for (int j = 0; j < 16; ++j) { const int64_t q = wsum[j]; total += q; if (j < w) before += q; }
+        int64_t run = carry + before + x - s;
+        for (int k = 0; k < 4; ++k) if (i + k < n) { start[i + k] = run; run += c[k]; }
+        carry += total;
+        __syncthreads();
+    }
+    if (t == 0) start[n] = carry;
+}
+__global__ void k_rm_vf_fill(const int64_t* __restrict__ F, int64_t n_corners, const int64_t* __restrict__ start, int32_t* count, int64_t* __restrict__ vf_face) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n_corners) return;
+    const int64_t v = F[c];
+    if (v >= 0) vf_face[start[v] + (atomicSub(&count[v], 1) - 1)] = c / 3;
+}
+// each vertex: its run ascending (insertion sort of a handful), then -- when asked -- its area-weighted normal, summed in that order
+__global__ void k_rm_vf_sort(const int64_t* __restrict__ F, const int64_t* __restrict__ start, int64_t* __restrict__ vf_face, int64_t n_verts,
+                             const double* __restrict__ V, double* __restrict__ vn) {
+    const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (v >= n_verts) return;
+    const int64_t lo = start[v], hi = start[v + 1];
+    for (int64_t i = lo + 1; i < hi; ++i) {
+        const int64_t f = vf_face[i];
+        int64_t j = i;
+        for (; j > lo && vf_face[j - 1] > f; --j) vf_face[j] = vf_face[j - 1];
+        vf_face[j] = f;
+    }
+    if (!vn) return;
+    d3 s{0, 0, 0};
+    for (int64_t q = lo; q < hi; ++q) {
+        const int64_t f = vf_face[q];
+        s += tri_normal(ldv(V, F[3 * f]), ldv(V, F[3 * f + 1]), ldv(V, F[3 * f + 2]));
+    }
+    store_d3(vn, v, s);
+}
+
 // ---- collapse -----------------------------------------------------------------------------------------------------------------
 // faces around `v` (other than the two that die with edge (a, b)) must stay valid when v moves to pnew; their centroids after the move
 // go to the query list (drt_remesh.cpp::faces_stay_valid)
@@ -125,7 +224,7 @@ __device__ bool faces_stay_valid(int64_t v, d3 pnew, int64_t ea, int64_t eb, con
     return true;
 }
 
-// one thread per candidate edge (length < min_len, listed by the driver): every check of drt_remesh.cpp::collapse_short_edges but the
+// one candidate edge (length < min_len): every check of drt_remesh.cpp::collapse_short_edges but the
 // surface distance, whose query points (the midpoint, then the centroids of the surviving faces) it writes to q[c][max_q][3]
 __device__ void collapse_eval_one(int64_t c, int64_t a, int64_t b, const int64_t* __restrict__ F,
                                   const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start,
@@ -153,17 +252,7 @@ __device__ void collapse_eval_one(int64_t c, int64_t a, int64_t b, const int64_t
     n_query[c] = nq;
     ok[c] = 1;
 }
-__global__ void k_rm_collapse_eval(const int64_t* __restrict__ cand, int64_t n_cand, const int64_t* __restrict__ E, const int64_t* __restrict__ F,
-                                   const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start,
-                                   const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
-                                   uint8_t* __restrict__ ok, int32_t* __restrict__ n_query, double* __restrict__ q) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= n_cand) return;
-    ok[c] = 0; n_query[c] = 0;
-    const int64_t e = cand[c];
-    collapse_eval_one(c, E[2 * e], E[2 * e + 1], F, V, vn, vf_start, vf_face, min_len, max_len, max_q, ok, n_query, q);
-}
-// The same over EVERY directed-edge slot c = 3 f + k of the face array as it stands (round 6: no candidate list, so no stream compaction and
+// collapse_eval_one over EVERY directed-edge slot c = 3 f + k of the face array as it stands (round 6: no candidate list, so no stream compaction and
 // no host round trip per round).  Every edge of a closed oriented mesh is the directed edge lo -> hi of exactly one face corner: slots with
 // F[c] < F[next] are the unique edges, the others -- and the slots of faces an earlier round killed (indices -1) -- report ok = 0.  Also
 // leaves the round's snapshot of the slot's edge (the claim / apply passes rewrite F) and its length (the priority key).
@@ -209,8 +298,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter_list(TraceCtx
     for (unsigned i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
         const int32_t it = item[i];
         if (it < 0 || !ok[it]) continue;
-        const Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(point, i), st);
-        if (!(sqrt(r.dist2) <= max_dist)) ok[it] = 0;
+        if (!within_distance(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(point, i), max_dist, st)) ok[it] = 0;
     }
 }
 // CheckSurfDist for the candidates that passed: item i has n_query[i] (or one) query points in q[i][max_q][3]; a point farther than max_dist
@@ -225,8 +313,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter(TraceCtx c, c
         const int64_t item = i / max_q;
         const int k = (int)(i - item * max_q);
         if (!ok[item] || k >= (n_query ? n_query[item] : 1)) continue;
-        const Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(q, i), st);
-        if (!(sqrt(r.dist2) <= max_dist)) ok[item] = 0;
+        if (!within_distance(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(q, i), max_dist, st)) ok[item] = 0;
     }
 }
 // the faces a round's collapses killed leave the face array in place: their indices become -1 (the next round's tables skip them; one
@@ -297,33 +384,30 @@ __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_
 }
 
 // ---- flip ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool edge_exists(const int64_t* __restrict__ E, int64_t n_edges, int64_t x, int64_t y) {
-    const int64_t lo = x < y ? x : y, hi = x < y ? y : x;
-    int64_t l = 0, r = n_edges;                                  // E ascends by (lo, hi)
-    while (l < r) {
-        const int64_t mid = (l + r) >> 1;
-        const int64_t a = E[2 * mid], b = E[2 * mid + 1];
-        if (a < lo || (a == lo && b < hi)) l = mid + 1; else r = mid;
-    }
-    return l < n_edges && E[2 * l] == lo && E[2 * l + 1] == hi;
-}
-// one thread per edge: the rules of drt_remesh.cpp::flip_edges (valence improvement across nearly flat pairs, or the repair of a folded
-// pair); edge_rows [E,2] = the two directed-edge rows (3 f + k) of every unique edge.  Writes the four vertices and two faces of a flip
-// that passes, and the midpoint of the new edge as its surface-distance query.
-__global__ void k_rm_flip_eval(const int64_t* __restrict__ E, int64_t n_edges, const int64_t* __restrict__ edge_rows, const int64_t* __restrict__ F,
-                               const double* __restrict__ V, const double* __restrict__ vn, const int64_t* __restrict__ vf_start, double max_len,
-                               uint8_t* __restrict__ ok, int64_t* __restrict__ quad /* [E,6]: a b c d f1 f2 */, double* __restrict__ q) {
+// one thread per directed-edge slot c = 3 f + k of the face array (as the collapse: the slots with F[c] < F[next] are the unique edges of a
+// closed oriented mesh, the others report ok = 0): the rules of drt_remesh.cpp::flip_edges (valence improvement across nearly flat pairs,
+// or the repair of a folded pair).  The face across the edge and the "does edge (c, d) exist already" test both come from the vertex ->
+// face lists -- a walk over one ring -- so a flip round needs no edge table (round 6: the sorted edge list and the edge -> rows table were
+// 350 us of radix and merge sorts per round, most of a round).  Writes the four vertices and two faces of a flip that passes, and the
+// midpoint of the new edge as its surface-distance query.
+__global__ void k_rm_flip_eval(const int64_t* __restrict__ F, int64_t n_faces, const double* __restrict__ V, const double* __restrict__ vn,
+                               const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double max_len,
+                               uint8_t* __restrict__ ok, int64_t* __restrict__ quad /* [3F,6]: a b c d f1 f2 */, double* __restrict__ q) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (e >= n_edges) return;
+    if (e >= 3 * n_faces) return;
     ok[e] = 0;
-    const int64_t a = E[2 * e], b = E[2 * e + 1];
-    int64_t f1 = edge_rows[2 * e] / 3, f2 = edge_rows[2 * e + 1] / 3;
-    auto has_dir = [&](int64_t f, int64_t x, int64_t y) { for (int k = 0; k < 3; ++k) if (F[3 * f + k] == x && F[3 * f + (k + 1) % 3] == y) return true; return false; };
-    if (!has_dir(f1, a, b)) { const int64_t t = f1; f1 = f2; f2 = t; }
-    if (!has_dir(f1, a, b) || !has_dir(f2, b, a)) return;
-    auto third = [&](int64_t f) { for (int k = 0; k < 3; ++k) if (F[3 * f + k] != a && F[3 * f + k] != b) return F[3 * f + k]; return (int64_t)-1; };
-    const int64_t c = third(f1), d = third(f2);
-    if (c < 0 || d < 0 || c == d) return;
+    const int64_t f1 = e / 3;
+    const int k1 = (int)(e - 3 * f1);
+    const int64_t a = F[e], b = F[3 * f1 + (k1 + 1) % 3], c = F[3 * f1 + (k1 + 2) % 3];
+    if (a < 0 || !(a < b)) return;
+    // the face that holds the edge the other way round (b -> a): one of b's
+    int64_t f2 = -1, d = -1;
+    for (int64_t s = vf_start[b]; s < vf_start[b + 1] && f2 < 0; ++s) {
+        const int64_t f = vf_face[s];
+        for (int k = 0; k < 3; ++k)
+            if (F[3 * f + k] == b && F[3 * f + (k + 1) % 3] == a) { f2 = f; d = F[3 * f + (k + 2) % 3]; break; }
+    }
+    if (f2 < 0 || c < 0 || d < 0 || c == d || c == a || c == b || d == a || d == b) return;
     auto val = [&](int64_t v) { return (int)(vf_start[v + 1] - vf_start[v]); };
     const int va = val(a), vb = val(b), vc = val(c), vd = val(d);
     if (va < 4 || vb < 4) return;
@@ -331,20 +415,23 @@ __global__ void k_rm_flip_eval(const int64_t* __restrict__ E, int64_t n_edges, c
     const d3 n1 = tri_normal(ldv(V, F[3 * f1]), ldv(V, F[3 * f1 + 1]), ldv(V, F[3 * f1 + 2]));
     const d3 n2 = tri_normal(ldv(V, F[3 * f2]), ldv(V, F[3 * f2 + 1]), ldv(V, F[3 * f2 + 2]));
     const d3 m1 = tri_normal(pc, pa, pd), m2 = tri_normal(pd, pb, pc);
-    const double l1 = len3(n1), l2 = len3(n2), k1 = len3(m1), k2 = len3(m2);
-    if (!(k1 > 1e-12 * (1.0 + l1)) || !(k2 > 1e-12 * (1.0 + l2))) return;
+    const double l1 = len3(n1), l2 = len3(n2), k1n = len3(m1), k2n = len3(m2);
+    if (!(k1n > 1e-12 * (1.0 + l1)) || !(k2n > 1e-12 * (1.0 + l2))) return;
     const bool folded = dot(n1, n2) < -0.5 * l1 * l2;                      // the pair overlaps itself: repair, whatever the valences
     if (folded) {
-        if (dot(m1, m2) < 0.5 * k1 * k2) return;
+        if (dot(m1, m2) < 0.5 * k1n * k2n) return;
         if (agreement(m1, vn, c, a, d) < 0.3 || agreement(m2, vn, d, b, c) < 0.3) return;
     } else {
         const int before = abs(va - 6) + abs(vb - 6) + abs(vc - 6) + abs(vd - 6);
         const int after = abs(va - 7) + abs(vb - 7) + abs(vc - 5) + abs(vd - 5);
         if (after >= before) return;
         if (dot(n1, n2) < 0.94 * l1 * l2) return;                          // only across nearly flat pairs (< 20 degrees)
-        if (dot(m1, n1) < 0.5 * k1 * l1 || dot(m1, n2) < 0.5 * k1 * l2 || dot(m2, n1) < 0.5 * k2 * l1 || dot(m2, n2) < 0.5 * k2 * l2) return;
+        if (dot(m1, n1) < 0.5 * k1n * l1 || dot(m1, n2) < 0.5 * k1n * l2 || dot(m2, n1) < 0.5 * k2n * l1 || dot(m2, n2) < 0.5 * k2n * l2) return;
     }
-    if (edge_exists(E, n_edges, c, d)) return;
+    for (int64_t s = vf_start[c]; s < vf_start[c + 1]; ++s) {              // edge (c, d) exists already: a face of c holds d
+        const int64_t f = vf_face[s];
+        if (F[3 * f] == d || F[3 * f + 1] == d || F[3 * f + 2] == d) return;
+    }
     if (len3(pc - pd) > max_len) return;
     const d3 mid = (pc + pd) * 0.5;
     q[3 * e] = mid.x; q[3 * e + 1] = mid.y; q[3 * e + 2] = mid.z;
@@ -357,7 +444,9 @@ __global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok,
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= n_edges || !ok[e]) return;
     const int64_t* o = quad + 6 * e;
-    const unsigned key = (unsigned)e;
+    // priority: a bijective hash of the slot (a strict index order would leave only the local minima of a smooth field to win a round)
+    unsigned key = (unsigned)e * 2654435761u;
+    key ^= key >> 15; key *= 2246822519u; key ^= key >> 13;
     // (sub-rounds as in k_rm_collapse_claim: a flip that went ahead dirties its four vertices -- their valences and two of their faces
     // changed; a later sub-round admits only quads that are clean, whose evaluation therefore still stands)
     if (!APPLY) {
@@ -435,17 +524,49 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? 
 
 extern "C" {
 
-int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int32_t* d_row2edge, const int64_t* d_mid_of_edge, const double* d_verts,
-                       int64_t* d_count, const int64_t* d_offset, int64_t* d_faces_out, void* stream) {
+int drt_rm_split_mark(const int64_t* d_faces, int64_t n_faces, const double* d_verts, double max_len, uint8_t* d_flag, void* stream) {
     if (n_faces < 0) return fail(DRT_E_INVALID, "negative face count");
     if (n_faces == 0) return DRT_OK;
-    if (!d_faces || !d_row2edge || !d_mid_of_edge) return fail(DRT_E_INVALID, "null pointer argument");
+    if (!d_faces || !d_verts || !d_flag) return fail(DRT_E_INVALID, "null pointer argument");
+    k_rm_split_mark<<<blocks_for(3 * n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, n_faces, d_verts, max_len, d_flag);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_split_plan(const int64_t* d_faces, int64_t n_faces, const int64_t* d_vf_start, const int64_t* d_vf_face, const uint8_t* d_flag,
+                      const int64_t* d_rank, int64_t n_verts, int64_t* d_mid_of_slot, int64_t* d_count, void* stream) {
+    if (n_faces < 0) return fail(DRT_E_INVALID, "negative face count");
+    if (n_faces == 0) return DRT_OK;
+    if (!d_faces || !d_vf_start || !d_vf_face || !d_flag || !d_rank || !d_mid_of_slot || !d_count) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    if (d_count) k_rm_split_count<<<blocks_for(n_faces), 256, 0, st>>>(d_row2edge, d_mid_of_edge, n_faces, d_count);
-    if (d_faces_out) {
-        if (!d_offset || !d_verts) return fail(DRT_E_INVALID, "null pointer argument");
-        k_rm_split_faces<<<blocks_for(n_faces), 256, 0, st>>>(d_faces, d_row2edge, d_mid_of_edge, d_verts, n_faces, d_offset, d_faces_out);
-    }
+    k_rm_split_assign<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, n_faces, d_vf_start, d_vf_face, d_flag, d_rank, n_verts, d_mid_of_slot);
+    k_rm_split_count<<<blocks_for(n_faces), 256, 0, st>>>(d_mid_of_slot, n_faces, d_count);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int64_t* d_mid_of_slot, double* d_verts, const int64_t* d_offset,
+                       int64_t* d_faces_out, void* stream) {
+    if (n_faces < 0) return fail(DRT_E_INVALID, "negative face count");
+    if (n_faces == 0) return DRT_OK;
+    if (!d_faces || !d_mid_of_slot || !d_verts || !d_offset || !d_faces_out) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    k_rm_split_midpoints<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, n_faces, d_mid_of_slot, d_verts);
+    k_rm_split_faces<<<blocks_for(n_faces), 256, 0, st>>>(d_faces, d_mid_of_slot, d_verts, n_faces, d_offset, d_faces_out);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_vertex_faces(const int64_t* d_faces, int64_t n_faces, int64_t n_verts, int32_t* d_count, int64_t* d_vf_start, int64_t* d_vf_face,
+                        const double* d_verts, double* d_vn, void* stream) {
+    if (n_faces < 0 || n_verts <= 0) return fail(DRT_E_INVALID, "bad mesh size");
+    if (!d_count || !d_vf_start || !d_vf_face || (n_faces && !d_faces) || (d_vn && !d_verts)) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t) * (size_t)n_verts, st));
+    if (n_faces) k_rm_vf_count<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, d_count);
+    k_rm_vf_scan<<<1, 1024, 0, st>>>(d_count, n_verts, d_vf_start);
+    if (n_faces) k_rm_vf_fill<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, d_vf_start, d_count, d_vf_face);
+    k_rm_vf_sort<<<blocks_for(n_verts), 256, 0, st>>>(d_faces, d_vf_start, d_vf_face, n_verts, d_verts, d_vn);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -455,18 +576,6 @@ int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const i
     if (n_verts <= 0) return DRT_OK;
     if (!d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_vn) return fail(DRT_E_INVALID, "null pointer argument");
     k_rm_vertex_normals<<<blocks_for(n_verts), 256, 0, (hipStream_t)stream>>>(d_faces, d_verts, d_vf_start, d_vf_face, n_verts, d_vn);
-    HIP_TRY(hipGetLastError());
-    return DRT_OK;
-}
-
-int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d_edges, const int64_t* d_faces, const double* d_verts,
-                         const double* d_vn, const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, double max_len, int max_q,
-                         uint8_t* d_ok, int32_t* d_n_query, double* d_query, void* stream) {
-    if (n_cand <= 0) return DRT_OK;
-    if (!d_cand || !d_edges || !d_faces || !d_verts || !d_vn || !d_vf_start || !d_vf_face || !d_ok || !d_n_query || !d_query || max_q < 1)
-        return fail(DRT_E_INVALID, "bad argument");
-    k_rm_collapse_eval<<<blocks_for(n_cand), 256, 0, (hipStream_t)stream>>>(d_cand, n_cand, d_edges, d_faces, d_verts, d_vn, d_vf_start, d_vf_face,
-                                                                           min_len, max_len, max_q, d_ok, d_n_query, d_query);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -543,11 +652,11 @@ int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* 
     return DRT_OK;
 }
 
-int drt_rm_flip_eval(const int64_t* d_edges, int64_t n_edges, const int64_t* d_edge_rows, const int64_t* d_faces, const double* d_verts, const double* d_vn,
-                     const int64_t* d_vf_start, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream) {
-    if (n_edges <= 0) return DRT_OK;
-    if (!d_edges || !d_edge_rows || !d_faces || !d_verts || !d_vn || !d_vf_start || !d_ok || !d_quad || !d_query) return fail(DRT_E_INVALID, "null pointer argument");
-    k_rm_flip_eval<<<blocks_for(n_edges), 256, 0, (hipStream_t)stream>>>(d_edges, n_edges, d_edge_rows, d_faces, d_verts, d_vn, d_vf_start, max_len, d_ok, d_quad, d_query);
+int drt_rm_flip_eval(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
+                     const int64_t* d_vf_face, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream) {
+    if (n_faces <= 0) return DRT_OK;
+    if (!d_faces || !d_verts || !d_vn || !d_vf_start || !d_vf_face || !d_ok || !d_quad || !d_query) return fail(DRT_E_INVALID, "null pointer argument");
+    k_rm_flip_eval<<<blocks_for(3 * n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, n_faces, d_verts, d_vn, d_vf_start, d_vf_face, max_len, d_ok, d_quad, d_query);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }

@@ -6,19 +6,21 @@ The reference shells out to MeshLab's "Remeshing: Isotropic Explicit Remeshing" 
 MaxSurfDist 1, refine / collapse / swap / smooth / reproject).  ``drt_amd.remesh`` runs that algorithm (Botsch & Kobbelt 2004)
 sequentially on the host; here every step runs on the GPU without the mesh leaving it:
 
-    split     edge lengths, midpoints and the 1 -> 2 / 3 / 4 face patterns for all faces at once (drt_rm_split_faces)
+    split     long edges flagged by directed-edge slot, midpoints and the 1 -> 2 / 3 / 4 face patterns for all faces at once (drt_rm_split_*)
     collapse  all short edges evaluated at once (link condition, valences, fold test against the consensus normals, maximum
               length, surface distance of the midpoint and of every surviving face's centroid through the scene's closest-point
               kernel); the survivors claim their two rings by priority (length, index) and the ones that hold every claim are
               applied -- disjoint neighbourhoods commute -- then the rest is evaluated again on the new mesh, until a round
               applies nothing
-    flip      the same evaluate / claim / apply rounds on the four vertices of every edge
+    flip      the same evaluate / claim / apply rounds on the four vertices of every edge (the face across an edge and the "new edge
+              exists already" test come from the vertex -> face lists: no edge table)
     smooth    tangential relaxation of every vertex, faces that would fold take their vertices back (four rounds)
     project   closest point on the INPUT surface (the tree of the scene the mesh came from), same roll-back
-    topology  edge tables by the radix sort of drt_edge_tables; vertex -> face lists by a stable sort
+    topology  vertex -> face lists by drt_rm_vertex_faces (count / scan / fill / sort each run), once per round: every step works on the
+              directed-edge slots 3 f + k of the face array (the lo -> hi slot of an edge speaks for it) and these lists -- no edge table
 
-The geometric decisions and the conflict-free application are hand-written kernels (csrc/drt_remesh_gpu.hip); torch provides the
-prefix sums, stable sorts and stream compactions in between (plumbing).  The result is a closed oriented manifold of the same
+The geometric decisions, the conflict-free application and the tables are hand-written kernels (csrc/drt_remesh_gpu.hip); torch
+provides the prefix sums and the final compactions in between (plumbing).  The result is a closed oriented manifold of the same
 genus with edge lengths concentrated around the target, on the input surface, deterministic -- and statistically the mesh the
 host version produces (tests/test_gpu_remesh.py holds the two against each other); vertex order and the exact set of operations
 differ, as they do between the host version and MeshLab.
@@ -30,7 +32,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, diffrender, mesh_io
+from . import _lib
 from .optix_mesh import _stream
 from .remesh import SPLIT, COLLAPSE, FLIP, SMOOTH, REPROJECT, CHECK_DIST, ALL  # noqa: F401
 
@@ -58,20 +60,17 @@ class _Work:
         self.stats = {"collapse_rounds": 0, "flip_rounds": 0, "collapse_unfinished": 0, "flip_unfinished": 0, "move_rounds_max": 0, "move_unresolved": 0}
 
     # ---- derived tables
-    def edges(self):
-        """Edges [E,2] ascending by (lo, hi), row2edge int32 [3F], edge_rows int64 [E,2] (the two directed-edge rows of every edge)."""
-        E, _, _, rows = diffrender.edge_tables(self.F, self.V, want_rows=True, check=False)      # (no read-back: every step here keeps the mesh closed)
-        order = torch.argsort(rows, stable=True)                # rows grouped by edge id: two per edge (watertight: asserted above)
-        return E, rows, order.view(-1, 2)
-
-    def csr(self):
-        """vertex -> incident faces: vf_start int64 [V+1], vf_face int64 [3F] (ascending face order inside a vertex)."""
-        flat = self.F.reshape(-1)
-        order = torch.argsort(flat, stable=True)
-        vf_face = (order // 3).contiguous()
-        # (the start of every vertex's run in the sorted list: one search, no histogram -- torch.bincount asks the device for the maximum first)
-        vf_start = torch.searchsorted(flat[order], torch.arange(self.V.shape[0] + 1, device=self.dev))
-        return vf_start, vf_face
+    def csr(self, normals=False):
+        """vertex -> incident faces: vf_start int64 [V+1], vf_face int64 [3F] (ascending face order inside a vertex; faces a collapse round
+        killed -- indices -1 -- in nobody's list), by drt_rm_vertex_faces; with ``normals`` also the area-weighted vertex normals."""
+        nv, nf = self.V.shape[0], self.F.shape[0]
+        vf_start = torch.empty(nv + 1, dtype=torch.long, device=self.dev)
+        vf_face = torch.empty(3 * nf, dtype=torch.long, device=self.dev)
+        count = torch.empty(nv, dtype=torch.int32, device=self.dev)
+        vn = torch.empty_like(self.V) if normals else None
+        _check(_lib.lib().drt_rm_vertex_faces(self.F.data_ptr(), nf, nv, count.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
+                                              self.V.data_ptr(), _lib.ptr(vn), _stream()))
+        return (vf_start, vf_face, vn) if normals else (vf_start, vf_face)
 
     def vertex_normals(self, vf_start, vf_face):
         vn = torch.empty_like(self.V)
@@ -87,30 +86,28 @@ class _Work:
 
     # ---- 1. refine
     def split_long_edges(self, max_len):
-        E, rows, _ = self.edges()
-        lo, hi = self.V[E[:, 0]], self.V[E[:, 1]]
-        long_ = (lo - hi).norm(dim=1) > max_len
-        nv, nf = self.V.shape[0], self.F.shape[0]
-        # the new vertex of every long edge, numbered in edge order; face counts; ONE host round trip for both totals (the sizes of the new arrays)
-        rank = torch.cumsum(long_, 0)
-        mid_of_edge = torch.where(long_, nv + rank - 1, torch.full_like(rank, -1))
-        count = torch.empty(nf, dtype=torch.long, device=self.dev)
+        """Long edges by directed-edge slot (no edge table): flag, prefix sum = the new vertices' numbers, the midpoint id of every slot on
+        both sides of its edge, faces per face, prefix sum, ONE host round trip for both totals (the sizes of the new arrays), write."""
         lib = _lib.lib()
-        _check(lib.drt_rm_split_faces(self.F.data_ptr(), nf, rows.data_ptr(), mid_of_edge.data_ptr(), None, count.data_ptr(), None, None, _stream()))
+        nv, nf = self.V.shape[0], self.F.shape[0]
+        vf_start, vf_face = self.csr()
+        flag = torch.empty(3 * nf, dtype=torch.uint8, device=self.dev)
+        _check(lib.drt_rm_split_mark(self.F.data_ptr(), nf, self.V.data_ptr(), float(max_len), flag.data_ptr(), _stream()))
+        rank = torch.cumsum(flag, 0)                             # (int64)
+        mid = torch.empty(3 * nf, dtype=torch.long, device=self.dev)
+        count = torch.empty(nf, dtype=torch.long, device=self.dev)
+        _check(lib.drt_rm_split_plan(self.F.data_ptr(), nf, vf_start.data_ptr(), vf_face.data_ptr(), flag.data_ptr(), rank.data_ptr(), nv,
+                                     mid.data_ptr(), count.data_ptr(), _stream()))
         offset = torch.cumsum(count, 0)
         n_split, n_out = (int(x) for x in torch.stack([rank[-1], offset[-1]]).tolist())
         if n_split == 0:
             return 0
         offset = offset - count
-        # midpoints written by destination row (no stream compaction): short edges all go to one scratch row behind the new vertices
-        newV = torch.empty((nv + n_split + 1, 3), dtype=torch.float64, device=self.dev)
+        newV = torch.empty((nv + n_split, 3), dtype=torch.float64, device=self.dev)
         newV[:nv] = self.V
-        newV.index_copy_(0, torch.where(long_, mid_of_edge, torch.full_like(rank, nv + n_split)), (lo + hi) * 0.5)     # (V[lo] + V[hi]) * 0.5: the host version's bits
-        self.V = newV[:nv + n_split]
         out = torch.empty((n_out, 3), dtype=torch.long, device=self.dev)
-        _check(lib.drt_rm_split_faces(self.F.data_ptr(), nf, rows.data_ptr(), mid_of_edge.data_ptr(), self.V.data_ptr(), None, offset.data_ptr(),
-                                      out.data_ptr(), _stream()))
-        self.F = out
+        _check(lib.drt_rm_split_faces(self.F.data_ptr(), nf, mid.data_ptr(), newV.data_ptr(), offset.data_ptr(), out.data_ptr(), _stream()))
+        self.V, self.F = newV, out
         return n_split
 
     # ---- 2. collapse
@@ -150,8 +147,7 @@ class _Work:
                 self.stats["collapse_unfinished"] += 1            # candidates were still being applied when the rounds ran out
                 break
             self.stats["collapse_rounds"] += 1
-            vf_start, vf_face = self.csr()                        # (killed faces hold -1: sorted to the front, outside every vertex's run)
-            vn = self.vertex_normals(vf_start, vf_face)
+            vf_start, vf_face, vn = self.csr(normals=True)        # (killed faces hold -1: in nobody's list)
             _check(lib.drt_rm_collapse_eval_all(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
                                                 float(min_len), float(max_len), MAX_Q, E_snap.data_ptr(), length.data_ptr(), ok.data_ptr(),
                                                 nq.data_ptr(), q.data_ptr(), _lib.ptr(ql_item), _lib.ptr(ql_point), _lib.ptr(ql_count), ql_cap, _stream()))
@@ -183,23 +179,22 @@ class _Work:
         lib = _lib.lib()
         done = first = 0
         nv = self.V.shape[0]
+        nf = self.F.shape[0]
+        n_e = 3 * nf                                              # one candidate per directed-edge slot (the lo -> hi slot of an edge speaks for it)
         lock = torch.empty(nv, dtype=torch.int32, device=self.dev)
         dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
         n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        ok = torch.empty(n_e, dtype=torch.uint8, device=self.dev)
+        quad = torch.empty((n_e, 6), dtype=torch.long, device=self.dev)
+        q = torch.empty((n_e, 3), dtype=torch.float64, device=self.dev)
         for rnd in range(MAX_ROUNDS + 1):
             if rnd == MAX_ROUNDS:
                 self.stats["flip_unfinished"] += 1
                 break
             self.stats["flip_rounds"] += 1
-            E, _, edge_rows = self.edges()
-            vf_start, vf_face = self.csr()
-            vn = self.vertex_normals(vf_start, vf_face)
-            n_e = E.shape[0]
-            ok = torch.empty(n_e, dtype=torch.uint8, device=self.dev)
-            quad = torch.empty((n_e, 6), dtype=torch.long, device=self.dev)
-            q = torch.empty((n_e, 3), dtype=torch.float64, device=self.dev)
-            _check(lib.drt_rm_flip_eval(E.data_ptr(), n_e, edge_rows.contiguous().data_ptr(), self.F.data_ptr(), self.V.data_ptr(), vn.data_ptr(),
-                                        vf_start.data_ptr(), float(max_len), ok.data_ptr(), quad.data_ptr(), q.data_ptr(), _stream()))
+            vf_start, vf_face, vn = self.csr(normals=True)
+            _check(lib.drt_rm_flip_eval(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
+                                        float(max_len), ok.data_ptr(), quad.data_ptr(), q.data_ptr(), _stream()))
             self._filter_by_surface(ok, None, q, n_e, 1)          # the midpoint of the new edge
             n_done.zero_()
             _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), nv, lock.data_ptr(), dirty.data_ptr(), SUB_ROUNDS,

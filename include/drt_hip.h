@@ -341,44 +341,53 @@ int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double*
 /* ---- remeshing between passes ON THE DEVICE: the geometric kernels of drt_amd/remesh_gpu.py (csrc/drt_remesh_gpu.hip) ----------
  * The data-parallel form of drt_remesh_isotropic below (same algorithm and acceptance rules; every candidate operation evaluated at
  * once, the ones whose neighbourhoods do not overlap applied together, in rounds).  d_faces int64 [F,3], d_verts float64 [V,3];
- * d_vf_start int64 [V+1] / d_vf_face int64 [3F]: vertex -> incident faces (CSR, ascending face ids); d_vn float64 [V,3]: area-weighted
- * vertex normals (drt_rm_vertex_normals).  All pointers are DEVICE pointers; everything is enqueued on `stream`.
- *   drt_rm_split_faces      d_mid_of_edge int64 [E]: the midpoint vertex of every unique edge or -1; d_row2edge int32 [3F] (drt_edge_tables).
- *                           Pass 1 (d_count non-null): faces each face becomes (1..4).  Pass 2 (d_faces_out non-null, d_offset = exclusive
- *                           prefix sum of the counts, d_verts with the midpoints appended): the new faces (1 -> 2, 2 -> 3 by the shorter
- *                           diagonal, 3 -> 4).
- *   drt_rm_collapse_eval    candidates d_cand int64 [n] (indices into d_edges int64 [E,2]): ok uint8 [n] = every rule but the surface
- *                           distance; d_query float64 [n, max_q, 3] / d_n_query int32 [n]: the points whose distance to the input surface
- *                           the caller still has to check (midpoint, centroids of the faces that survive).
+ * d_vf_start int64 [V+1] / d_vf_face int64 [3F]: vertex -> incident faces (CSR, ascending face ids; drt_rm_vertex_faces); d_vn float64
+ * [V,3]: area-weighted vertex normals (drt_rm_vertex_normals).  All pointers are DEVICE pointers; everything is enqueued on `stream`.
+ *   drt_rm_vertex_faces     the CSR pair of the mesh as it stands (faces whose indices are -1 -- drt_rm_kill_faces -- are in nobody's
+ *                           list): count, scan, fill, each run sorted ascending; d_count int32 [V]: workspace.  With d_vn (and d_verts)
+ *                           non-null also the vertex normals, summed in list order (what drt_rm_vertex_normals gives).
+ *   drt_rm_split_mark       d_flag uint8 [3F]: 1 on the lo -> hi directed-edge slot c = 3 f + k of every edge longer than max_len.
+ *   drt_rm_split_plan       d_rank int64 [3F] = inclusive prefix sum of d_flag (the caller's): d_mid_of_slot int64 [3F] = for every slot, on
+ *                           both sides of its edge, the new vertex n_verts + rank - 1 of that edge or -1; d_count int64 [F]: faces each face
+ *                           becomes (1..4).
+ *   drt_rm_split_faces      d_verts float64 [V + n_split, 3] holding the old vertices: writes the midpoints behind them and, with d_offset =
+ *                           exclusive prefix sum of the counts, the new faces (1 -> 2, 2 -> 3 by the shorter diagonal, 3 -> 4).
+ *   drt_rm_collapse_eval_all  every directed-edge slot c = 3 f + k of d_faces a candidate (below): ok uint8 [3F] = every rule but the surface
+ *                           distance; d_query float64 [3F, max_q, 3] / d_n_query int32 [3F]: the points whose distance to the input surface
+ *                           is still to be checked (midpoint, centroids of the faces that survive).
  *   drt_rm_collapse_apply   claim (64-bit atomicMin of (length class, hash(edge, seed), edge index) on d_lock uint64 [V] -- workspace, preset
  *                           here; d_length float64 [E]: edge lengths at the start of the round) what each candidate with ok = 1 writes, and
  *                           apply those that nobody with a higher priority contests: faces rewritten in place, d_f_alive / d_v_alive
  *                           cleared for what dies, *d_n_done += number applied.  `sub_rounds` claim / apply pairs on the same evaluation
  *                           and tables: a collapse that went ahead marks what it read or wrote in d_dirty uint8 [V] (workspace, cleared
  *                           here), and later sub-rounds admit only candidates whose vertices and rings are clean (their verdict stands).
- *   drt_rm_flip_eval/apply  the same for edge flips (d_edge_rows int64 [E,2]: the two directed-edge rows 3f+k of every edge; d_quad int64
- *                           [E,6] = a b c d f1 f2 of a flip that passes; d_query float64 [E,3] the midpoint of the new edge; d_lock uint32 [V], d_dirty uint8 [V] and
- *                           sub_rounds as above).
+ *   drt_rm_flip_eval/apply  the same for edge flips, again one candidate per directed-edge slot (the face across the edge and the "new edge
+ *                           exists already" test come from the vertex -> face lists: no edge table); d_quad int64 [3F,6] = a b c d f1 f2 of a
+ *                           flip that passes; d_query float64 [3F,3] the midpoint of the new edge; n_items = 3 F; d_lock uint32 [V], d_dirty
+ *                           uint8 [V] and sub_rounds as above.
  *   drt_rm_smooth_target    tangential relaxation targets float64 [V,3].
  *   drt_rm_face_agreement   cosine between each face normal and the consensus of its corners, float64 [F] (before a move).
  *   drt_rm_move_check       after vertices moved: every face that degenerated or folded (against d_a0) takes its three vertices back from
  *                           d_old; *d_n_bad = their number (the caller repeats, four rounds at most). */
-int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int32_t* d_row2edge, const int64_t* d_mid_of_edge, const double* d_verts,
-                       int64_t* d_count, const int64_t* d_offset, int64_t* d_faces_out, void* stream);
+int drt_rm_split_mark(const int64_t* d_faces, int64_t n_faces, const double* d_verts, double max_len, uint8_t* d_flag, void* stream);
+int drt_rm_split_plan(const int64_t* d_faces, int64_t n_faces, const int64_t* d_vf_start, const int64_t* d_vf_face, const uint8_t* d_flag,
+                      const int64_t* d_rank, int64_t n_verts, int64_t* d_mid_of_slot, int64_t* d_count, void* stream);
+int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int64_t* d_mid_of_slot, double* d_verts, const int64_t* d_offset,
+                       int64_t* d_faces_out, void* stream);
+int drt_rm_vertex_faces(const int64_t* d_faces, int64_t n_faces, int64_t n_verts, int32_t* d_count, int64_t* d_vf_start, int64_t* d_vf_face,
+                        const double* d_verts, double* d_vn, void* stream);
 int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
                           double* d_vn, void* stream);
-int drt_rm_collapse_eval(const int64_t* d_cand, int64_t n_cand, const int64_t* d_edges, const int64_t* d_faces, const double* d_verts,
-                         const double* d_vn, const int64_t* d_vf_start, const int64_t* d_vf_face, double min_len, double max_len, int max_q,
-                         uint8_t* d_ok, int32_t* d_n_query, double* d_query, void* stream);
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
                           const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, const double* d_length,
                           uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream);
-/* Round 6: the same evaluation over EVERY directed-edge slot c = 3 f + k of d_faces (no candidate list: no stream compaction, no host round
+/* Round 6: the collapse evaluation runs over EVERY directed-edge slot c = 3 f + k of d_faces (no candidate list: no stream compaction, no host round
  * trip per round).  Slots that are not the lo -> hi representative of their edge, not short, or belong to a face an earlier round killed
  * (indices -1, drt_rm_kill_faces) report ok = 0.  Outputs sized [3 n_faces]: d_edge_snap int64 [.,2] (the slot's edge at the start of the
  * round: what drt_rm_collapse_apply takes as d_edges with d_cand = NULL), d_length, d_ok, d_n_query, d_query [., max_q, 3].
  * drt_rm_surface_filter: CheckSurfDist on the device -- item i keeps d_ok[i] only if all of its d_n_query[i] (NULL: one) points
- * d_query[i][k] lie within max_dist of the surface held by scene `s` (the closest-point query of drt_closest_point).
+ * d_query[i][k] lie within max_dist of the surface held by scene `s` (the verdict of drt_closest_point's distance, by a search that
+ * starts bounded by max_dist and ends at the first triangle inside).
  * drt_rm_kill_faces: faces with d_f_alive[f] == 0 get the indices -1 in place. */
 int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
                              const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
@@ -392,9 +401,9 @@ int drt_rm_surface_filter_list(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_l
 int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_query, const double* d_query, int64_t n_items, int max_q,
                           double max_dist, void* stream);
 int drt_rm_kill_faces(int64_t* d_faces, const uint8_t* d_f_alive, int64_t n_faces, void* stream);
-int drt_rm_flip_eval(const int64_t* d_edges, int64_t n_edges, const int64_t* d_edge_rows, const int64_t* d_faces, const double* d_verts, const double* d_vn,
-                     const int64_t* d_vf_start, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream);
-int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, uint32_t* d_lock, uint8_t* d_dirty,
+int drt_rm_flip_eval(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
+                     const int64_t* d_vf_face, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream);
+int drt_rm_flip_apply(int64_t n_items, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, uint32_t* d_lock, uint8_t* d_dirty,
                       int sub_rounds, int32_t* d_n_done, void* stream);
 int drt_rm_smooth_target(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
                          double* d_target, void* stream);

@@ -201,6 +201,14 @@ void hs_closest_point(void* h, const double* points, int64_t n, double* dist, in
     }
 }
 
+// the remesher's surface-distance verdict (within_distance) for each point against its own radius
+void hs_within_distance(void* h, const double* points, const double* radius, int64_t n, uint8_t* within) {
+    HsScene* s = (HsScene*)h;
+    HostStack hs;
+    for (int64_t i = 0; i < n; ++i)
+        within[i] = within_distance(s->wide.data(), s->tris.data(), (int)s->tris.size(), s->faces.data(), s->verts.data(), load_d3(points, i), radius[i], hs.st) ? 1 : 0;
+}
+
 void hs_render_forward(void* h, const double* verts64, const double* origin, const double* dir, int64_t n, double ior_int,
                        double ior_ext, double* out_ori, double* out_dir, uint8_t* mask, int32_t* face1, int32_t* face2) {
     const PathCtx c = path_ctx((HsScene*)h, verts64, ior_int, ior_ext);

@@ -273,6 +273,15 @@ def test_closest_point_matches_bruteforce(hostsim):
     np.testing.assert_allclose(np.concatenate(d_face), dist[::37], rtol=1e-9, atol=1e-9)
     assert dist[600:700].max() < 1e-12                        # a vertex is on the surface
     assert dist[700:800].max() < 1e-4                         # face centroids (float32 vertices, float64 mean)
+    # within_distance (the remesher's surface-distance rule: early exit, bound = the radius) gives the verdict  dist <= radius  of the
+    # full query -- at the distance itself, one ulp either side of it, and at radii all over the range
+    for radius in (dist, np.nextafter(dist, np.inf), np.nextafter(dist, -np.inf), dist * rng.uniform(0.2, 3.0, len(dist)),
+                   np.full(len(dist), 0.05), np.zeros(len(dist)), np.full(len(dist), np.nan), np.full(len(dist), np.inf)):
+        radius = np.ascontiguousarray(radius)
+        got = np.empty(len(pts), dtype=np.uint8)
+        hostsim.hs_within_distance(h, pts.ctypes.data, radius.ctypes.data, len(pts), got.ctypes.data)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(got.astype(bool), (dist <= radius) & (radius >= 0))
     hostsim.hs_destroy(h)
 
 

@@ -16,5 +16,6 @@ sel = rows[-int(sys.argv[3]):]
 t0 = int(sel[0]["Start_Timestamp"])
 for r in sel:
     st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print("%-40s start %10.1f us  dur %8.1f us  grid %s" % (r["Kernel_Name"].split("(")[0][:40], (st - t0) / 1e3, (en - st) / 1e3, r.get("Grid_Size")))
+    name = re.sub(r"\(anonymous namespace\)::|drt::|^void ", "", r["Kernel_Name"])
+    print("%-40s start %10.1f us  dur %8.1f us  grid %s" % (name.split("(")[0][:40], (st - t0) / 1e3, (en - st) / 1e3, r.get("Grid_Size")))
 PY

@@ -18,12 +18,14 @@ def timed(name, fn):
         torch.cuda.synchronize(); T[name] = T.get(name, 0.0) + time.perf_counter() - t0
         return r
     return wrap
-for name in ("split_long_edges", "collapse_short_edges", "flip_edges", "smooth_tangential", "project_to_surface", "compact", "edges", "csr"):
+for name in ("split_long_edges", "collapse_short_edges", "flip_edges", "smooth_tangential", "project_to_surface", "compact", "csr"):
     setattr(RG._Work, name, timed(name, getattr(RG._Work, name)))
 for rep in range(3):
     T.clear()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     V2, F2, stats = RG.isotropic_remesh_gpu(V, F, L, surface=scene.optix_mesh, return_stats=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"remesh {len(F)} -> {len(F2)} faces, target {L:.3f}: {1e3 * dt:.1f} ms  {stats}")
-    print("   " + "  ".join(f"{k} {1e3 * v:.1f}" for k, v in sorted(T.items(), key=lambda kv: -kv[1])), "(ms; edges / csr are inside the steps)")
+    import hashlib
+    digest = hashlib.sha256(V2.cpu().numpy().tobytes() + F2.cpu().numpy().tobytes()).hexdigest()[:12]
+    print(f"remesh {len(F)} -> {len(F2)} faces, target {L:.3f}: {1e3 * dt:.1f} ms  {stats}  mesh sha256 {digest}")
+    print("   " + "  ".join(f"{k} {1e3 * v:.1f}" for k, v in sorted(T.items(), key=lambda kv: -kv[1])), "(ms; csr is inside the steps)")
