@@ -32,23 +32,21 @@ __device__ __forceinline__ double agreement(d3 n, const double* __restrict__ vn,
 }
 __device__ __forceinline__ bool acceptable(double before, double after) { return after >= 0.3 || after >= before; }
 
-struct Ring {
-    int n;
-    bool overflow;
-    int64_t v[kMaxRing];
-    __device__ void add(int64_t u) {
-        for (int k = 0; k < n; ++k) if (v[k] == u) return;
-        if (n < kMaxRing) v[n++] = u; else overflow = true;
-    }
-    __device__ bool has(int64_t u) const { for (int k = 0; k < n; ++k) if (v[k] == u) return true; return false; }
-};
-__device__ __forceinline__ void collect_ring(int64_t v, const int64_t* __restrict__ F, const int64_t* __restrict__ vf_start,
-                                             const int64_t* __restrict__ vf_face, Ring& r) {
-    r.n = 0; r.overflow = false;
+// The ring of a vertex without a list: in a closed oriented manifold the faces around v name each neighbour of v exactly once as "the
+// vertex that follows v in the face", so a walk over v's faces IS a walk over its neighbours, and the valence is the number of faces.
+// (Round 6: the rings used to be collected into per-thread arrays with a linear-search de-duplication -- 560 bytes of scratch per lane in
+// the evaluation and the claim kernels.)
+__device__ __forceinline__ int64_t next_in_face(const int64_t* __restrict__ F, int64_t f, int64_t v) {
+    const int64_t x = F[3 * f], y = F[3 * f + 1], z = F[3 * f + 2];
+    return x == v ? y : (y == v ? z : x);
+}
+__device__ __forceinline__ bool adjacent(int64_t u, int64_t v, const int64_t* __restrict__ F, const int64_t* __restrict__ vf_start,
+                                         const int64_t* __restrict__ vf_face) {
     for (int64_t q = vf_start[v]; q < vf_start[v + 1]; ++q) {
         const int64_t f = vf_face[q];
-        for (int k = 0; k < 3; ++k) { const int64_t u = F[3 * f + k]; if (u != v) r.add(u); }
+        if (F[3 * f] == u || F[3 * f + 1] == u || F[3 * f + 2] == u) return true;
     }
+    return false;
 }
 
 // ---- split -------------------------------------------------------------------------------------------------------------------
@@ -232,15 +230,15 @@ __device__ void collapse_eval_one(int64_t c, int64_t a, int64_t b, const int64_t
                                   uint8_t* __restrict__ ok, int32_t* __restrict__ n_query, double* __restrict__ q) {
     const d3 pa = ldv(V, a), pb = ldv(V, b);
     if (!(len3(pa - pb) < min_len)) return;
-    Ring ra, rb;
-    collect_ring(a, F, vf_start, vf_face, ra);
-    collect_ring(b, F, vf_start, vf_face, rb);
-    if (ra.overflow || rb.overflow) return;
+    const int64_t va = vf_start[a + 1] - vf_start[a], vb = vf_start[b + 1] - vf_start[b];
+    if (va > kMaxRing || vb > kMaxRing) return;
     int common = 0;
     int64_t opp[2] = {-1, -1};
-    for (int k = 0; k < ra.n; ++k) if (rb.has(ra.v[k])) { if (common < 2) opp[common] = ra.v[k]; ++common; }
+    for (int64_t s = vf_start[a]; s < vf_start[a + 1]; ++s) {
+        const int64_t u = next_in_face(F, vf_face[s], a);
+        if (u != b && adjacent(u, b, F, vf_start, vf_face)) { if (common < 2) opp[common] = u; ++common; }
+    }
     if (common != 2) return;                                                                        // link condition
-    const int64_t va = vf_start[a + 1] - vf_start[a], vb = vf_start[b + 1] - vf_start[b];
     if (vf_start[opp[0] + 1] - vf_start[opp[0]] < 4 || vf_start[opp[1] + 1] - vf_start[opp[1]] < 4) return;   // no valence-3 vertices
     if (va + vb - 4 < 3) return;
     const d3 m = (pa + pb) * 0.5;
@@ -318,9 +316,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter(TraceCtx c, c
 }
 // the faces a round's collapses killed leave the face array in place: their indices become -1 (the next round's tables skip them; one
 // compaction at the end of the step instead of one per round)
-__global__ void k_rm_kill_faces(int64_t* __restrict__ F, const uint8_t* __restrict__ f_alive, int64_t n_faces) {
+__global__ void k_rm_kill_faces(int64_t* __restrict__ F, uint8_t* __restrict__ f_alive, int64_t n_faces) {
     const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (f < n_faces && !f_alive[f]) { F[3 * f] = -1; F[3 * f + 1] = -1; F[3 * f + 2] = -1; }
+    if (f < n_faces && !f_alive[f]) { F[3 * f] = -1; F[3 * f + 1] = -1; F[3 * f + 2] = -1; f_alive[f] = 1; }      // (all ones again for the next round)
 }
 
 // Priority of a collapse: the shorter edges first (eight length classes below min_len, as the host version's sweep goes by length), a
@@ -340,36 +338,45 @@ __device__ __forceinline__ unsigned long long collapse_key(double l, double min_
 template <bool APPLY>
 __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_cand, const uint8_t* __restrict__ ok, const int64_t* __restrict__ E,
                                     int64_t* F, double* V, const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double min_len,
-                                    unsigned seed, const double* __restrict__ length, unsigned long long* lock, uint8_t* __restrict__ f_alive,
-                                    uint8_t* __restrict__ v_alive, uint8_t* dirty, int32_t* n_done) {
+                                    unsigned seed, unsigned generation, uint8_t stamp, const double* __restrict__ length, unsigned long long* lock,
+                                    uint8_t* __restrict__ f_alive, uint8_t* __restrict__ v_alive, uint8_t* dirty, int32_t* n_done) {
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= n_cand || !ok[c]) return;
     const int64_t e = cand ? cand[c] : c, a = E[2 * e], b = E[2 * e + 1];          // (no list: every directed-edge slot is a candidate slot)
-    const unsigned long long key = collapse_key(length[e], min_len, e, seed);      // (from the lengths of the round's start: V changes under APPLY)
+    // (from the lengths of the round's start: V changes under APPLY.)  The claim / apply pairs of a step are numbered, and the number sits
+    // on top of the key, counting DOWN: a claim of an earlier pair is larger than any of this one, so it reads as "no claim" -- `lock` is
+    // preset once per step, not once per pair.
+    const unsigned long long key = ((unsigned long long)(0x7FFFu - generation) << 48) | collapse_key(length[e], min_len, e, seed);
     // Sub-rounds (several claim / apply pairs on ONE evaluation and ONE set of tables): a collapse that went ahead marks everything it
-    // read or wrote `dirty`; a candidate takes part in a later sub-round only while its two vertices and both rings are clean -- then no
-    // face, position, normal or valence its evaluation relied on has changed (a face around a clean vertex cannot have been touched: the
-    // collapse that touched it would have had that vertex in a ring), so the verdict `ok` still stands.  `dirty` is read in the claim
-    // pass and written in the apply pass only: a candidate that was not eligible has left no claim and cannot find its key in `lock`.
-    if (!APPLY && (dirty[a] | dirty[b])) return;
+    // read or wrote `dirty` (= the round's stamp); a candidate takes part in a later sub-round only while its two vertices and both rings
+    // are clean -- then no face, position, normal or valence its evaluation relied on has changed (a face around a clean vertex cannot
+    // have been touched: the collapse that touched it would have had that vertex in a ring), so the verdict `ok` still stands.  `dirty` is
+    // read in the claim pass and written in the apply pass only: a candidate that was not eligible has left no claim and cannot find its
+    // key in `lock`.
+    if (!APPLY && (dirty[a] == stamp || dirty[b] == stamp)) return;
     if (APPLY && !(lock[a] == key && lock[b] == key)) return;
-    Ring ra, rb;
-    collect_ring(a, F, vf_start, vf_face, ra);
-    collect_ring(b, F, vf_start, vf_face, rb);
+    const int64_t a0 = vf_start[a], a1 = vf_start[a + 1], b0 = vf_start[b], b1 = vf_start[b + 1];
     if (!APPLY) {
-        for (int k = 0; k < ra.n; ++k) if (dirty[ra.v[k]]) return;
-        for (int k = 0; k < rb.n; ++k) if (dirty[rb.v[k]]) return;
+        for (int64_t s = a0; s < a1; ++s) if (dirty[next_in_face(F, vf_face[s], a)] == stamp) return;
+        for (int64_t s = b0; s < b1; ++s) if (dirty[next_in_face(F, vf_face[s], b)] == stamp) return;
         atomicMin(&lock[a], key); atomicMin(&lock[b], key);
-        for (int k = 0; k < ra.n; ++k) if (rb.has(ra.v[k])) atomicMin(&lock[ra.v[k]], key);       // the two opposite vertices
+        for (int64_t s = a0; s < a1; ++s) {                                          // the two opposite vertices: third corner of the faces on (a, b)
+            const int64_t f = vf_face[s];
+            const int64_t x = F[3 * f], y = F[3 * f + 1], z = F[3 * f + 2];
+            if (x == b || y == b || z == b) atomicMin(&lock[x != a && x != b ? x : (y != a && y != b ? y : z)], key);
+        }
         return;
     }
-    bool mine = lock[a] == key && lock[b] == key;
-    for (int k = 0; k < ra.n && mine; ++k) mine = lock[ra.v[k]] >= key;
-    for (int k = 0; k < rb.n && mine; ++k) mine = lock[rb.v[k]] >= key;
+    bool mine = true;
+    for (int64_t s = a0; s < a1 && mine; ++s) mine = lock[next_in_face(F, vf_face[s], a)] >= key;
+    for (int64_t s = b0; s < b1 && mine; ++s) mine = lock[next_in_face(F, vf_face[s], b)] >= key;
     if (!mine) return;
     // commit: b -> a, a moves to the midpoint, the two shared faces die (every face touched has all its vertices under this claim)
+    dirty[a] = stamp; dirty[b] = stamp;
+    for (int64_t s = a0; s < a1; ++s) dirty[next_in_face(F, vf_face[s], a)] = stamp;   // (before the faces are rewritten)
+    for (int64_t s = b0; s < b1; ++s) dirty[next_in_face(F, vf_face[s], b)] = stamp;
     const d3 m = (ldv(V, a) + ldv(V, b)) * 0.5;
-    for (int64_t s = vf_start[b]; s < vf_start[b + 1]; ++s) {
+    for (int64_t s = b0; s < b1; ++s) {
         const int64_t f = vf_face[s];
         const bool shared = F[3 * f] == a || F[3 * f + 1] == a || F[3 * f + 2] == a;
         if (shared) { f_alive[f] = 0; continue; }
@@ -377,9 +384,6 @@ __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_
     }
     v_alive[b] = 0;
     store_d3(V, a, m);
-    dirty[a] = 1; dirty[b] = 1;
-    for (int k = 0; k < ra.n; ++k) dirty[ra.v[k]] = 1;
-    for (int k = 0; k < rb.n; ++k) dirty[rb.v[k]] = 1;
     atomicAdd(n_done, 1);
 }
 
@@ -440,17 +444,20 @@ __global__ void k_rm_flip_eval(const int64_t* __restrict__ F, int64_t n_faces, c
     ok[e] = 1;
 }
 template <bool APPLY>
-__global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok, const int64_t* __restrict__ quad, int64_t* F, unsigned* lock, uint8_t* dirty, int32_t* n_done) {
+__global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok, const int64_t* __restrict__ quad, int64_t* F, unsigned generation, uint8_t stamp,
+                                unsigned long long* lock, uint8_t* dirty, int32_t* n_done) {
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= n_edges || !ok[e]) return;
     const int64_t* o = quad + 6 * e;
-    // priority: a bijective hash of the slot (a strict index order would leave only the local minima of a smooth field to win a round)
-    unsigned key = (unsigned)e * 2654435761u;
-    key ^= key >> 15; key *= 2246822519u; key ^= key >> 13;
+    // priority: a bijective hash of the slot (a strict index order would leave only the local minima of a smooth field to win a round),
+    // under the number of the claim / apply pair counting down (k_rm_collapse_claim: one preset of `lock` per step)
+    unsigned h = (unsigned)e * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const unsigned long long key = ((unsigned long long)(0x7FFFu - generation) << 48) | h;
     // (sub-rounds as in k_rm_collapse_claim: a flip that went ahead dirties its four vertices -- their valences and two of their faces
     // changed; a later sub-round admits only quads that are clean, whose evaluation therefore still stands)
     if (!APPLY) {
-        for (int k = 0; k < 4; ++k) if (dirty[o[k]]) return;
+        for (int k = 0; k < 4; ++k) if (dirty[o[k]] == stamp) return;
         for (int k = 0; k < 4; ++k) atomicMin(&lock[o[k]], key);
         return;
     }
@@ -458,8 +465,27 @@ __global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok,
     const int64_t a = o[0], b = o[1], c = o[2], d = o[3], f1 = o[4], f2 = o[5];
     F[3 * f1] = c; F[3 * f1 + 1] = a; F[3 * f1 + 2] = d;
     F[3 * f2] = d; F[3 * f2 + 1] = b; F[3 * f2 + 2] = c;
-    for (int k = 0; k < 4; ++k) dirty[o[k]] = 1;
+    for (int k = 0; k < 4; ++k) dirty[o[k]] = stamp;
     atomicAdd(n_done, 1);
+}
+
+// the neighbours of one vertex as a list (the relaxation sums them in ascending order of their ids)
+struct Ring {
+    int n;
+    bool overflow;
+    int64_t v[kMaxRing];
+    __device__ void add(int64_t u) {
+        for (int k = 0; k < n; ++k) if (v[k] == u) return;
+        if (n < kMaxRing) v[n++] = u; else overflow = true;
+    }
+};
+__device__ __forceinline__ void collect_ring(int64_t v, const int64_t* __restrict__ F, const int64_t* __restrict__ vf_start,
+                                             const int64_t* __restrict__ vf_face, Ring& r) {
+    r.n = 0; r.overflow = false;
+    for (int64_t q = vf_start[v]; q < vf_start[v + 1]; ++q) {
+        const int64_t f = vf_face[q];
+        for (int k = 0; k < 3; ++k) { const int64_t u = F[3 * f + k]; if (u != v) r.add(u); }
+    }
 }
 
 // ---- relaxation / projection with roll-back ---------------------------------------------------------------------------------------
@@ -624,7 +650,7 @@ int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_quer
     return DRT_OK;
 }
 
-int drt_rm_kill_faces(int64_t* d_faces, const uint8_t* d_f_alive, int64_t n_faces, void* stream) {
+int drt_rm_kill_faces(int64_t* d_faces, uint8_t* d_f_alive, int64_t n_faces, void* stream) {
     if (n_faces <= 0) return DRT_OK;
     if (!d_faces || !d_f_alive) return fail(DRT_E_INVALID, "null pointer argument");
     k_rm_kill_faces<<<blocks_for(n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, d_f_alive, n_faces);
@@ -633,20 +659,24 @@ int drt_rm_kill_faces(int64_t* d_faces, const uint8_t* d_f_alive, int64_t n_face
 }
 
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
-                          const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, const double* d_length,
+                          const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, int round, const double* d_length,
                           uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream) {
     if (n_cand <= 0) return DRT_OK;
     if (!d_ok || !d_edges || !d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_length || !d_lock || !d_f_alive || !d_v_alive || !d_dirty ||
-        !d_n_done || n_verts <= 0 || sub_rounds < 1)
+        !d_n_done || n_verts <= 0 || sub_rounds < 1 || round < 0 || round > 254 || (int64_t)(round + 1) * sub_rounds > 0x7FFF)
         return fail(DRT_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* lock = reinterpret_cast<unsigned long long*>(d_lock);
-    HIP_TRY(hipMemsetAsync(d_dirty, 0, (size_t)n_verts, st));
+    if (round == 0) {                       // the step's presets: no claim (all ones), nothing dirty, every face alive
+        HIP_TRY(hipMemsetAsync(lock, 0xFF, sizeof(unsigned long long) * (size_t)n_verts, st));
+        HIP_TRY(hipMemsetAsync(d_dirty, 0, (size_t)n_verts, st));
+    }
+    const uint8_t stamp = (uint8_t)(round + 1);
     for (int r = 0; r < sub_rounds; ++r) {
-        HIP_TRY(hipMemsetAsync(lock, 0xFF, sizeof(unsigned long long) * (size_t)n_verts, st));          // all ones = no claim
         const uint32_t sd = seed + 0x632BE5ABu * (uint32_t)r;
-        k_rm_collapse_claim<false><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
-        k_rm_collapse_claim<true><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
+        const unsigned gen = (unsigned)(round * sub_rounds + r);
+        k_rm_collapse_claim<false><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, gen, stamp, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
+        k_rm_collapse_claim<true><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, gen, stamp, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
@@ -661,16 +691,23 @@ int drt_rm_flip_eval(const int64_t* d_faces, int64_t n_faces, const double* d_ve
     return DRT_OK;
 }
 
-int drt_rm_flip_apply(int64_t n_edges, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, uint32_t* d_lock, uint8_t* d_dirty,
-                      int sub_rounds, int32_t* d_n_done, void* stream) {
-    if (n_edges <= 0) return DRT_OK;
-    if (!d_ok || !d_quad || !d_faces || !d_lock || !d_dirty || !d_n_done || n_verts <= 0 || sub_rounds < 1) return fail(DRT_E_INVALID, "bad argument");
+int drt_rm_flip_apply(int64_t n_items, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, int round, uint64_t* d_lock,
+                      uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream) {
+    if (n_items <= 0) return DRT_OK;
+    if (!d_ok || !d_quad || !d_faces || !d_lock || !d_dirty || !d_n_done || n_verts <= 0 || sub_rounds < 1 || round < 0 || round > 254 ||
+        (int64_t)(round + 1) * sub_rounds > 0x7FFF)
+        return fail(DRT_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(d_dirty, 0, (size_t)n_verts, st));
+    unsigned long long* lock = reinterpret_cast<unsigned long long*>(d_lock);
+    if (round == 0) {
+        HIP_TRY(hipMemsetAsync(lock, 0xFF, sizeof(unsigned long long) * (size_t)n_verts, st));
+        HIP_TRY(hipMemsetAsync(d_dirty, 0, (size_t)n_verts, st));
+    }
+    const uint8_t stamp = (uint8_t)(round + 1);
     for (int r = 0; r < sub_rounds; ++r) {
-        HIP_TRY(hipMemsetAsync(d_lock, 0xFF, sizeof(uint32_t) * (size_t)n_verts, st));
-        k_rm_flip_claim<false><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_dirty, d_n_done);
-        k_rm_flip_claim<true><<<blocks_for(n_edges), 256, 0, st>>>(n_edges, d_ok, d_quad, d_faces, d_lock, d_dirty, d_n_done);
+        const unsigned gen = (unsigned)(round * sub_rounds + r);
+        k_rm_flip_claim<false><<<blocks_for(n_items), 256, 0, st>>>(n_items, d_ok, d_quad, d_faces, gen, stamp, lock, d_dirty, d_n_done);
+        k_rm_flip_claim<true><<<blocks_for(n_items), 256, 0, st>>>(n_items, d_ok, d_quad, d_faces, gen, stamp, lock, d_dirty, d_n_done);
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;

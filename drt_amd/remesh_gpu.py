@@ -140,8 +140,8 @@ class _Work:
         nv = self.V.shape[0]
         lock = torch.empty(nv, dtype=torch.int64, device=dev)                           # (workspaces: preset by the call)
         dirty = torch.empty(nv, dtype=torch.uint8, device=dev)
-        f_alive = torch.empty(nf, dtype=torch.uint8, device=dev)
-        n_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        f_alive = torch.ones(nf, dtype=torch.uint8, device=dev)                          # (drt_rm_kill_faces leaves it all ones again)
+        n_done = torch.zeros(1, dtype=torch.int32, device=dev)                           # cumulative over the step
         for rnd in range(MAX_ROUNDS + 1):
             if rnd == MAX_ROUNDS:
                 self.stats["collapse_unfinished"] += 1            # candidates were still being applied when the rounds ran out
@@ -155,13 +155,11 @@ class _Work:
             if check_dist:
                 _check(lib.drt_rm_surface_filter_list(self.surface._h, ok.data_ptr(), ql_item.data_ptr(), ql_point.data_ptr(), ql_count.data_ptr(), ql_cap,
                                                       float(self.max_dist), _stream()))
-            f_alive.fill_(1)
-            n_done.zero_()
             _check(lib.drt_rm_collapse_apply(None, 3 * nf, ok.data_ptr(), E_snap.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
-                                             vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, length.data_ptr(),
+                                             vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, rnd, length.data_ptr(),
                                              lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), dirty.data_ptr(), SUB_ROUNDS, n_done.data_ptr(), _stream()))
             _check(lib.drt_rm_kill_faces(self.F.data_ptr(), f_alive.data_ptr(), nf, _stream()))
-            n = int(n_done.item())                                # the round's one host round trip
+            n = int(n_done.item()) - done                         # the round's one host round trip
             if DEBUG:
                 print(f"  collapse round: {int(ok.sum())} pass, {n} applied")
             if n == 0:
@@ -181,9 +179,9 @@ class _Work:
         nv = self.V.shape[0]
         nf = self.F.shape[0]
         n_e = 3 * nf                                              # one candidate per directed-edge slot (the lo -> hi slot of an edge speaks for it)
-        lock = torch.empty(nv, dtype=torch.int32, device=self.dev)
+        lock = torch.empty(nv, dtype=torch.int64, device=self.dev)                       # (workspaces: preset by the first round's call)
         dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
-        n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)                      # cumulative over the step
         ok = torch.empty(n_e, dtype=torch.uint8, device=self.dev)
         quad = torch.empty((n_e, 6), dtype=torch.long, device=self.dev)
         q = torch.empty((n_e, 3), dtype=torch.float64, device=self.dev)
@@ -196,10 +194,9 @@ class _Work:
             _check(lib.drt_rm_flip_eval(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
                                         float(max_len), ok.data_ptr(), quad.data_ptr(), q.data_ptr(), _stream()))
             self._filter_by_surface(ok, None, q, n_e, 1)          # the midpoint of the new edge
-            n_done.zero_()
-            _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), nv, lock.data_ptr(), dirty.data_ptr(), SUB_ROUNDS,
+            _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), nv, rnd, lock.data_ptr(), dirty.data_ptr(), SUB_ROUNDS,
                                          n_done.data_ptr(), _stream()))
-            n = int(n_done.item())                                # the round's one host round trip
+            n = int(n_done.item()) - done                         # the round's one host round trip
             if DEBUG:
                 print(f"  flip round: {int(ok.sum())} pass, {n} applied")
             if n == 0:

@@ -355,16 +355,18 @@ int drt_closest_point(drt_scene_t* s, const double* d_points, int64_t n, double*
  *   drt_rm_collapse_eval_all  every directed-edge slot c = 3 f + k of d_faces a candidate (below): ok uint8 [3F] = every rule but the surface
  *                           distance; d_query float64 [3F, max_q, 3] / d_n_query int32 [3F]: the points whose distance to the input surface
  *                           is still to be checked (midpoint, centroids of the faces that survive).
- *   drt_rm_collapse_apply   claim (64-bit atomicMin of (length class, hash(edge, seed), edge index) on d_lock uint64 [V] -- workspace, preset
- *                           here; d_length float64 [E]: edge lengths at the start of the round) what each candidate with ok = 1 writes, and
- *                           apply those that nobody with a higher priority contests: faces rewritten in place, d_f_alive / d_v_alive
- *                           cleared for what dies, *d_n_done += number applied.  `sub_rounds` claim / apply pairs on the same evaluation
- *                           and tables: a collapse that went ahead marks what it read or wrote in d_dirty uint8 [V] (workspace, cleared
- *                           here), and later sub-rounds admit only candidates whose vertices and rings are clean (their verdict stands).
+ *   drt_rm_collapse_apply   claim (64-bit atomicMin of (claim / apply pair number counting down, length class, hash(edge, seed), edge index)
+ *                           on d_lock uint64 [V] -- workspace, preset here when round == 0, the first round of a step; d_length float64
+ *                           [3F]: edge lengths at the start of the round) what each candidate with ok = 1 writes, and apply those that
+ *                           nobody with a higher priority contests: faces rewritten in place, d_f_alive / d_v_alive cleared for what
+ *                           dies, *d_n_done += number applied (cumulative: the caller zeroes it).  `sub_rounds` claim / apply pairs on the
+ *                           same evaluation and tables: a collapse that went ahead stamps what it read or wrote in d_dirty uint8 [V]
+ *                           (workspace, cleared when round == 0) with round + 1, and later sub-rounds admit only candidates whose
+ *                           vertices and rings are clean (their verdict stands).  round in 0 .. 254, consecutive within a step.
  *   drt_rm_flip_eval/apply  the same for edge flips, again one candidate per directed-edge slot (the face across the edge and the "new edge
  *                           exists already" test come from the vertex -> face lists: no edge table); d_quad int64 [3F,6] = a b c d f1 f2 of a
- *                           flip that passes; d_query float64 [3F,3] the midpoint of the new edge; n_items = 3 F; d_lock uint32 [V], d_dirty
- *                           uint8 [V] and sub_rounds as above.
+ *                           flip that passes; d_query float64 [3F,3] the midpoint of the new edge; n_items = 3 F; round, d_lock uint64 [V],
+ *                           d_dirty uint8 [V] and sub_rounds as above.
  *   drt_rm_smooth_target    tangential relaxation targets float64 [V,3].
  *   drt_rm_face_agreement   cosine between each face normal and the consensus of its corners, float64 [F] (before a move).
  *   drt_rm_move_check       after vertices moved: every face that degenerated or folded (against d_a0) takes its three vertices back from
@@ -379,7 +381,7 @@ int drt_rm_vertex_faces(const int64_t* d_faces, int64_t n_faces, int64_t n_verts
 int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
                           double* d_vn, void* stream);
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
-                          const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, const double* d_length,
+                          const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, int round, const double* d_length,
                           uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream);
 /* Round 6: the collapse evaluation runs over EVERY directed-edge slot c = 3 f + k of d_faces (no candidate list: no stream compaction, no host round
  * trip per round).  Slots that are not the lo -> hi representative of their edge, not short, or belong to a face an earlier round killed
@@ -388,7 +390,7 @@ int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* 
  * drt_rm_surface_filter: CheckSurfDist on the device -- item i keeps d_ok[i] only if all of its d_n_query[i] (NULL: one) points
  * d_query[i][k] lie within max_dist of the surface held by scene `s` (the verdict of drt_closest_point's distance, by a search that
  * starts bounded by max_dist and ends at the first triangle inside).
- * drt_rm_kill_faces: faces with d_f_alive[f] == 0 get the indices -1 in place. */
+ * drt_rm_kill_faces: faces with d_f_alive[f] == 0 get the indices -1 in place, and d_f_alive[f] = 1 again (all ones for the next round). */
 int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
                              const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
                              uint8_t* d_ok, int32_t* d_n_query, double* d_query, int32_t* d_list_item, double* d_list_point, uint32_t* d_list_count,
@@ -400,11 +402,11 @@ int drt_rm_surface_filter_list(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_l
                                int64_t list_cap, double max_dist, void* stream);
 int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_query, const double* d_query, int64_t n_items, int max_q,
                           double max_dist, void* stream);
-int drt_rm_kill_faces(int64_t* d_faces, const uint8_t* d_f_alive, int64_t n_faces, void* stream);
+int drt_rm_kill_faces(int64_t* d_faces, uint8_t* d_f_alive, int64_t n_faces, void* stream);
 int drt_rm_flip_eval(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
                      const int64_t* d_vf_face, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream);
-int drt_rm_flip_apply(int64_t n_items, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, uint32_t* d_lock, uint8_t* d_dirty,
-                      int sub_rounds, int32_t* d_n_done, void* stream);
+int drt_rm_flip_apply(int64_t n_items, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, int round, uint64_t* d_lock,
+                      uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream);
 int drt_rm_smooth_target(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
                          double* d_target, void* stream);
 int drt_rm_face_agreement(const int64_t* d_faces, const double* d_verts, const double* d_vn, int64_t n_faces, double* d_a0, void* stream);
