@@ -74,14 +74,16 @@ SIGNATURES = {
     "drt_rm_split_plan": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "drt_rm_split_faces": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
     "drt_rm_vertex_normals": (_c.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
-    "drt_rm_vertex_faces": (_c.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
-    "drt_rm_collapse_eval_all": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _D, _D, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
-    "drt_rm_surface_filter_list": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _D, _P]),
-    "drt_rm_surface_filter": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _D, _P]),
-    "drt_rm_kill_faces": (_c.c_int, [_P, _P, _I64, _P]),
-    "drt_rm_collapse_apply": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _D, _c.c_uint32, _c.c_int, _P, _P, _P, _P, _P, _c.c_int, _P, _P]),
-    "drt_rm_flip_eval": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _D, _P, _P, _P, _P]),
-    "drt_rm_flip_apply": (_c.c_int, [_I64, _P, _P, _P, _I64, _c.c_int, _P, _P, _c.c_int, _P, _P]),
+    "drt_rm_vertex_faces": (_c.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "drt_rm_collapse_eval_all": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _D, _D, _c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "drt_rm_surface_filter_list": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _D, _P, _P]),
+    "drt_rm_surface_filter": (_c.c_int, [_P, _P, _P, _P, _I64, _c.c_int, _D, _P, _P]),
+    "drt_rm_closest_near": (_c.c_int, [_P, _P, _I64, _D, _P, _P]),
+    "drt_rm_kill_faces": (_c.c_int, [_P, _P, _I64, _P, _P]),
+    "drt_rm_collapse_apply": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _D, _c.c_uint32, _c.c_int, _P, _P, _P, _P, _P, _c.c_int, _P, _P, _P]),
+    "drt_rm_round_end": (_c.c_int, [_P, _c.c_int, _P]),
+    "drt_rm_flip_eval": (_c.c_int, [_P, _I64, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P]),
+    "drt_rm_flip_apply": (_c.c_int, [_I64, _P, _P, _P, _I64, _c.c_int, _P, _P, _c.c_int, _P, _P, _P]),
     "drt_rm_smooth_target": (_c.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
     "drt_rm_face_agreement": (_c.c_int, [_P, _P, _P, _I64, _P, _P]),
     "drt_rm_move_check": (_c.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),

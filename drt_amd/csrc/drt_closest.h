@@ -70,10 +70,13 @@ DRT_HD double box_dist2(const Box& b, d3 p) {
     return (gx * gx + gy * gy) + gz * gz;
 }
 
+// (start_dist2: an upper bound the caller believes in -- a triangle must be STRICTLY closer to be reported; face stays -1 when none is, and
+// the caller asks again without a bound.  A search that starts bounded opens a fraction of the nodes and, when it finds anything, finds what
+// the unbounded one finds: same visiting order, same arithmetic, same winner among ties.)
 template <class STACK>
 DRT_HD Closest closest_point(const Node4Q* __restrict__ nodes, const TriRec* __restrict__ tris, int n_tris,
-                             const int32_t* __restrict__ faces, const float* __restrict__ verts, d3 p, STACK& st) {
-    Closest best{INFINITY, -1, d3{0.0, 0.0, 0.0}};
+                             const int32_t* __restrict__ faces, const float* __restrict__ verts, d3 p, STACK& st, double start_dist2 = INFINITY) {
+    Closest best{start_dist2, -1, d3{0.0, 0.0, 0.0}};
     if (n_tris <= 0) return best;
     constexpr double kSlack = 1.0 - 1e-12;
     st.sp = 0;

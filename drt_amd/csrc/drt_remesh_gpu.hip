@@ -137,7 +137,8 @@ __global__ void k_rm_vertex_normals(const int64_t* __restrict__ F, const double*
 // a merge sort of a dozen launches, plus a gather and a search) took 160 us a time, 35 times per remesh call.  Count, scan, fill with an
 // atomic cursor, then each vertex puts its handful of faces in ascending order: four small launches, and the same table bit for bit
 // (ascending runs are what make the vertex normals -- float64 sums in run order -- and so the whole remesh deterministic).
-__global__ void k_rm_vf_count(const int64_t* __restrict__ F, int64_t n_corners, int32_t* count) {
+__global__ void k_rm_vf_count(const int64_t* __restrict__ F, int64_t n_corners, int32_t* count, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= n_corners) return;
     const int64_t v = F[c];
@@ -145,7 +146,8 @@ __global__ void k_rm_vf_count(const int64_t* __restrict__ F, int64_t n_corners, 
 }
 // exclusive scan of count[0 .. n) -> start[0 .. n] by ONE workgroup (n = V is tens of thousands): tiles of 4096, four counts per thread
 // (coalesced), a shuffle scan inside each wavefront, the sixteen wavefront totals through LDS, the running total carried from tile to tile
-__global__ void __launch_bounds__(1024) k_rm_vf_scan(const int32_t* __restrict__ count, int64_t n, int64_t* __restrict__ start) {
+__global__ void __launch_bounds__(1024) k_rm_vf_scan(const int32_t* __restrict__ count, int64_t n, int64_t* __restrict__ start, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     __shared__ int64_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     int64_t carry = 0;
@@ -170,7 +172,8 @@ __global__ void __launch_bounds__(1024) k_rm_vf_scan(const int32_t* __restrict__
     }
     if (t == 0) start[n] = carry;
 }
-__global__ void k_rm_vf_fill(const int64_t* __restrict__ F, int64_t n_corners, const int64_t* __restrict__ start, int32_t* count, int64_t* __restrict__ vf_face) {
+__global__ void k_rm_vf_fill(const int64_t* __restrict__ F, int64_t n_corners, const int64_t* __restrict__ start, int32_t* count, int64_t* __restrict__ vf_face, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= n_corners) return;
     const int64_t v = F[c];
@@ -178,7 +181,8 @@ __global__ void k_rm_vf_fill(const int64_t* __restrict__ F, int64_t n_corners, c
 }
 // each vertex: its run ascending (insertion sort of a handful), then -- when asked -- its area-weighted normal, summed in that order
 __global__ void k_rm_vf_sort(const int64_t* __restrict__ F, const int64_t* __restrict__ start, int64_t* __restrict__ vf_face, int64_t n_verts,
-                             const double* __restrict__ V, double* __restrict__ vn) {
+                             const double* __restrict__ V, double* __restrict__ vn, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (v >= n_verts) return;
     const int64_t lo = start[v], hi = start[v + 1];
@@ -257,7 +261,8 @@ __device__ void collapse_eval_one(int64_t c, int64_t a, int64_t b, const int64_t
 __global__ void k_rm_collapse_eval_all(const int64_t* __restrict__ F, int64_t n_faces, const double* __restrict__ V, const double* __restrict__ vn,
                                        const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double min_len, double max_len, int max_q,
                                        int64_t* __restrict__ E_snap, double* __restrict__ length, uint8_t* __restrict__ ok, int32_t* __restrict__ n_query,
-                                       double* __restrict__ q, int32_t* __restrict__ ql_item, double* __restrict__ ql_point, unsigned* ql_count, unsigned ql_cap) {
+                                       double* __restrict__ q, int32_t* __restrict__ ql_item, double* __restrict__ ql_point, unsigned* ql_count, unsigned ql_cap, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= 3 * n_faces) return;
     const int64_t f = c / 3;
@@ -289,7 +294,8 @@ __global__ void k_rm_collapse_eval_all(const int64_t* __restrict__ F, int64_t n_
 // CheckSurfDist over the compact list of the round's query points (count on the device: no host round trip)
 __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter_list(TraceCtx c, const int32_t* __restrict__ faces, const float* __restrict__ verts,
                                                                          uint8_t* ok, const int32_t* __restrict__ item, const double* __restrict__ point,
-                                                                         const unsigned* __restrict__ count, unsigned cap, double max_dist) {
+                                                                         const unsigned* __restrict__ count, unsigned cap, double max_dist, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     __shared__ int32_t lds[kStackFast][kTraceBlock];
     Stack st = make_stack(lds, c);
     const unsigned n = min(*count, cap);
@@ -303,7 +309,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter_list(TraceCtx
 // from the INPUT surface (closest point on the scene's tree, the query of drt_closest_point) takes the item's `ok` back.
 __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter(TraceCtx c, const int32_t* __restrict__ faces, const float* __restrict__ verts,
                                                                     uint8_t* ok, const int32_t* __restrict__ n_query, const double* __restrict__ q,
-                                                                    int64_t n_items, int max_q, double max_dist) {
+                                                                    int64_t n_items, int max_q, double max_dist, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     __shared__ int32_t lds[kStackFast][kTraceBlock];
     Stack st = make_stack(lds, c);
     const int64_t n = n_items * max_q;
@@ -314,9 +321,24 @@ __global__ void __launch_bounds__(kTraceBlock) k_rm_surface_filter(TraceCtx c, c
         if (!within_distance(c.nodes, c.tris, c.n_tris, faces, verts, load_d3(q, i), max_dist, st)) ok[item] = 0;
     }
 }
+// the projection step: the closest point of the input surface to every vertex.  The vertices sit within a fraction of an edge length of
+// it (they were on it before the relaxation), so the search starts bounded by `hint` and falls back to the unbounded query for the rare
+// vertex farther out -- the result is the one drt_closest_point gives, at a fifth of its (latency-bound) time.
+__global__ void __launch_bounds__(kTraceBlock) k_rm_closest_near(TraceCtx c, const int32_t* __restrict__ faces, const float* __restrict__ verts,
+                                                                  const double* __restrict__ points, int64_t n, double hint2, double* __restrict__ closest) {
+    __shared__ int32_t lds[kStackFast][kTraceBlock];
+    Stack st = make_stack(lds, c);
+    for (int64_t i = blockIdx.x * (int64_t)kTraceBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTraceBlock) {
+        const d3 p = load_d3(points, i);
+        Closest r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, p, st, hint2);
+        if (r.face < 0) r = closest_point(c.nodes, c.tris, c.n_tris, faces, verts, p, st);
+        store_d3(closest, i, r.point);
+    }
+}
 // the faces a round's collapses killed leave the face array in place: their indices become -1 (the next round's tables skip them; one
 // compaction at the end of the step instead of one per round)
-__global__ void k_rm_kill_faces(int64_t* __restrict__ F, uint8_t* __restrict__ f_alive, int64_t n_faces) {
+__global__ void k_rm_kill_faces(int64_t* __restrict__ F, uint8_t* __restrict__ f_alive, int64_t n_faces, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (f < n_faces && !f_alive[f]) { F[3 * f] = -1; F[3 * f + 1] = -1; F[3 * f + 2] = -1; f_alive[f] = 1; }      // (all ones again for the next round)
 }
@@ -339,7 +361,8 @@ template <bool APPLY>
 __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_cand, const uint8_t* __restrict__ ok, const int64_t* __restrict__ E,
                                     int64_t* F, double* V, const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double min_len,
                                     unsigned seed, unsigned generation, uint8_t stamp, const double* __restrict__ length, unsigned long long* lock,
-                                    uint8_t* __restrict__ f_alive, uint8_t* __restrict__ v_alive, uint8_t* dirty, int32_t* n_done) {
+                                    uint8_t* __restrict__ f_alive, uint8_t* __restrict__ v_alive, uint8_t* dirty, int32_t* n_done, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= n_cand || !ok[c]) return;
     const int64_t e = cand ? cand[c] : c, a = E[2 * e], b = E[2 * e + 1];          // (no list: every directed-edge slot is a candidate slot)
@@ -396,7 +419,8 @@ __global__ void k_rm_collapse_claim(const int64_t* __restrict__ cand, int64_t n_
 // midpoint of the new edge as its surface-distance query.
 __global__ void k_rm_flip_eval(const int64_t* __restrict__ F, int64_t n_faces, const double* __restrict__ V, const double* __restrict__ vn,
                                const int64_t* __restrict__ vf_start, const int64_t* __restrict__ vf_face, double max_len,
-                               uint8_t* __restrict__ ok, int64_t* __restrict__ quad /* [3F,6]: a b c d f1 f2 */, double* __restrict__ q) {
+                               uint8_t* __restrict__ ok, int64_t* __restrict__ quad /* [3F,6]: a b c d f1 f2 */, double* __restrict__ q, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= 3 * n_faces) return;
     ok[e] = 0;
@@ -445,7 +469,8 @@ __global__ void k_rm_flip_eval(const int64_t* __restrict__ F, int64_t n_faces, c
 }
 template <bool APPLY>
 __global__ void k_rm_flip_claim(int64_t n_edges, const uint8_t* __restrict__ ok, const int64_t* __restrict__ quad, int64_t* F, unsigned generation, uint8_t stamp,
-                                unsigned long long* lock, uint8_t* dirty, int32_t* n_done) {
+                                unsigned long long* lock, uint8_t* dirty, int32_t* n_done, const int32_t* __restrict__ live) {
+    if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
     const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= n_edges || !ok[e]) return;
     const int64_t* o = quad + 6 * e;
@@ -544,6 +569,20 @@ __global__ void k_rm_revert(double* __restrict__ V, const double* __restrict__ o
     if (v < n_verts && revert[v]) store_d3(V, v, ldv(old, v));
 }
 
+// The end of an evaluate / claim / apply round, decided ON THE DEVICE (round 6: the driver used to read the round's count back -- one host
+// round trip per round, 76 us of an idle GPU each -- to decide whether to go on).  ctl int32 [8]: [0] live, [1] operations applied so far
+// (what the apply kernels add to), [2] that count at the end of the previous round, [3] the first round's count, [4] rounds that ran.
+// A step ends when a round applies nothing, or less than 1 / tail_cut of what its first round applied (and less than four); every kernel
+// of a later round of the batch the driver enqueued ahead returns at once.
+__global__ void k_rm_round_end(int32_t* ctl, int tail_cut) {
+    if (!ctl[0]) return;
+    const int32_t n = ctl[1] - ctl[2];
+    ctl[2] = ctl[1];
+    if (ctl[4]++ == 0) ctl[3] = n;
+    const int32_t floor_ = ctl[3] / tail_cut > 4 ? ctl[3] / tail_cut : 4;
+    ctl[0] = n > 0 && n >= floor_ ? 1 : 0;
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
 }  // namespace
@@ -584,15 +623,15 @@ int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int64_t* d
 }
 
 int drt_rm_vertex_faces(const int64_t* d_faces, int64_t n_faces, int64_t n_verts, int32_t* d_count, int64_t* d_vf_start, int64_t* d_vf_face,
-                        const double* d_verts, double* d_vn, void* stream) {
+                        const double* d_verts, double* d_vn, const int32_t* d_live, void* stream) {
     if (n_faces < 0 || n_verts <= 0) return fail(DRT_E_INVALID, "bad mesh size");
     if (!d_count || !d_vf_start || !d_vf_face || (n_faces && !d_faces) || (d_vn && !d_verts)) return fail(DRT_E_INVALID, "null pointer argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t) * (size_t)n_verts, st));
-    if (n_faces) k_rm_vf_count<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, d_count);
-    k_rm_vf_scan<<<1, 1024, 0, st>>>(d_count, n_verts, d_vf_start);
-    if (n_faces) k_rm_vf_fill<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, d_vf_start, d_count, d_vf_face);
-    k_rm_vf_sort<<<blocks_for(n_verts), 256, 0, st>>>(d_faces, d_vf_start, d_vf_face, n_verts, d_verts, d_vn);
+    if (n_faces) k_rm_vf_count<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, d_count, d_live);
+    k_rm_vf_scan<<<1, 1024, 0, st>>>(d_count, n_verts, d_vf_start, d_live);
+    if (n_faces) k_rm_vf_fill<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, 3 * n_faces, d_vf_start, d_count, d_vf_face, d_live);
+    k_rm_vf_sort<<<blocks_for(n_verts), 256, 0, st>>>(d_faces, d_vf_start, d_vf_face, n_verts, d_verts, d_vn, d_live);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
@@ -609,7 +648,7 @@ int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const i
 int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
                              const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
                              uint8_t* d_ok, int32_t* d_n_query, double* d_query, int32_t* d_list_item, double* d_list_point, uint32_t* d_list_count,
-                             int64_t list_cap, void* stream) {
+                             int64_t list_cap, const int32_t* d_live, void* stream) {
     if (n_faces <= 0) return DRT_OK;
     if (!d_faces || !d_verts || !d_vn || !d_vf_start || !d_vf_face || !d_edge_snap || !d_length || !d_ok || !d_n_query || !d_query || max_q < 1)
         return fail(DRT_E_INVALID, "bad argument");
@@ -618,26 +657,26 @@ int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const doub
     if (d_list_item) HIP_TRY(hipMemsetAsync(d_list_count, 0, sizeof(uint32_t), st));
     k_rm_collapse_eval_all<<<blocks_for(3 * n_faces), 256, 0, st>>>(d_faces, n_faces, d_verts, d_vn, d_vf_start, d_vf_face, min_len, max_len, max_q,
                                                                    d_edge_snap, d_length, d_ok, d_n_query, d_query, d_list_item, d_list_point, d_list_count,
-                                                                   (unsigned)(d_list_item ? list_cap : 0));
+                                                                   (unsigned)(d_list_item ? list_cap : 0), d_live);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
 int drt_rm_surface_filter_list(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_list_item, const double* d_list_point, const uint32_t* d_list_count,
-                               int64_t list_cap, double max_dist, void* stream) {
+                               int64_t list_cap, double max_dist, const int32_t* d_live, void* stream) {
     CHECK_BUILT(s);
     if (!d_ok || !d_list_item || !d_list_point || !d_list_count || list_cap <= 0 || list_cap > UINT32_MAX / 2) return fail(DRT_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     { int rc = wait_build(s, st); if (rc) return rc; }
     { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
     k_rm_surface_filter_list<<<grid_for(list_cap, kTraceBlock, s->grid_trace), kTraceBlock, 0, st>>>(trace_ctx(s), s->faces, s->verts, d_ok, d_list_item, d_list_point,
-                                                                                                      d_list_count, (unsigned)list_cap, max_dist);
+                                                                                                      d_list_count, (unsigned)list_cap, max_dist, d_live);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
 int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_query, const double* d_query, int64_t n_items, int max_q, double max_dist,
-                          void* stream) {
+                          const int32_t* d_live, void* stream) {
     CHECK_BUILT(s);
     if (n_items <= 0) return DRT_OK;
     if (!d_ok || !d_query || max_q < 1) return fail(DRT_E_INVALID, "bad argument");
@@ -645,22 +684,36 @@ int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_quer
     { int rc = wait_build(s, st); if (rc) return rc; }
     { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
     k_rm_surface_filter<<<grid_for(n_items * max_q, kTraceBlock, s->grid_trace), kTraceBlock, 0, st>>>(trace_ctx(s), s->faces, s->verts, d_ok, d_n_query, d_query,
-                                                                                                        n_items, max_q, max_dist);
+                                                                                                        n_items, max_q, max_dist, d_live);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
-int drt_rm_kill_faces(int64_t* d_faces, uint8_t* d_f_alive, int64_t n_faces, void* stream) {
+int drt_rm_closest_near(drt_scene_t* s, const double* d_points, int64_t n, double hint_radius, double* d_closest, void* stream) {
+    CHECK_BUILT(s);
+    if (n < 0) return fail(DRT_E_INVALID, "negative point count");
+    if (n == 0) return DRT_OK;
+    if (!d_points || !d_closest) return fail(DRT_E_INVALID, "null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = wait_build(s, st); if (rc) return rc; }
+    { int rc = ensure_slow_stack(s, st); if (rc) return rc; }
+    const double hint2 = hint_radius > 0.0 ? hint_radius * hint_radius : INFINITY;          // (NaN, zero, negative: no hint)
+    k_rm_closest_near<<<grid_for(n, kTraceBlock, s->grid_trace), kTraceBlock, 0, st>>>(trace_ctx(s), s->faces, s->verts, d_points, n, hint2, d_closest);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
+int drt_rm_kill_faces(int64_t* d_faces, uint8_t* d_f_alive, int64_t n_faces, const int32_t* d_live, void* stream) {
     if (n_faces <= 0) return DRT_OK;
     if (!d_faces || !d_f_alive) return fail(DRT_E_INVALID, "null pointer argument");
-    k_rm_kill_faces<<<blocks_for(n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, d_f_alive, n_faces);
+    k_rm_kill_faces<<<blocks_for(n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, d_f_alive, n_faces, d_live);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
                           const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, int round, const double* d_length,
-                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream) {
+                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, const int32_t* d_live, void* stream) {
     if (n_cand <= 0) return DRT_OK;
     if (!d_ok || !d_edges || !d_faces || !d_verts || !d_vf_start || !d_vf_face || !d_length || !d_lock || !d_f_alive || !d_v_alive || !d_dirty ||
         !d_n_done || n_verts <= 0 || sub_rounds < 1 || round < 0 || round > 254 || (int64_t)(round + 1) * sub_rounds > 0x7FFF)
@@ -675,24 +728,31 @@ int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* 
     for (int r = 0; r < sub_rounds; ++r) {
         const uint32_t sd = seed + 0x632BE5ABu * (uint32_t)r;
         const unsigned gen = (unsigned)(round * sub_rounds + r);
-        k_rm_collapse_claim<false><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, gen, stamp, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
-        k_rm_collapse_claim<true><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, gen, stamp, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done);
+        k_rm_collapse_claim<false><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, gen, stamp, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done, d_live);
+        k_rm_collapse_claim<true><<<blocks_for(n_cand), 256, 0, st>>>(d_cand, n_cand, d_ok, d_edges, d_faces, d_verts, d_vf_start, d_vf_face, min_len, sd, gen, stamp, d_length, lock, d_f_alive, d_v_alive, d_dirty, d_n_done, d_live);
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
+int drt_rm_round_end(int32_t* d_ctl, int tail_cut, void* stream) {
+    if (!d_ctl || tail_cut < 1) return fail(DRT_E_INVALID, "bad argument");
+    k_rm_round_end<<<1, 1, 0, (hipStream_t)stream>>>(d_ctl, tail_cut);
+    HIP_TRY(hipGetLastError());
+    return DRT_OK;
+}
+
 int drt_rm_flip_eval(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
-                     const int64_t* d_vf_face, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream) {
+                     const int64_t* d_vf_face, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, const int32_t* d_live, void* stream) {
     if (n_faces <= 0) return DRT_OK;
     if (!d_faces || !d_verts || !d_vn || !d_vf_start || !d_vf_face || !d_ok || !d_quad || !d_query) return fail(DRT_E_INVALID, "null pointer argument");
-    k_rm_flip_eval<<<blocks_for(3 * n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, n_faces, d_verts, d_vn, d_vf_start, d_vf_face, max_len, d_ok, d_quad, d_query);
+    k_rm_flip_eval<<<blocks_for(3 * n_faces), 256, 0, (hipStream_t)stream>>>(d_faces, n_faces, d_verts, d_vn, d_vf_start, d_vf_face, max_len, d_ok, d_quad, d_query, d_live);
     HIP_TRY(hipGetLastError());
     return DRT_OK;
 }
 
 int drt_rm_flip_apply(int64_t n_items, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, int round, uint64_t* d_lock,
-                      uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream) {
+                      uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, const int32_t* d_live, void* stream) {
     if (n_items <= 0) return DRT_OK;
     if (!d_ok || !d_quad || !d_faces || !d_lock || !d_dirty || !d_n_done || n_verts <= 0 || sub_rounds < 1 || round < 0 || round > 254 ||
         (int64_t)(round + 1) * sub_rounds > 0x7FFF)
@@ -706,8 +766,8 @@ int drt_rm_flip_apply(int64_t n_items, const uint8_t* d_ok, const int64_t* d_qua
     const uint8_t stamp = (uint8_t)(round + 1);
     for (int r = 0; r < sub_rounds; ++r) {
         const unsigned gen = (unsigned)(round * sub_rounds + r);
-        k_rm_flip_claim<false><<<blocks_for(n_items), 256, 0, st>>>(n_items, d_ok, d_quad, d_faces, gen, stamp, lock, d_dirty, d_n_done);
-        k_rm_flip_claim<true><<<blocks_for(n_items), 256, 0, st>>>(n_items, d_ok, d_quad, d_faces, gen, stamp, lock, d_dirty, d_n_done);
+        k_rm_flip_claim<false><<<blocks_for(n_items), 256, 0, st>>>(n_items, d_ok, d_quad, d_faces, gen, stamp, lock, d_dirty, d_n_done, d_live);
+        k_rm_flip_claim<true><<<blocks_for(n_items), 256, 0, st>>>(n_items, d_ok, d_quad, d_faces, gen, stamp, lock, d_dirty, d_n_done, d_live);
     }
     HIP_TRY(hipGetLastError());
     return DRT_OK;

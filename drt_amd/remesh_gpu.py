@@ -40,6 +40,8 @@ MAX_Q = 24                 # surface-distance queries per collapse candidate (mi
 MAX_ROUNDS = 96            # evaluate / claim / apply rounds per step (a round applies an independent set of the candidates: a few per cent)
 SUB_ROUNDS = int(__import__("os").environ.get("DRT_REMESH_SUB_ROUNDS", 3))     # claim / apply pairs per evaluation (one set of edge tables, vertex -> face lists and surface queries
                            # serves several independent sets: candidates whose neighbourhood an earlier pair of the round touched sit out until the next evaluation)
+ROUND_BATCH = int(__import__("os").environ.get("DRT_REMESH_ROUND_BATCH", 4))  # rounds enqueued between two read-backs of the step's control block: the DEVICE ends a step
+                           # (drt_rm_round_end); the rounds of a batch that come after the end are no-ops (every kernel returns at its first instruction)
 TAIL_CUT = int(__import__("os").environ.get("DRT_REMESH_TAIL_CUT", 32))       # a step ends when a round applies less than 1 / TAIL_CUT of what its first round applied
 DEBUG = False
 
@@ -51,16 +53,24 @@ def _check(rc):
 class _Work:
     """The mesh being edited: float64 vertices [V,3], int64 faces [F,3] on the device, and the derived tables."""
 
-    def __init__(self, V, F, surface, max_dist):
+    def __init__(self, V, F, surface, max_dist, hint=0.0):
         self.V, self.F = V.contiguous(), F.contiguous()
+        self.hint = hint                 # how far from the input surface a vertex is expected to be at most (bounds the projection's search; 0: no bound)
         self.surface, self.max_dist = surface, max_dist
         self.dev = V.device
+        self.n_dead_vertices = 0         # vertices the collapses since the last compact() left without a face
         # what a caller can check afterwards: evaluation rounds per step, steps that ran out of rounds with candidates still passing,
         # moves that still folded a face after the last roll-back round (each is then rolled back by more rounds: see move_vertices)
         self.stats = {"collapse_rounds": 0, "flip_rounds": 0, "collapse_unfinished": 0, "flip_unfinished": 0, "move_rounds_max": 0, "move_unresolved": 0}
 
+    def _new_ctl(self):
+        """The round control block of a step (drt_rm_round_end): live = 1, everything else 0."""
+        ctl = torch.zeros(8, dtype=torch.int32, device=self.dev)
+        ctl[0] = 1
+        return ctl
+
     # ---- derived tables
-    def csr(self, normals=False):
+    def csr(self, normals=False, live=None):
         """vertex -> incident faces: vf_start int64 [V+1], vf_face int64 [3F] (ascending face order inside a vertex; faces a collapse round
         killed -- indices -1 -- in nobody's list), by drt_rm_vertex_faces; with ``normals`` also the area-weighted vertex normals."""
         nv, nf = self.V.shape[0], self.F.shape[0]
@@ -69,7 +79,7 @@ class _Work:
         count = torch.empty(nv, dtype=torch.int32, device=self.dev)
         vn = torch.empty_like(self.V) if normals else None
         _check(_lib.lib().drt_rm_vertex_faces(self.F.data_ptr(), nf, nv, count.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
-                                              self.V.data_ptr(), _lib.ptr(vn), _stream()))
+                                              self.V.data_ptr(), _lib.ptr(vn), _lib.ptr(live), _stream()))
         return (vf_start, vf_face, vn) if normals else (vf_start, vf_face)
 
     def vertex_normals(self, vf_start, vf_face):
@@ -111,18 +121,19 @@ class _Work:
         return n_split
 
     # ---- 2. collapse
-    def _filter_by_surface(self, ok, nq, q, n_items, max_q):
+    def _filter_by_surface(self, ok, nq, q, n_items, max_q, live=None):
         """CheckSurfDist on the device (drt_rm_surface_filter): candidates whose query points leave the input surface lose their `ok`."""
         if self.surface is None or not np.isfinite(self.max_dist) or n_items == 0:
             return
-        _check(_lib.lib().drt_rm_surface_filter(self.surface._h, ok.data_ptr(), _lib.ptr(nq), q.data_ptr(), n_items, max_q, float(self.max_dist), _stream()))
+        _check(_lib.lib().drt_rm_surface_filter(self.surface._h, ok.data_ptr(), _lib.ptr(nq), q.data_ptr(), n_items, max_q, float(self.max_dist),
+                                                _lib.ptr(live), _stream()))
 
     def collapse_short_edges(self, min_len, max_len):
         """Rounds of evaluate (every directed-edge slot of the face array at once) -> surface filter -> claim / apply.  Round 6: no candidate
-        list, no per-round compaction of the face array (killed faces stay in place with indices -1 until the step is through) and ONE host
-        round trip per round -- the number of collapses it applied, which ends the step -- instead of seven; about a third of the launches."""
+        list, no per-round compaction of the face array (killed faces stay in place with indices -1 until the step is through), and the
+        DEVICE decides when the step is over (drt_rm_round_end): the driver enqueues ROUND_BATCH rounds at a time and reads the step's
+        control block back once per batch -- two or three host round trips per step, where there were seven per round."""
         lib = _lib.lib()
-        done = first = 0
         nf = self.F.shape[0]
         dev = self.dev
         v_alive = torch.ones(self.V.shape[0], dtype=torch.uint8, device=dev)
@@ -141,35 +152,36 @@ class _Work:
         lock = torch.empty(nv, dtype=torch.int64, device=dev)                           # (workspaces: preset by the call)
         dirty = torch.empty(nv, dtype=torch.uint8, device=dev)
         f_alive = torch.ones(nf, dtype=torch.uint8, device=dev)                          # (drt_rm_kill_faces leaves it all ones again)
-        n_done = torch.zeros(1, dtype=torch.int32, device=dev)                           # cumulative over the step
-        for rnd in range(MAX_ROUNDS + 1):
-            if rnd == MAX_ROUNDS:
-                self.stats["collapse_unfinished"] += 1            # candidates were still being applied when the rounds ran out
+        ctl = self._new_ctl()
+        live, n_done = ctl.data_ptr(), ctl.data_ptr() + 4
+        rnd = 0
+        while True:
+            for _ in range(ROUND_BATCH):                          # rounds enqueued ahead: the device ends the step (drt_rm_round_end)
+                vf_start, vf_face, vn = self.csr(normals=True, live=ctl)      # (killed faces hold -1: in nobody's list)
+                _check(lib.drt_rm_collapse_eval_all(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
+                                                    float(min_len), float(max_len), MAX_Q, E_snap.data_ptr(), length.data_ptr(), ok.data_ptr(),
+                                                    nq.data_ptr(), q.data_ptr(), _lib.ptr(ql_item), _lib.ptr(ql_point), _lib.ptr(ql_count), ql_cap, live, _stream()))
+                # CheckSurfDist: the midpoint and the centroid of every face that survives must stay near the input surface
+                if check_dist:
+                    _check(lib.drt_rm_surface_filter_list(self.surface._h, ok.data_ptr(), ql_item.data_ptr(), ql_point.data_ptr(), ql_count.data_ptr(), ql_cap,
+                                                          float(self.max_dist), live, _stream()))
+                _check(lib.drt_rm_collapse_apply(None, 3 * nf, ok.data_ptr(), E_snap.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
+                                                 vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, rnd, length.data_ptr(),
+                                                 lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), dirty.data_ptr(), SUB_ROUNDS, n_done, live, _stream()))
+                _check(lib.drt_rm_kill_faces(self.F.data_ptr(), f_alive.data_ptr(), nf, live, _stream()))
+                _check(lib.drt_rm_round_end(ctl.data_ptr(), TAIL_CUT, _stream()))
+                rnd += 1
+            still_live, done, _, _, ran = ctl.tolist()[:5]        # the batch's one host round trip
+            if not still_live or rnd + ROUND_BATCH > MAX_ROUNDS:
                 break
-            self.stats["collapse_rounds"] += 1
-            vf_start, vf_face, vn = self.csr(normals=True)        # (killed faces hold -1: in nobody's list)
-            _check(lib.drt_rm_collapse_eval_all(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
-                                                float(min_len), float(max_len), MAX_Q, E_snap.data_ptr(), length.data_ptr(), ok.data_ptr(),
-                                                nq.data_ptr(), q.data_ptr(), _lib.ptr(ql_item), _lib.ptr(ql_point), _lib.ptr(ql_count), ql_cap, _stream()))
-            # CheckSurfDist: the midpoint and the centroid of every face that survives must stay near the input surface
-            if check_dist:
-                _check(lib.drt_rm_surface_filter_list(self.surface._h, ok.data_ptr(), ql_item.data_ptr(), ql_point.data_ptr(), ql_count.data_ptr(), ql_cap,
-                                                      float(self.max_dist), _stream()))
-            _check(lib.drt_rm_collapse_apply(None, 3 * nf, ok.data_ptr(), E_snap.data_ptr(), self.F.data_ptr(), self.V.data_ptr(),
-                                             vf_start.data_ptr(), vf_face.data_ptr(), nv, float(min_len), 0x9E3779B9 * (rnd + 1) & 0xFFFFFFFF, rnd, length.data_ptr(),
-                                             lock.data_ptr(), f_alive.data_ptr(), v_alive.data_ptr(), dirty.data_ptr(), SUB_ROUNDS, n_done.data_ptr(), _stream()))
-            _check(lib.drt_rm_kill_faces(self.F.data_ptr(), f_alive.data_ptr(), nf, _stream()))
-            n = int(n_done.item()) - done                         # the round's one host round trip
-            if DEBUG:
-                print(f"  collapse round: {int(ok.sum())} pass, {n} applied")
-            if n == 0:
-                break
-            done += n
-            first = first or n
-            if n < max(4, first // TAIL_CUT):     # the tail of a step: a handful of candidates per round, each round a rebuild of the tables;
-                break                             # what is left is picked up by the next of the call's iterations (or the next pass)
+        self.stats["collapse_rounds"] += ran
+        self.stats["collapse_unfinished"] += int(bool(still_live))        # candidates were still being applied when the rounds ran out
         if done:
-            self.F = self.F[self.F[:, 0] >= 0].contiguous()
+            # every collapse killed exactly two faces and one vertex (closed manifold, link condition): the sizes are known, so the compaction
+            # needs no read-back
+            keep = torch.nonzero_static(self.F[:, 0] >= 0, size=nf - 2 * done).squeeze(1)
+            self.F = self.F[keep].contiguous()
+            self.n_dead_vertices += done
         return done
 
     # ---- 3. flip
@@ -181,30 +193,27 @@ class _Work:
         n_e = 3 * nf                                              # one candidate per directed-edge slot (the lo -> hi slot of an edge speaks for it)
         lock = torch.empty(nv, dtype=torch.int64, device=self.dev)                       # (workspaces: preset by the first round's call)
         dirty = torch.empty(nv, dtype=torch.uint8, device=self.dev)
-        n_done = torch.zeros(1, dtype=torch.int32, device=self.dev)                      # cumulative over the step
         ok = torch.empty(n_e, dtype=torch.uint8, device=self.dev)
         quad = torch.empty((n_e, 6), dtype=torch.long, device=self.dev)
         q = torch.empty((n_e, 3), dtype=torch.float64, device=self.dev)
-        for rnd in range(MAX_ROUNDS + 1):
-            if rnd == MAX_ROUNDS:
-                self.stats["flip_unfinished"] += 1
+        ctl = self._new_ctl()
+        live, n_done = ctl.data_ptr(), ctl.data_ptr() + 4
+        rnd = 0
+        while True:
+            for _ in range(ROUND_BATCH):
+                vf_start, vf_face, vn = self.csr(normals=True, live=ctl)
+                _check(lib.drt_rm_flip_eval(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
+                                            float(max_len), ok.data_ptr(), quad.data_ptr(), q.data_ptr(), live, _stream()))
+                self._filter_by_surface(ok, None, q, n_e, 1, live=ctl)   # the midpoint of the new edge
+                _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), nv, rnd, lock.data_ptr(), dirty.data_ptr(), SUB_ROUNDS,
+                                             n_done, live, _stream()))
+                _check(lib.drt_rm_round_end(ctl.data_ptr(), TAIL_CUT, _stream()))
+                rnd += 1
+            still_live, done, _, _, ran = ctl.tolist()[:5]        # the batch's one host round trip
+            if not still_live or rnd + ROUND_BATCH > MAX_ROUNDS:
                 break
-            self.stats["flip_rounds"] += 1
-            vf_start, vf_face, vn = self.csr(normals=True)
-            _check(lib.drt_rm_flip_eval(self.F.data_ptr(), nf, self.V.data_ptr(), vn.data_ptr(), vf_start.data_ptr(), vf_face.data_ptr(),
-                                        float(max_len), ok.data_ptr(), quad.data_ptr(), q.data_ptr(), _stream()))
-            self._filter_by_surface(ok, None, q, n_e, 1)          # the midpoint of the new edge
-            _check(lib.drt_rm_flip_apply(n_e, ok.data_ptr(), quad.data_ptr(), self.F.data_ptr(), nv, rnd, lock.data_ptr(), dirty.data_ptr(), SUB_ROUNDS,
-                                         n_done.data_ptr(), _stream()))
-            n = int(n_done.item()) - done                         # the round's one host round trip
-            if DEBUG:
-                print(f"  flip round: {int(ok.sum())} pass, {n} applied")
-            if n == 0:
-                break
-            done += n
-            first = first or n
-            if n < max(4, first // TAIL_CUT):
-                break
+        self.stats["flip_rounds"] += ran
+        self.stats["flip_unfinished"] += int(bool(still_live))
         return done
 
     # ---- 4./5. relaxation and projection, with roll-back
@@ -245,16 +254,21 @@ class _Work:
         if self.surface is None:
             return
         vf_start, vf_face = self.csr()
-        _, _, closest = self.surface.closest_point(self.V.contiguous(), want_face=False, want_point=True)
+        closest = torch.empty_like(self.V)
+        _check(_lib.lib().drt_rm_closest_near(self.surface._h, self.V.data_ptr(), self.V.shape[0], float(self.hint), closest.data_ptr(), _stream()))
         self.move_vertices(closest, vf_start, vf_face)
 
     def compact(self):
         """Drop the vertices no face uses (ascending order kept)."""
+        if not self.n_dead_vertices:
+            return
         used = torch.zeros(self.V.shape[0], dtype=torch.bool, device=self.dev)
         used[self.F.reshape(-1)] = True
         remap = torch.cumsum(used.long(), 0) - 1
-        self.V = self.V[used].contiguous()
+        keep = torch.nonzero_static(used, size=self.V.shape[0] - self.n_dead_vertices).squeeze(1)      # (the collapses' count: no read-back)
+        self.V = self.V[keep].contiguous()
         self.F = remap[self.F].contiguous()
+        self.n_dead_vertices = 0
 
 
 def isotropic_remesh_gpu(vertices, faces, target_len, surface=None, iterations=3, max_surf_dist=1.0, flags=ALL, return_stats=False):
@@ -263,10 +277,14 @@ def isotropic_remesh_gpu(vertices, faces, target_len, surface=None, iterations=3
     both.  Closed manifold in, closed manifold out."""
     if not vertices.is_cuda:
         raise RuntimeError("isotropic_remesh_gpu needs device tensors (drt_amd.remesh is the host version)")
-    w = _Work(vertices.detach().to(torch.float64), faces.to(torch.long), surface, float(max_surf_dist) if (flags & CHECK_DIST) and max_surf_dist > 0 else float("inf"))
+    w = _Work(vertices.detach().to(torch.float64), faces.to(torch.long), surface, float(max_surf_dist) if (flags & CHECK_DIST) and max_surf_dist > 0 else float("inf"), hint=float(target_len))
     min_len, max_len = 0.8 * target_len, 4.0 / 3.0 * target_len
     stats = {"split": 0, "collapsed": 0, "flipped": 0, "iterations": 0}
     with torch.no_grad(), torch.cuda.device(vertices.device):
+        # (vertices of the INPUT that no face uses, counted once before anything is enqueued: compact() then knows its sizes from the collapses alone)
+        used = torch.zeros(w.V.shape[0], dtype=torch.bool, device=w.dev)
+        used[w.F.reshape(-1)] = True
+        w.n_dead_vertices = w.V.shape[0] - int(used.sum())
         for _ in range(iterations):
             if flags & SPLIT:
                 for _k in range(3):

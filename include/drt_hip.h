@@ -377,12 +377,12 @@ int drt_rm_split_plan(const int64_t* d_faces, int64_t n_faces, const int64_t* d_
 int drt_rm_split_faces(const int64_t* d_faces, int64_t n_faces, const int64_t* d_mid_of_slot, double* d_verts, const int64_t* d_offset,
                        int64_t* d_faces_out, void* stream);
 int drt_rm_vertex_faces(const int64_t* d_faces, int64_t n_faces, int64_t n_verts, int32_t* d_count, int64_t* d_vf_start, int64_t* d_vf_face,
-                        const double* d_verts, double* d_vn, void* stream);
+                        const double* d_verts, double* d_vn, const int32_t* d_live, void* stream);
 int drt_rm_vertex_normals(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
                           double* d_vn, void* stream);
 int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* d_ok, const int64_t* d_edges, int64_t* d_faces, double* d_verts,
                           const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts, double min_len, uint32_t seed, int round, const double* d_length,
-                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream);
+                          uint64_t* d_lock, uint8_t* d_f_alive, uint8_t* d_v_alive, uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, const int32_t* d_live, void* stream);
 /* Round 6: the collapse evaluation runs over EVERY directed-edge slot c = 3 f + k of d_faces (no candidate list: no stream compaction, no host round
  * trip per round).  Slots that are not the lo -> hi representative of their edge, not short, or belong to a face an earlier round killed
  * (indices -1, drt_rm_kill_faces) report ok = 0.  Outputs sized [3 n_faces]: d_edge_snap int64 [.,2] (the slot's edge at the start of the
@@ -394,19 +394,29 @@ int drt_rm_collapse_apply(const int64_t* d_cand, int64_t n_cand, const uint8_t* 
 int drt_rm_collapse_eval_all(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
                              const int64_t* d_vf_face, double min_len, double max_len, int max_q, int64_t* d_edge_snap, double* d_length,
                              uint8_t* d_ok, int32_t* d_n_query, double* d_query, int32_t* d_list_item, double* d_list_point, uint32_t* d_list_count,
-                             int64_t list_cap, void* stream);
+                             int64_t list_cap, const int32_t* d_live, void* stream);
 /* (d_list_item / d_list_point / d_list_count, optional: the query points of the candidates that passed, appended to ONE compact list of at
  * most list_cap entries -- item = slot, point [3] -- whose length stays on the device; a candidate that does not fit is left to the next
  * round.  drt_rm_surface_filter_list is drt_rm_surface_filter over that list.) */
 int drt_rm_surface_filter_list(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_list_item, const double* d_list_point, const uint32_t* d_list_count,
-                               int64_t list_cap, double max_dist, void* stream);
+                               int64_t list_cap, double max_dist, const int32_t* d_live, void* stream);
 int drt_rm_surface_filter(drt_scene_t* s, uint8_t* d_ok, const int32_t* d_n_query, const double* d_query, int64_t n_items, int max_q,
-                          double max_dist, void* stream);
-int drt_rm_kill_faces(int64_t* d_faces, uint8_t* d_f_alive, int64_t n_faces, void* stream);
+                          double max_dist, const int32_t* d_live, void* stream);
+/* The projection step's query: d_closest float64 [n,3] = the closest point of scene `s` to each of d_points float64 [n,3] -- the point
+ * drt_closest_point reports, by a search that starts bounded by hint_radius (> 0; the vertices of a remesh sit within a fraction of an
+ * edge length of the surface) and falls back to the unbounded one for a point farther out. */
+int drt_rm_closest_near(drt_scene_t* s, const double* d_points, int64_t n, double hint_radius, double* d_closest, void* stream);
+int drt_rm_kill_faces(int64_t* d_faces, uint8_t* d_f_alive, int64_t n_faces, const int32_t* d_live, void* stream);
+/* Round termination on the device.  d_ctl int32 [8], preset {1, 0, 0, 0, 0, ...} at the start of a step: [0] live, [1] operations applied so
+ * far (pass d_ctl + 1 as d_n_done of the apply calls), [2] / [3] the previous / the first round's figures, [4] rounds that ran.
+ * drt_rm_round_end, enqueued after each round, clears [0] when the round applied nothing or fewer than max(4, first / tail_cut); every
+ * call above that takes d_live (= d_ctl, or NULL: always live) turns into a no-op from then on -- so the driver enqueues several rounds
+ * ahead and reads d_ctl back once per batch instead of once per round. */
+int drt_rm_round_end(int32_t* d_ctl, int tail_cut, void* stream);
 int drt_rm_flip_eval(const int64_t* d_faces, int64_t n_faces, const double* d_verts, const double* d_vn, const int64_t* d_vf_start,
-                     const int64_t* d_vf_face, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, void* stream);
+                     const int64_t* d_vf_face, double max_len, uint8_t* d_ok, int64_t* d_quad, double* d_query, const int32_t* d_live, void* stream);
 int drt_rm_flip_apply(int64_t n_items, const uint8_t* d_ok, const int64_t* d_quad, int64_t* d_faces, int64_t n_verts, int round, uint64_t* d_lock,
-                      uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, void* stream);
+                      uint8_t* d_dirty, int sub_rounds, int32_t* d_n_done, const int32_t* d_live, void* stream);
 int drt_rm_smooth_target(const int64_t* d_faces, const double* d_verts, const int64_t* d_vf_start, const int64_t* d_vf_face, int64_t n_verts,
                          double* d_target, void* stream);
 int drt_rm_face_agreement(const int64_t* d_faces, const double* d_verts, const double* d_vn, int64_t n_faces, double* d_a0, void* stream);

@@ -74,6 +74,7 @@ def hostsim():
     hs.hs_intersect.argtypes = [_P, _P, _I64, _P, _P, ctypes.c_int, _P]
     hs.hs_closest_point.argtypes = [_P, _P, _I64, _P, _P, _P]
     hs.hs_within_distance.argtypes = [_P, _P, _P, _I64, _P]
+    hs.hs_closest_near.argtypes = [_P, _P, _P, _I64, _P, _P, _P]
     hs.hs_render_forward.argtypes = [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P]
     hs.hs_render_backward.argtypes = [_P, _P, _P, _P, _I64, _D, _D, _P, _P, _P, _P, _P]
     hs.hs_ray_loss.argtypes = [_P, _P, _P, _P, _P, _I64, _P, _P]

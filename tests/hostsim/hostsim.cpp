@@ -201,6 +201,21 @@ void hs_closest_point(void* h, const double* points, int64_t n, double* dist, in
     }
 }
 
+// the remesher's projection query (k_rm_closest_near): bounded first, unbounded when nothing is strictly inside the bound; found[i] = the
+// bounded search was enough
+void hs_closest_near(void* h, const double* points, const double* hint, int64_t n, double* closest, int32_t* face, uint8_t* found) {
+    HsScene* s = (HsScene*)h;
+    HostStack hs;
+    for (int64_t i = 0; i < n; ++i) {
+        const d3 p = load_d3(points, i);
+        Closest r = closest_point(s->wide.data(), s->tris.data(), (int)s->tris.size(), s->faces.data(), s->verts.data(), p, hs.st, hint[i] * hint[i]);
+        found[i] = r.face >= 0;
+        if (r.face < 0) r = closest_point(s->wide.data(), s->tris.data(), (int)s->tris.size(), s->faces.data(), s->verts.data(), p, hs.st);
+        face[i] = r.face;
+        store_d3(closest, i, r.point);
+    }
+}
+
 // the remesher's surface-distance verdict (within_distance) for each point against its own radius
 void hs_within_distance(void* h, const double* points, const double* radius, int64_t n, uint8_t* within) {
     HsScene* s = (HsScene*)h;

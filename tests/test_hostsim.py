@@ -282,6 +282,15 @@ def test_closest_point_matches_bruteforce(hostsim):
         hostsim.hs_within_distance(h, pts.ctypes.data, radius.ctypes.data, len(pts), got.ctypes.data)
         with np.errstate(invalid="ignore"):
             assert np.array_equal(got.astype(bool), (dist <= radius) & (radius >= 0))
+    # a search that starts bounded (the remesher's projection query) reports the point and the face of the unbounded one -- bit for bit --
+    # whether the bound was enough (strictly farther than the surface) or the fallback ran
+    for hint in (dist * 1.5 + 1e-9, dist, dist * 0.5, np.full(len(dist), 0.05), np.full(len(dist), 1e9)):
+        hint = np.ascontiguousarray(hint)
+        c2 = np.empty((len(pts), 3)); f2 = np.empty(len(pts), dtype=np.int32); found = np.empty(len(pts), dtype=np.uint8)
+        hostsim.hs_closest_near(h, pts.ctypes.data, hint.ctypes.data, len(pts), c2.ctypes.data, f2.ctypes.data, found.ctypes.data)
+        assert np.array_equal(c2, closest) and np.array_equal(f2, face)
+        clear = np.abs(hint - dist) > 1e-9 * (1 + dist)          # (at hint == dist the rounding of dist = sqrt(dist2) decides: either way is right)
+        assert np.array_equal(found.astype(bool)[clear], (dist < hint)[clear])
     hostsim.hs_destroy(h)
 
 
