@@ -39,6 +39,10 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager, 
   DRT_DETERMINISTIC=1 python tools/fuzz_soak_path.py 760 20; } 2>&1 | grep -v amdgpu > $O/soak.txt
 python tools/ubench/trace_repeat.py 9 2>&1 | grep -v amdgpu > $O/trace_repeat.txt
 python tools/ubench/remesh_probe.py 0.9 2>&1 | grep -v amdgpu > $O/remesh_probe.txt
+# the kernels of the remesh probe (five un-instrumented calls + one bracketed = six remesh calls: rocprofv3 --stats summary, names cut)
+( export TMPDIR=/tmp; rm -rf /tmp/rp_rm; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_rm -o t -- python tools/ubench/remesh_probe.py 0.9 > /tmp/rp_rm.log 2>&1;
+  f=$(find /tmp/rp_rm -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/kstats_top.py "$f" 40 ) > $O/remesh_kernels.txt 2>&1
+python tools/recon_error_map.py 2>&1 | grep -v amdgpu > $O/recon_error_map.txt
 python tools/ubench/vh_probe.py 2>&1 | grep -v amdgpu | head -3 > $O/vh_probe.txt
 for r in gpu host; do REMESH=$r python tools/recon_trend.py 2>&1 | grep -v amdgpu > $O/recon_trend_$r.txt; done
 python -m drt_amd.reconstruct --name monkey --views 144 --res 1024 2>&1 | grep -v amdgpu > $O/recon_monkey_144views.txt

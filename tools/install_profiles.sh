@@ -19,3 +19,4 @@ for line in sys.stdin:
 cp $O/bench.json profiles/${P}_bench.json; cp $O/bench_fused.json profiles/${P}_fused_bench.json; cp $O/configs.txt profiles/${P}_configs.txt; cp $O/scaling_proxy.txt profiles/${P}_scaling_proxy.txt; cp $O/modes.txt profiles/${P}_modes.txt; cp $O/iter_bench.txt profiles/${P}_iter_bench.txt; cp $O/remesh_probe.txt profiles/${P}_remesh_probe.txt; cp $O/recon_trend_gpu.txt profiles/${P}_recon_trend_gpu_remesh.txt; cp $O/recon_trend_host.txt profiles/${P}_recon_trend_host_remesh.txt; cp $O/recon_monkey_144views.txt profiles/${P}_recon_monkey_144views.txt; cp $O/bench_2rank_gloo.json profiles/${P}_bench_2rank_gloo_one_gpu.json; cp $O/trace_repeat.txt profiles/${P}_trace_repeat.txt; cp $O/step_timeline_tight.txt profiles/${P}_step_timeline_tight.txt; cp $O/bind_det.txt profiles/${P}_bind_det.txt; cp $O/bench_8rank_gloo.json profiles/${P}_bench_8rank_gloo_one_gpu.json
 grep -v 'amdgpu.ids' $O/gputest.log | tail -n 40 > profiles/${P}_gputest.log
 cp $O/soak.txt profiles/${P}_soak.txt
+cp $O/remesh_kernels.txt profiles/${P}_remesh_kernels.txt; cp $O/recon_error_map.txt profiles/${P}_recon_error_map.txt
