@@ -104,7 +104,7 @@ class _Work:
         flag = torch.empty(3 * nf, dtype=torch.uint8, device=self.dev)
         _check(lib.drt_rm_split_mark(self.F.data_ptr(), nf, self.V.data_ptr(), float(max_len), flag.data_ptr(), _stream()))
         rank = torch.cumsum(flag, 0)                             # (int64)
-        mid = torch.empty(3 * nf, dtype=torch.long, device=self.dev)
+        mid = torch.full((3 * nf,), -1, dtype=torch.long, device=self.dev)      # (a slot nobody owns -- the hi -> lo side of a boundary edge, were the mesh open -- is left alone)
         count = torch.empty(nf, dtype=torch.long, device=self.dev)
         _check(lib.drt_rm_split_plan(self.F.data_ptr(), nf, vf_start.data_ptr(), vf_face.data_ptr(), flag.data_ptr(), rank.data_ptr(), nv,
                                      mid.data_ptr(), count.data_ptr(), _stream()))

@@ -208,3 +208,43 @@ def test_device_remesh_on_random_shapes(seed):
         assert abs(len(dev.faces) / len(host.faces) - 1) < 0.08, (len(dev.faces), len(host.faces))
         # (chords cut corners: an 80-face shape coarsened loses 15 % of its volume -- in both versions alike)
         assert abs(_volume(dev) / _volume(mesh) - 1) < 0.25 and abs(_volume(dev) / _volume(host) - 1) < 0.03, (_volume(dev) / _volume(mesh), _volume(host) / _volume(mesh))
+
+
+def test_the_device_ends_a_step_and_the_batch_size_does_not_matter(hand, monkeypatch):
+    """The rounds of a collapse / flip step are enqueued ROUND_BATCH at a time and the DEVICE decides when the step is over
+    (drt_rm_round_end): rounds of a batch that come after the end are no-ops, so any batch size gives the same mesh, the same number of
+    rounds that ran, and a handful of host read-backs per step instead of one per round."""
+    from drt_amd import remesh_gpu
+    results = {}
+    for batch in (1, 3, 4, 7):
+        monkeypatch.setattr(remesh_gpu, "ROUND_BATCH", batch)
+        trips = {"n": 0}
+        for meth in ("item", "tolist"):
+            orig = getattr(torch.Tensor, meth)
+
+            def counted(self, *a, _orig=orig, **k):
+                trips["n"] += 1
+                return _orig(self, *a, **k)
+            monkeypatch.setattr(torch.Tensor, meth, counted)
+        m, st = _gpu_remesh(hand, 4.0)
+        monkeypatch.undo()
+        results[batch] = (m, st, trips["n"])
+        assert st["collapse_unfinished"] == 0 and st["flip_unfinished"] == 0
+    ref, st_ref, trips_1 = results[1]
+    for batch, (m, st, trips) in results.items():
+        assert np.array_equal(m.vertices, ref.vertices) and np.array_equal(m.faces, ref.faces), batch
+        assert st == st_ref, (batch, st, st_ref)
+    assert results[4][2] < trips_1 and results[4][2] <= 3 * (3 + 3 * 2 + 2 + 2 * 3) + 2, (results[4][2], trips_1)
+
+
+def test_device_remesh_of_an_input_with_unused_vertices(hand):
+    """compact() sizes its output from the number of collapses (no read-back): vertices no face of the INPUT uses are counted once, up front."""
+    from drt_amd import remesh_gpu
+    from drt_amd.optix_mesh import optix_mesh
+    V = np.concatenate([hand.vertices, hand.vertices[:7] + 1000.0])           # seven stray vertices behind the mesh
+    surf = optix_mesh(0)
+    surf.update_mesh(torch.tensor(hand.faces, dtype=torch.int32, device="cuda"), torch.tensor(V, dtype=torch.float32, device="cuda"))
+    Vo, Fo = remesh_gpu.isotropic_remesh_gpu(torch.tensor(V, dtype=torch.float64, device="cuda"), torch.tensor(hand.faces, device="cuda"), 4.0, surface=surf)
+    ref, _ = _gpu_remesh(hand, 4.0)
+    assert int(Fo.max()) == len(Vo) - 1 and len(torch.unique(Fo)) == len(Vo)
+    assert np.array_equal(Vo.cpu().numpy().astype(np.float32), ref.vertices.astype(np.float32)) and np.array_equal(Fo.cpu().numpy(), ref.faces)
