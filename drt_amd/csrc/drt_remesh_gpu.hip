@@ -5,7 +5,7 @@
 // towards valence 6, tangential relaxation, projection onto the input surface) with sequential edge operations.  This file is its
 // data-parallel form: every edge operation is EVALUATED for all candidates at once against the mesh as it stands; the candidates
 // that pass claim the vertices they would write with an atomicMin of their priority (collapses: shorter length class first, a hash
-// inside a class; flips: edge index), and those that no higher priority contests anywhere in what they read or write are APPLIED --
+// inside a class; flips: a hash of the directed-edge slot), and those that no higher priority contests anywhere in what they read or write are APPLIED --
 // they share no face and do not change each other's premises, so they commute; the driver repeats evaluate / claim / apply on the
 // updated mesh until a round applies nothing.  Same acceptance rules as the host version (link condition, valence limits, consensus-normal fold
 // test, maximum edge length, MaxSurfDist through closest-point queries on the scene's tree), same split patterns, same
@@ -572,15 +572,15 @@ __global__ void k_rm_revert(double* __restrict__ V, const double* __restrict__ o
 // The end of an evaluate / claim / apply round, decided ON THE DEVICE (round 6: the driver used to read the round's count back -- one host
 // round trip per round, 76 us of an idle GPU each -- to decide whether to go on).  ctl int32 [8]: [0] live, [1] operations applied so far
 // (what the apply kernels add to), [2] that count at the end of the previous round, [3] the first round's count, [4] rounds that ran.
-// A step ends when a round applies nothing, or less than 1 / tail_cut of what its first round applied (and less than four); every kernel
+// A step ends when a round applies nothing, or less than 1 / tail_cut of what its first round applied (a small mesh -- a first round of less
+// than tail_cut operations -- goes on until a round applies nothing: its rounds cost next to nothing); every kernel
 // of a later round of the batch the driver enqueued ahead returns at once.
 __global__ void k_rm_round_end(int32_t* ctl, int tail_cut) {
     if (!ctl[0]) return;
     const int32_t n = ctl[1] - ctl[2];
     ctl[2] = ctl[1];
     if (ctl[4]++ == 0) ctl[3] = n;
-    const int32_t floor_ = ctl[3] / tail_cut > 4 ? ctl[3] / tail_cut : 4;
-    ctl[0] = n > 0 && n >= floor_ ? 1 : 0;
+    ctl[0] = n > 0 && n >= ctl[3] / tail_cut ? 1 : 0;
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }

@@ -409,7 +409,7 @@ int drt_rm_closest_near(drt_scene_t* s, const double* d_points, int64_t n, doubl
 int drt_rm_kill_faces(int64_t* d_faces, uint8_t* d_f_alive, int64_t n_faces, const int32_t* d_live, void* stream);
 /* Round termination on the device.  d_ctl int32 [8], preset {1, 0, 0, 0, 0, ...} at the start of a step: [0] live, [1] operations applied so
  * far (pass d_ctl + 1 as d_n_done of the apply calls), [2] / [3] the previous / the first round's figures, [4] rounds that ran.
- * drt_rm_round_end, enqueued after each round, clears [0] when the round applied nothing or fewer than max(4, first / tail_cut); every
+ * drt_rm_round_end, enqueued after each round, clears [0] when the round applied nothing or fewer than first / tail_cut; every
  * call above that takes d_live (= d_ctl, or NULL: always live) turns into a no-op from then on -- so the driver enqueues several rounds
  * ahead and reads d_ctl back once per batch instead of once per round. */
 int drt_rm_round_end(int32_t* d_ctl, int tail_cut, void* stream);

@@ -36,7 +36,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('views $v eager, 
 } > $O/modes.txt 2>&1
 # soak: the fuzz tests of the suite over seeds it does not hold (round 6: 1600-1899 / 700-759 / 1000-1149; with RECYCLE + binding defaults)
 { python tools/fuzz_soak.py 1600 300; python tools/fuzz_soak_path.py 700 60; python tools/fuzz_soak_raster.py 1000 150;
-  DRT_DETERMINISTIC=1 python tools/fuzz_soak_path.py 760 20; } 2>&1 | grep -v amdgpu > $O/soak.txt
+  DRT_DETERMINISTIC=1 python tools/fuzz_soak_path.py 760 20; python tools/fuzz_soak_remesh.py 6 80 | grep 'FAILED\|AssertionError\|failures'; } 2>&1 | grep -v amdgpu > $O/soak.txt
 python tools/ubench/trace_repeat.py 9 2>&1 | grep -v amdgpu > $O/trace_repeat.txt
 python tools/ubench/remesh_probe.py 0.9 2>&1 | grep -v amdgpu > $O/remesh_probe.txt
 # the kernels of the remesh probe (five un-instrumented calls + one bracketed = six remesh calls: rocprofv3 --stats summary, names cut)
