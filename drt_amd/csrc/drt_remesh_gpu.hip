@@ -144,31 +144,42 @@ __global__ void k_rm_vf_count(const int64_t* __restrict__ F, int64_t n_corners, 
     const int64_t v = F[c];
     if (v >= 0) atomicAdd(&count[v], 1);                       // (a killed face holds -1: in nobody's run)
 }
-// exclusive scan of count[0 .. n) -> start[0 .. n] by ONE workgroup (n = V is tens of thousands): tiles of 4096, four counts per thread
-// (coalesced), a shuffle scan inside each wavefront, the sixteen wavefront totals through LDS, the running total carried from tile to tile
+// exclusive scan of count[0 .. n) -> start[0 .. n] by ONE workgroup (n = V is tens of thousands): tiles of 8192, eight counts per thread
+// (two 16-byte loads), a 32-bit shuffle scan inside each wavefront, the sixteen wavefront totals through LDS, the running total carried
+// from tile to tile in 64 bits
 __global__ void __launch_bounds__(1024) k_rm_vf_scan(const int32_t* __restrict__ count, int64_t n, int64_t* __restrict__ start, const int32_t* __restrict__ live) {
     if (live && !*live) return;                   // (the step's rounds are over: drt_rm_round_end)
-    __shared__ int64_t wsum[16];
+    __shared__ int32_t wsum[2][16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     int64_t carry = 0;
-    for (int64_t base = 0; base < n; base += 4096) {
-        const int64_t i = base + 4 * t;
-        int32_t c[4];
-        for (int k = 0; k < 4; ++k) c[k] = i + k < n ? count[i + k] : 0;
-        const int64_t s = ((int64_t)c[0] + c[1]) + ((int64_t)c[2] + c[3]);
-        int64_t x = s;
+    int buf = 0;
+    for (int64_t base = 0; base < n; base += 8192, buf ^= 1) {
+        const int64_t i = base + 8 * t;
+        int32_t c[8];
+        if (i + 8 <= n) {
+            const int4 lo = *reinterpret_cast<const int4*>(count + i), hi = *reinterpret_cast<const int4*>(count + i + 4);
+            c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+        } else {
+            for (int k = 0; k < 8; ++k) c[k] = i + k < n ? count[i + k] : 0;
+        }
+        int32_t s = 0;
+        for (int k = 0; k < 8; ++k) s += c[k];            // (a tile holds at most 8192 x 3 F / V corners: far inside 32 bits)
+        int32_t x = s;
         for (int off = 1; off < 64; off <<= 1) {
-            const int64_t y = __shfl_up((long long)x, off);
+            const int32_t y = __shfl_up(x, off);
             if (lane >= off) x += y;
         }
-        if (lane == 63) wsum[w] = x;
-        __syncthreads();
-        int64_t before = 0, total = 0;
-        for (int j = 0; j < 16; ++j) { const int64_t q = wsum[j]; total += q; if (j < w) before += q; }
-        int64_t run = carry + before + x - s;
-        for (int k = 0; k < 4; ++k) if (i + k < n) { start[i + k] = run; run += c[k]; }
+        if (lane == 63) wsum[buf][w] = x;
+        __syncthreads();                                    // (one barrier per tile: the two halves of wsum alternate)
+        int32_t before = 0, total = 0;
+        for (int j = 0; j < 16; ++j) { const int32_t q = wsum[buf][j]; total += q; if (j < w) before += q; }
+        int64_t run = carry + before + (x - s);
+        if (i + 8 <= n) {
+            for (int k = 0; k < 8; ++k) { start[i + k] = run; run += c[k]; }
+        } else {
+            for (int k = 0; k < 8; ++k) if (i + k < n) { start[i + k] = run; run += c[k]; }
+        }
         carry += total;
-        __syncthreads();
     }
     if (t == 0) start[n] = carry;
 }
